@@ -1,0 +1,182 @@
+/* simt_hip.h -- C ABI of libsimt_hip.so, the gfx950 (MI355X) implementation of SimT's per-iteration hot path.
+ *
+ * The reference (CityU-AIM-Group/SimT) has no FFI layer: its hot path is a chain of torch ops called from
+ * Python (tools/trainV2_simt.py:326-436 through model/deeplab_multi.py and utils/loss.py).  Each entry point
+ * below replaces the torch op(s) cited next to it.  Conventions:
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (borrowed for the call),
+ *     except descriptors, which are host structs read during the call;
+ *   - `stream` is a hipStream_t; kernels are enqueued there and the call never synchronises;
+ *   - activations are NHWC ([B][H][W][C], C contiguous), dtype SIMT_BF16 or SIMT_F32 (fp32 = parity mode);
+ *   - master weights / gradients are fp32 in PyTorch OIHW layout (the reference's state_dict contract);
+ *   - return value: SIMT_OK or an error code; simt_last_error() gives the text (mirrors the reference's
+ *     assert-style failures, utils/loss.py:22-27).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ */
+#ifndef SIMT_HIP_H
+#define SIMT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* simt_stream_t; /* hipStream_t */
+
+enum { SIMT_OK = 0, SIMT_ERR_INVALID = 1, SIMT_ERR_LAUNCH = 2 };
+enum { SIMT_F32 = 0, SIMT_BF16 = 1 };
+#define SIMT_MAX_TAPS 36
+
+const char* simt_last_error(void);
+int simt_abi_version(void);
+
+/* ---- convolution: fprop / dgrad (implicit GEMM, MFMA) --------------------------------------------------
+ * y[m][n] = act( sum_{tap,ci} x[pixel(m)*stride + (dy,dx)[tap]][ci] * w[n][tap*Cin+ci] + bias[n] + res[m][n] )
+ * replaces nn.Conv2d forward (model/deeplab_multi.py:62,68,73,110,127,156; Classifier_Module.forward :115-119 is
+ * ONE call with the taps of both live dilations) and, with the dgrad-packed weight and negated taps, its dgrad.
+ * stats (optional): [ceil(M/128)][2][Cout] per-tile sum / sum-of-squares of the fp32 results (BatchNorm batch stats). */
+typedef struct {
+  const void* x;       /* [B][H][W][Cin] dtype_in */
+  const void* w;       /* [Npad][ntaps*Cin] dtype_in, K contiguous (simt_pack_weight) */
+  void* y;             /* [B*Ho*Wo][ldy] dtype_out */
+  const float* bias;   /* [Cout] or NULL */
+  const void* res;     /* [B*Ho*Wo][ldr] dtype_in, added before the activation, or NULL */
+  float* stats;        /* or NULL */
+  int32_t B, H, W, Cin, Ho, Wo, Cout;
+  int32_t Npad;        /* rows of w, multiple of tile_n */
+  int32_t Nstore;      /* columns written, multiple of 8, <= ldy */
+  int32_t ldy, ldr, stride, ntaps, relu;
+  int32_t dtype_in, dtype_out, tile_n; /* tile_n in {128,64,32} */
+  int16_t dy[SIMT_MAX_TAPS], dx[SIMT_MAX_TAPS];
+} simt_conv_desc;
+int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);
+
+/* ---- convolution: wgrad (split-K over pixels, transposed MFMA operands) -------------------------------
+ * slab[split][co][tap*Cin+ci] = sum_{m in split} dy[m][co] * x[pixel(m)*stride + (dy,dx)[tap]][ci]
+ * then simt_wgrad_reduce sums the splits in fixed order into the OIHW fp32 gradient.
+ * replaces the weight gradient autograd computes for the convs above (tools/trainV2_simt.py:428). */
+typedef struct {
+  const void* dy;      /* [B*Ho*Wo][ldd] dtype; channels >= Cd are ignored */
+  const void* x;       /* [B][H][W][Cin] dtype */
+  float* slab;         /* [nsplit][Cd][ntaps*Cin] fp32 workspace */
+  int32_t B, H, W, Cin, Ho, Wo, Cd, ldd, stride, ntaps, nsplit, dtype;
+  int16_t dy_[SIMT_MAX_TAPS], dx_[SIMT_MAX_TAPS];
+} simt_wgrad_desc;
+int simt_conv_wgrad(const simt_wgrad_desc* d, simt_stream_t stream);
+int simt_wgrad_reduce(const float* slab, float* dst, int nsplit, int Cd, int Ktot, int Cin, int co_off, int tap_off,
+                      int Cout, int RS, int accumulate, simt_stream_t stream);
+
+/* ---- weight packing / BN folding ------------------------------------------------------------------------ */
+int simt_pack_weight(const float* w, void* dst, int Cout, int Cin, int RS, int row_off, int tap_off, long ldk, int Ck,
+                     int mode, const float* cscale, int dtype, simt_stream_t stream);
+int simt_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale,
+                 float* shift, int C, simt_stream_t stream);
+
+/* ---- BatchNorm2d, train mode with frozen affine (model/deeplab_multi.py:63-76; quirk: batch stats are used and
+ * back-propagated through although gamma/beta never change) ------------------------------------------------ */
+int simt_bn_finalize(const float* part, int nblk, int C, long count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, float* mean, float* rstd,
+                     float* scale, float* shift, simt_stream_t stream);
+int simt_bn_apply(const void* y, const float* scale, const float* shift, const void* res, const void* y2,
+                  const float* scale2, const float* shift2, void* z, long M, int C, int relu, int dtype,
+                  simt_stream_t stream);
+typedef struct {
+  const void* dz;      /* [M][C] upstream gradient */
+  const void* z;       /* [M][C] block output (mask_mode 1) or NULL */
+  const void* y;       /* [M][C] raw conv output */
+  const float *mean, *rstd, *scale, *shift;
+  const void* y2;      /* second BN sharing the masked gradient (downsample branch) or NULL */
+  const float *mean2, *rstd2, *scale2;
+  float* part;         /* [simt_bn_bwd_nblk(M,C)][3][C] workspace */
+  float* coef;         /* [3][C] workspace */
+  void* dy;            /* [M][C] gradient wrt y */
+  void* dy2;           /* [M][C] gradient wrt y2 or NULL */
+  void* gout;          /* [M][C] masked gradient (may alias dz) or NULL */
+  int64_t M;
+  int32_t C, mask_mode, dtype; /* mask_mode: 0 none, 1 z>0, 2 y*scale+shift>0 */
+} simt_bn_bwd_desc;
+int simt_bn_bwd_nblk(long M, int C);
+int simt_bn_bwd(const simt_bn_bwd_desc* d, simt_stream_t stream);
+
+/* ---- stem: 7x7/s2 conv via im2col, BN+ReLU+MaxPool(3,2,1,ceil) (model/deeplab_multi.py:127-133,172-176) --- */
+int simt_im2col_stem(const float* x_nchw, void* A, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW,
+                     int stride, int pad, int ldk, int dtype, simt_stream_t stream);
+int simt_bn_relu_maxpool(const void* y, const float* scale, const float* shift, void* p, unsigned char* idx, int B,
+                         int H, int W, int C, int Hp, int Wp, int dtype, simt_stream_t stream);
+int simt_maxpool_bwd(const void* dp, const unsigned char* idx, void* da, int B, int H, int W, int C, int Hp, int Wp,
+                     int dtype, simt_stream_t stream);
+int simt_scatter_stride(const void* src, void* dx, int B, int H, int W, int C, int Ho, int Wo, int stride, int dtype,
+                        simt_stream_t stream);
+int simt_colsum(const void* src, float* out, long M, int ld, int C, int accumulate, int dtype, simt_stream_t stream);
+
+/* ---- fused SimT head: upsample + softmax + per-pixel loss terms + anchors (tools/trainV2_simt.py:351-409,
+ * :202-230 Placeholder_loss, utils/loss.py:14-40) ------------------------------------------------------- */
+typedef struct {
+  const float* pred1;   /* [B*h*w][ldp] fp32 low-res logits of the aux head (first Q channels) */
+  const float* pred2;   /* [B*h*w][ldp] main head */
+  const float* fixp;    /* [B*h*w][ldf] softmax probabilities of the frozen model's main head (first C channels) */
+  const int64_t* label; /* [B][H][W] noisy pseudo labels, 255 = ignore */
+  const float* T1;      /* [Q][C] transition matrices (simt_ntm_inner_loop / simt_sig_ntm) */
+  const float* T2;
+  float* part;          /* [simt_head_nblk][simt_head_part_floats] workspace */
+  void* keys;           /* [simt_head_keys_count] u64 workspace (zeroed by the call) */
+  float* hout;          /* [simt_head_hout_floats] result block, layout in csrc/head_loss.hip */
+  float* g1;            /* [2][B][H][w][QP] workspace (simt_head_grad) */
+  float* dpred1_f32;    /* [B*h*w][ld_f32] gradient outputs (any may be NULL) */
+  float* dpred2_f32;
+  void* dpred1_t;       /* [B*h*w][ld_t] gradient in grad_dtype for the dgrad GEMM (pad columns untouched) */
+  void* dpred2_t;
+  int32_t B, h, w, H, W, C, Q, ldp, ldf, QP, ld_f32, ld_t, grad_dtype;
+  float th_high, th_low, lambda_seg, lambda_place, gscale;
+} simt_head_desc;
+int simt_head_nblk(int B, int H, int W);
+int simt_head_part_floats(int Q, int C);
+int simt_head_hout_floats(int Q, int C);
+int simt_head_keys_count(void);
+int simt_softmax_rows(const float* in, int ldi, float* out, int ldo, long M, int C, simt_stream_t stream);
+int simt_head_loss(const simt_head_desc* d, simt_stream_t stream);
+int simt_head_grad(const simt_head_desc* d, simt_stream_t stream);
+
+/* ---- NTM micro-solver (model/deeplab_multi.py:244-286, tools/trainV2_simt.py:326-339,412-424,435-436) ---- */
+typedef struct {
+  float* ntm[2];        /* [Q][C] NTM1/NTM2 parameters */
+  float* w[2];          /* [Q][Q] sig_W weights (updated in place by Adam; diag := -1e4) */
+  float* ntm_grad[2];   /* [Q][C] accumulated (+=): the inner-loop leak, SURVEY quirk 3 */
+  float* w_m[2];        /* Adam exp_avg of w */
+  float* w_v[2];        /* Adam exp_avg_sq of w */
+  float* T_out[2];      /* [Q][C] T = sig_NTM() */
+  const float* class_dist; /* [C] */
+  int32_t Q, C, steps, step0; /* step0 = Adam steps already taken on w */
+  float lr, beta1, beta2, eps;
+} simt_ntm_inner_desc;
+int simt_ntm_inner_loop(const simt_ntm_inner_desc* d, simt_stream_t stream);
+typedef struct {
+  const float* ntm[2];
+  float* w[2];
+  float* ntm_grad[2];
+  const float* class_dist;
+  const float* hout;    /* from simt_head_loss */
+  float* lout;          /* [16]: total*gscale, loss_p1, loss_p2, loss_y1, loss_y2, Place, Convex, Volume, Anchor, vol_ok */
+  int32_t Q, C;
+  float lambda_seg, lambda_convex, lambda_volume, lambda_anchor, gscale;
+} simt_ntm_post_desc;
+int simt_ntm_post(const simt_ntm_post_desc* d, simt_stream_t stream);
+int simt_sig_ntm(const float* ntm, const float* class_dist, const float* dT, float* T_out, float* dN_out, int Q, int C,
+                 simt_stream_t stream);
+int simt_sig_w(float* weight, const float* dW, float* W_out, float* dweight_out, int Q, simt_stream_t stream);
+int simt_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                   int step, simt_stream_t stream);
+
+/* ---- fused SGD with duplicate-listing semantics (tools/trainV2_simt.py:296-297,434; model/deeplab_multi.py:194-237) --- */
+typedef struct {
+  const void* segs;    /* device array of {float* p; const float* g; float* buf; int64 n; int32 mult; int32 group} */
+  const void* chunks;  /* device int32 [nchunks][2]: (segment index, chunk index inside the segment) */
+  int32_t nchunks, chunk;
+  float lr[4], wd[4];  /* per param group */
+  float momentum, dampening;
+  int32_t first_step;  /* 1: momentum buffers are created (= d_p) like torch's first step */
+} simt_sgd_desc;
+int simt_sgd_multi(const simt_sgd_desc* d, simt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

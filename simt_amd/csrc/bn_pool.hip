@@ -1,0 +1,573 @@
+// Train-mode BatchNorm (frozen affine), ReLU, residual add, stem max-pool, im2col and weight packing.
+// All HBM-bound: NHWC rows are walked with 16-B (bf16) / 32-B (f32) vector accesses, 8 channels per lane.
+//
+// Replaces, on the reference path:
+//   nn.BatchNorm2d in train mode with requires_grad=False affine  (model/deeplab_multi.py:63-76,129-131,158-160)
+//   nn.ReLU(inplace) + residual add                                (model/deeplab_multi.py:81-101)
+//   nn.MaxPool2d(3, 2, 1, ceil_mode=True)                          (model/deeplab_multi.py:133)
+// and their autograd backward passes.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// bn_finalize: per-channel batch statistics from the conv epilogue partials.
+//   part [nblk][2][C] (sum, sum of squares)  ->  mean, rstd, scale = gamma*rstd, shift = beta - mean*scale
+//   running_mean/var updated like PyTorch (momentum 0.1, unbiased var), if running != null.
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* part, int nblk, int C, long count, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps, float* mean_out,
+                                   float* rstd_out, float* scale_out, float* shift_out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s1 += (double)part[((long)b * 2 + 0) * C + c];
+    s2 += (double)part[((long)b * 2 + 1) * C + c];
+  }
+  double mean = s1 / (double)count;
+  double var = s2 / (double)count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  float sc = g * rstd;
+  mean_out[c] = (float)mean;
+  rstd_out[c] = rstd;
+  scale_out[c] = sc;
+  shift_out[c] = bt - (float)mean * sc;
+  if (running_mean) {
+    double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+extern "C" int simt_bn_finalize(const float* part, int nblk, int C, long count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                                float* rstd, float* scale, float* shift, simt_stream_t stream) {
+  SIMT_CHECK(part && mean && rstd && scale && shift && C > 0 && nblk > 0);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, nblk, C, count,
+                     gamma, beta, running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bn_apply:  z = act( y*scale + shift  [+ res]  [+ y2*scale2 + shift2] )
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bn_apply_kernel(const T* y, const float* scale, const float* shift, const T* res, const T* y2,
+                                const float* scale2, const float* shift2, T* z, long nvec, int C, int relu) {
+  const int vpr = C >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % vpr) << 3;
+    float v[8], sc[8], sh[8];
+    load8(y + i * 8, v);
+    load8(scale + c, sc);
+    load8(shift + c, sh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+    if (res) {
+      float r[8];
+      load8(res + i * 8, r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+    if (y2) {
+      float r[8];
+      load8(y2 + i * 8, r);
+      load8(scale2 + c, sc);
+      load8(shift2 + c, sh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e] * sc[e] + sh[e];
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    }
+    store8(z + i * 8, v);
+  }
+}
+
+static inline int ew_grid(long nvec) {
+  long g = (nvec + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int simt_bn_apply(const void* y, const float* scale, const float* shift, const void* res, const void* y2,
+                             const float* scale2, const float* shift2, void* z, long M, int C, int relu, int dtype,
+                             simt_stream_t stream) {
+  SIMT_CHECK(y && scale && shift && z && C % 8 == 0);
+  long nvec = M * (C / 8);
+  if (dtype == SIMT_BF16)
+    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
+                       scale, shift, (const bf16_t*)res, (const bf16_t*)y2, scale2, shift2, (bf16_t*)z, nvec, C, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)y,
+                       scale, shift, (const float*)res, (const float*)y2, scale2, shift2, (float*)z, nvec, C, relu);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm backward (batch statistics, frozen affine).
+//   g   = dz * mask         mask: z>0 (mask_mode 1), y*scale+shift>0 (mask_mode 2), 1 (mask_mode 0)
+//   xh  = (y - mean)*rstd
+//   reduce:  S1 = sum g, S2 = sum g*xh [, S3 = sum g*xh2 for the downsample BN that shares g]
+//   apply :  dy = scale*(g - S1/M - xh*S2/M)
+// Deterministic: per-block partials [nblk][3][C], summed in fixed order by bn_bwd_finalize.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dz, const T* z, const T* y, const float* mean,
+                                                           const float* rstd, const float* scale, const float* shift,
+                                                           const T* y2, const float* mean2, const float* rstd2,
+                                                           float* part, long M, int C, int rows_per_block,
+                                                           int mask_mode) {
+  __shared__ float red[3][256][8 + 1];
+  const int vpr = C >> 3;              // vectors per row (<= 256)
+  const int rpar = 256 / vpr;          // rows processed in parallel
+  const int tid = threadIdx.x;
+  const int vc = tid % vpr, rl = tid / vpr;
+  const int c = vc << 3;
+  float mu[8], rs[8], sc[8], sh[8], mu2[8], rs2[8];
+  load8(mean + c, mu);
+  load8(rstd + c, rs);
+  if (mask_mode == 2) { load8(scale + c, sc); load8(shift + c, sh); }
+  if (y2) { load8(mean2 + c, mu2); load8(rstd2 + c, rs2); }
+  float s1[8], s2[8], s3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; s3[e] = 0.f; }
+  long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  if (rl < rpar) {
+    for (long r = r0 + rl; r < r1; r += rpar) {
+      long off = r * C + c;
+      float g[8], yv[8];
+      load8(dz + off, g);
+      load8(y + off, yv);
+      if (mask_mode == 1) {
+        float zv[8];
+        load8(z + off, zv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = zv[e] > 0.f ? g[e] : 0.f;
+      } else if (mask_mode == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = (yv[e] * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1[e] += g[e];
+        s2[e] += g[e] * ((yv[e] - mu[e]) * rs[e]);
+      }
+      if (y2) {
+        float y2v[8];
+        load8(y2 + off, y2v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s3[e] += g[e] * ((y2v[e] - mu2[e]) * rs2[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[0][tid][e] = s1[e]; red[1][tid][e] = s2[e]; red[2][tid][e] = s3[e]; }
+  __syncthreads();
+  // fixed-order reduction over the rpar row lanes
+  for (int idx = tid; idx < 3 * C; idx += 256) {
+    int j = idx / C, cc = idx - j * C;
+    int v = cc >> 3, e = cc & 7;
+    float s = 0.f;
+    for (int q = 0; q < rpar; ++q) s += red[j][q * vpr + v][e];
+    part[((long)blockIdx.x * 3 + j) * C + cc] = s;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* part, int nblk, int C, long count, float* coef) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 3 * C) return;
+  int j = idx / C, c = idx - j * C;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)part[((long)b * 3 + j) * C + c];
+  coef[j * C + c] = (float)(s / (double)count);
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* dz, const T* z, const T* y, const float* mean, const float* rstd,
+                                    const float* scale, const float* shift, const float* coef, const T* y2,
+                                    const float* mean2, const float* rstd2, const float* scale2, T* dy, T* dy2, T* gout,
+                                    long nvec, int C, int mask_mode) {
+  const int vpr = C >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % vpr) << 3;
+    float g[8], yv[8], mu[8], rs[8], sc[8], c1[8], c2[8];
+    load8(dz + i * 8, g);
+    load8(y + i * 8, yv);
+    load8(mean + c, mu);
+    load8(rstd + c, rs);
+    load8(scale + c, sc);
+    load8(coef + c, c1);
+    load8(coef + C + c, c2);
+    if (mask_mode == 1) {
+      float zv[8];
+      load8(z + i * 8, zv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = zv[e] > 0.f ? g[e] : 0.f;
+    } else if (mask_mode == 2) {
+      float sh[8];
+      load8(shift + c, sh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = (yv[e] * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
+    }
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = sc[e] * (g[e] - c1[e] - ((yv[e] - mu[e]) * rs[e]) * c2[e]);
+    store8(dy + i * 8, o);
+    if (y2) {
+      float y2v[8], c3[8];
+      load8(y2 + i * 8, y2v);
+      load8(mean2 + c, mu);
+      load8(rstd2 + c, rs);
+      load8(scale2 + c, sc);
+      load8(coef + 2 * C + c, c3);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = sc[e] * (g[e] - c1[e] - ((y2v[e] - mu[e]) * rs[e]) * c3[e]);
+      store8(dy2 + i * 8, o);
+    }
+    if (gout) store8(gout + i * 8, g);
+  }
+}
+
+static inline int bn_bwd_rows_per_block(long M, int C) {
+  int rpar = 256 / (C / 8);
+  long target_blocks = 2048;
+  long rpb = (M + target_blocks - 1) / target_blocks;
+  rpb = ((rpb + rpar - 1) / rpar) * rpar;
+  if (rpb < rpar * 4) rpb = rpar * 4;
+  return (int)rpb;
+}
+
+extern "C" int simt_bn_bwd_nblk(long M, int C) {
+  int rpb = bn_bwd_rows_per_block(M, C);
+  return (int)((M + rpb - 1) / rpb);
+}
+
+extern "C" int simt_bn_bwd(const simt_bn_bwd_desc* d, simt_stream_t stream) {
+  SIMT_CHECK(d && d->dz && d->y && d->mean && d->rstd && d->scale && d->part && d->coef && d->dy);
+  SIMT_CHECK(d->C % 8 == 0 && d->C / 8 <= 256 && 256 % (d->C / 8) == 0);
+  SIMT_CHECK(d->mask_mode != 1 || d->z);
+  SIMT_CHECK(d->mask_mode != 2 || d->shift);
+  SIMT_CHECK(!d->y2 || (d->mean2 && d->rstd2 && d->scale2 && d->dy2));
+  hipStream_t st = (hipStream_t)stream;
+  const int rpb = bn_bwd_rows_per_block(d->M, d->C);
+  const int nblk = (int)((d->M + rpb - 1) / rpb);
+  const long nvec = d->M * (d->C / 8);
+  if (d->dtype == SIMT_BF16) {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)d->dz,
+                       (const bf16_t*)d->z, (const bf16_t*)d->y, d->mean, d->rstd, d->scale, d->shift,
+                       (const bf16_t*)d->y2, d->mean2, d->rstd2, d->part, d->M, d->C, rpb, d->mask_mode);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, st, (const float*)d->dz,
+                       (const float*)d->z, (const float*)d->y, d->mean, d->rstd, d->scale, d->shift,
+                       (const float*)d->y2, d->mean2, d->rstd2, d->part, d->M, d->C, rpb, d->mask_mode);
+  }
+  SIMT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((3 * d->C + 255) / 256), dim3(256), 0, st, d->part, nblk, d->C, d->M,
+                     d->coef);
+  SIMT_LAUNCH_CHECK();
+  if (d->dtype == SIMT_BF16) {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)d->dz,
+                       (const bf16_t*)d->z, (const bf16_t*)d->y, d->mean, d->rstd, d->scale, d->shift, d->coef,
+                       (const bf16_t*)d->y2, d->mean2, d->rstd2, d->scale2, (bf16_t*)d->dy, (bf16_t*)d->dy2,
+                       (bf16_t*)d->gout, nvec, d->C, d->mask_mode);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)d->dz,
+                       (const float*)d->z, (const float*)d->y, d->mean, d->rstd, d->scale, d->shift, d->coef,
+                       (const float*)d->y2, d->mean2, d->rstd2, d->scale2, (float*)d->dy, (float*)d->dy2,
+                       (float*)d->gout, nvec, d->C, d->mask_mode);
+  }
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stem: im2col for the 7x7 stride-2 pad-3 conv on the NCHW fp32 image (Cin = 3 is not MFMA-shaped as an
+// implicit GEMM; the explicit [M][192] matrix is 0.2 GB at 4x768x768 and is read once by the GEMM).
+// Column order k = ci*KH*KW + r*KW + s (matches the OIHW flattening of the weight), zero-padded to ldk.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void im2col_stem_kernel(const float* x, T* A, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW,
+                                   int stride, int pad, int ldk, long nvec) {
+  const int vpr = ldk >> 3;
+  const int K = Cin * KH * KW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    int kv = (int)(i % vpr) << 3;
+    long m = i / vpr;
+    int ox = (int)(m % Wo);
+    long t = m / Wo;
+    int oy = (int)(t % Ho);
+    int b = (int)(t / Ho);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int k = kv + e;
+      float val = 0.f;
+      if (k < K) {
+        int ci = k / (KH * KW);
+        int rs = k - ci * KH * KW;
+        int r = rs / KW, s = rs - r * KW;
+        int iy = oy * stride - pad + r, ix = ox * stride - pad + s;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = x[(((long)b * Cin + ci) * H + iy) * W + ix];
+      }
+      v[e] = val;
+    }
+    store8(A + i * 8, v);
+  }
+}
+
+extern "C" int simt_im2col_stem(const float* x, void* A, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW,
+                                int stride, int pad, int ldk, int dtype, simt_stream_t stream) {
+  SIMT_CHECK(x && A && ldk % 8 == 0 && ldk >= Cin * KH * KW);
+  long nvec = (long)B * Ho * Wo * (ldk / 8);
+  if (dtype == SIMT_BF16)
+    hipLaunchKernelGGL(im2col_stem_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)A,
+                       B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, ldk, nvec);
+  else
+    hipLaunchKernelGGL(im2col_stem_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, x, (float*)A, B,
+                       Cin, H, W, Ho, Wo, KH, KW, stride, pad, ldk, nvec);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stem pool: p = maxpool3x3/s2/p1/ceil( relu(y*scale+shift) ), first-max index kept in a byte.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bn_relu_maxpool_kernel(const T* y, const float* scale, const float* shift, T* p, unsigned char* idx,
+                                       int B, int H, int W, int C, int Hp, int Wp, long nvec) {
+  const int vpr = C >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % vpr) << 3;
+    long m = i / vpr;
+    int px = (int)(m % Wp);
+    long t = m / Wp;
+    int py = (int)(t % Hp);
+    int b = (int)(t / Hp);
+    float sc[8], sh[8], best[8];
+    int bi[8];
+    load8(scale + c, sc);
+    load8(shift + c, sh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    bool first = true;
+    for (int r = 0; r < 3; ++r) {
+      int iy = py * 2 - 1 + r;
+      if (iy < 0 || iy >= H) continue;
+      for (int s = 0; s < 3; ++s) {
+        int ix = px * 2 - 1 + s;
+        if (ix < 0 || ix >= W) continue;
+        float v[8];
+        load8(y + (((long)b * H + iy) * W + ix) * C + c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float a = v[e] * sc[e] + sh[e];
+          a = a > 0.f ? a : 0.f;
+          // PyTorch: take if (val > max) || isnan(val); first element always taken
+          if (first || a > best[e] || a != a) { best[e] = a; bi[e] = r * 3 + s; }
+        }
+        first = false;
+      }
+    }
+    store8(p + i * 8, best);
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) packed |= (unsigned long long)(bi[e] & 0xff) << (8 * e);
+    *(unsigned long long*)(idx + i * 8) = packed;
+  }
+}
+
+// da[b,iy,ix,c] = sum over windows containing (iy,ix) whose argmax is (iy,ix) of dp
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* dp, const unsigned char* idx, T* da, int B, int H, int W, int C, int Hp,
+                                   int Wp, long nvec) {
+  const int vpr = C >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % vpr) << 3;
+    long m = i / vpr;
+    int ix = (int)(m % W);
+    long t = m / W;
+    int iy = (int)(t % H);
+    int b = (int)(t / H);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    int py0 = iy >> 1, px0 = ix >> 1;  // candidates: py in {floor(iy/2), floor(iy/2)+ (iy odd)}: windows start at 2py-1
+    for (int py = py0; py <= ((iy + 1) >> 1); ++py) {
+      if (py >= Hp) continue;
+      int r = iy - (py * 2 - 1);
+      if (r < 0 || r > 2) continue;
+      for (int px = px0; px <= ((ix + 1) >> 1); ++px) {
+        if (px >= Wp) continue;
+        int s = ix - (px * 2 - 1);
+        if (s < 0 || s > 2) continue;
+        long o = (((long)b * Hp + py) * Wp + px) * C + c;
+        unsigned long long packed = *(const unsigned long long*)(idx + o);
+        float g[8];
+        load8(dp + o, g);
+        int want = r * 3 + s;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if ((int)((packed >> (8 * e)) & 0xff) == want) acc[e] += g[e];
+      }
+    }
+    store8(da + i * 8, acc);
+  }
+}
+
+extern "C" int simt_bn_relu_maxpool(const void* y, const float* scale, const float* shift, void* p, unsigned char* idx,
+                                    int B, int H, int W, int C, int Hp, int Wp, int dtype, simt_stream_t stream) {
+  SIMT_CHECK(y && scale && shift && p && idx && C % 8 == 0);
+  long nvec = (long)B * Hp * Wp * (C / 8);
+  if (dtype == SIMT_BF16)
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)y, scale, shift, (bf16_t*)p, idx, B, H, W, C, Hp, Wp, nvec);
+  else
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)y, scale, shift, (float*)p, idx, B, H, W, C, Hp, Wp, nvec);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+extern "C" int simt_maxpool_bwd(const void* dp, const unsigned char* idx, void* da, int B, int H, int W, int C, int Hp,
+                                int Wp, int dtype, simt_stream_t stream) {
+  SIMT_CHECK(dp && idx && da && C % 8 == 0);
+  long nvec = (long)B * H * W * (C / 8);
+  if (dtype == SIMT_BF16)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dp, idx, (bf16_t*)da, B, H, W, C, Hp, Wp, nvec);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)dp,
+                       idx, (float*)da, B, H, W, C, Hp, Wp, nvec);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing: OIHW fp32 master -> K-contiguous GEMM operand in the compute dtype.
+//   mode 0 (fprop): dst[(row_off+co)*ldk + (tap_off+t)*Cin + ci] = w[co][ci][t] * (cscale ? cscale[co] : 1)
+//   mode 1 (dgrad): dst[ci*ldk + (tap_off+t)*Ck + row_off + co]  = w[co][ci][t]
+// Padding entries are never written (the buffer is zeroed once at allocation).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weight_kernel(const float* w, T* dst, int Cout, int Cin, int RS, int row_off, int tap_off, long ldk,
+                                   int Ck, int mode, const float* cscale, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int t = (int)(i % RS);
+    long r = i / RS;
+    int ci = (int)(r % Cin);
+    int co = (int)(r / Cin);
+    float v = w[i];
+    if (cscale) v *= cscale[co];
+    long o = mode == 0 ? (long)(row_off + co) * ldk + (long)(tap_off + t) * Cin + ci
+                       : (long)ci * ldk + (long)(tap_off + t) * Ck + row_off + co;
+    Elem<T>::st(dst + o, v);
+  }
+}
+
+extern "C" int simt_pack_weight(const float* w, void* dst, int Cout, int Cin, int RS, int row_off, int tap_off, long ldk,
+                                int Ck, int mode, const float* cscale, int dtype, simt_stream_t stream) {
+  SIMT_CHECK(w && dst && Cout > 0 && Cin > 0 && RS > 0);
+  long total = (long)Cout * Cin * RS;
+  if (dtype == SIMT_BF16)
+    hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst,
+                       Cout, Cin, RS, row_off, tap_off, ldk, Ck, mode, cscale, total);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, (float*)dst,
+                       Cout, Cin, RS, row_off, tap_off, ldk, Ck, mode, cscale, total);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+// eval-mode BN folding constants: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                               float* scale, float* shift, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float sc = gamma[c] / sqrtf(rv[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+extern "C" int simt_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                            float* scale, float* shift, int C, simt_stream_t stream) {
+  SIMT_CHECK(gamma && beta && rm && rv && scale && shift);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, gamma, beta, rm, rv, eps,
+                     scale, shift, C);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small glue used by the stride-2 1x1 dgrad and the head bias gradient.
+// ---------------------------------------------------------------------------------------------
+// dx[b, 2*oy, 2*ox, :] (+)= src[b,oy,ox,:]; every other pixel of dx is written with zero (or left, if add).
+template <typename T>
+__global__ void scatter_stride_kernel(const T* src, T* dx, int B, int H, int W, int C, int Ho, int Wo, int stride,
+                                      long nvec) {
+  const int vpr = C >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % vpr) << 3;
+    long m = i / vpr;
+    int ix = (int)(m % W);
+    long t = m / W;
+    int iy = (int)(t % H);
+    int b = (int)(t / H);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (iy % stride == 0 && ix % stride == 0) {
+      int oy = iy / stride, ox = ix / stride;
+      if (oy < Ho && ox < Wo) load8(src + (((long)b * Ho + oy) * Wo + ox) * C + c, v);
+    }
+    store8(dx + i * 8, v);
+  }
+}
+extern "C" int simt_scatter_stride(const void* src, void* dx, int B, int H, int W, int C, int Ho, int Wo, int stride,
+                                   int dtype, simt_stream_t stream) {
+  SIMT_CHECK(src && dx && C % 8 == 0);
+  long nvec = (long)B * H * W * (C / 8);
+  if (dtype == SIMT_BF16)
+    hipLaunchKernelGGL(scatter_stride_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, (bf16_t*)dx, B, H, W, C, Ho, Wo, stride, nvec);
+  else
+    hipLaunchKernelGGL(scatter_stride_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)src, (float*)dx, B, H, W, C, Ho, Wo, stride, nvec);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+// out[c] (+)= sum_m src[m*ld + c]   (bias gradients of the head convs; c < C <= 64, one block)
+template <typename T>
+__global__ __launch_bounds__(1024) void colsum_kernel(const T* src, float* out, long M, int ld, int C, int accumulate) {
+  __shared__ double red[1024];
+  int c = threadIdx.x % 64, lane_r = threadIdx.x / 64;  // 16 row lanes
+  double s = 0.0;
+  if (c < C)
+    for (long m = lane_r; m < M; m += 16) s += (double)Elem<T>::ld(src + m * ld + c);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < C) {
+    double t = 0.0;
+    for (int q = 0; q < 16; ++q) t += red[q * 64 + c];
+    out[c] = accumulate ? out[c] + (float)t : (float)t;
+  }
+}
+extern "C" int simt_colsum(const void* src, float* out, long M, int ld, int C, int accumulate, int dtype,
+                           simt_stream_t stream) {
+  SIMT_CHECK(src && out && C <= 64);
+  if (dtype == SIMT_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)src, out, M, ld,
+                       C, accumulate);
+  else
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)src, out, M, ld, C,
+                       accumulate);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}

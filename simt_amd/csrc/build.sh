@@ -1,0 +1,21 @@
+#!/bin/bash
+# Build libsimt_hip.so for gfx950 (in-tree; the .so is git-ignored but travels with gpurun snapshots).
+set -e
+cd "$(dirname "$0")"
+OUT=../libsimt_hip.so
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
+mkdir -p ../_build
+objs=()
+pids=()
+for f in *.hip; do
+  o=../_build/${f%.hip}.o
+  objs+=("$o")
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/simt_hip.h -nt "$o" ]; then
+    $HIPCC $FLAGS -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o $OUT
+echo "built $OUT"

@@ -1,0 +1,104 @@
+// Shared device helpers for the SimT gfx950 kernels.
+// Everything here is written for CDNA4 (wave64, MFMA, 160 KB LDS); there is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/simt_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf4v;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 8 consecutive elements <-> 8 floats (16 B for bf16, 32 B for f32)
+__device__ __forceinline__ void load8(const float* p, float* v) {
+  float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float* v) {
+  uint4 r = *(const uint4*)p;
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+  v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+  v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ void store8(float* p, const float* v) {
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+  *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float* v) {
+  uint4 r;
+  r.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  r.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  r.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+  r.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  *(uint4*)p = r;
+}
+
+// Blocks b and b+8 share an XCD (observed round-robin dispatch). Remap so that each XCD works on a
+// contiguous chunk of the tile list -> neighbouring tiles share operand panels in one L2. Bijective
+// for any nwg. Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// floor(m / d) for 0 <= m < 2^24 via a float reciprocal + one correction step each way.
+__device__ __forceinline__ void fast_divmod(int m, int d, float rcp, int& q, int& r) {
+  q = (int)((float)m * rcp);
+  r = m - q * d;
+  if (r < 0) { q--; r += d; }
+  if (r >= d) { q++; r -= d; }
+}
+
+const void* simt_zero_page(void);  // 4 KB of device zeros (conv_igemm.hip)
+
+#define SIMT_CHECK(cond)                                                        \
+  do {                                                                          \
+    if (!(cond)) {                                                              \
+      simt_set_error(__FILE__, __LINE__, #cond);                                \
+      return SIMT_ERR_INVALID;                                                  \
+    }                                                                           \
+  } while (0)
+#define SIMT_LAUNCH_CHECK()                                                     \
+  do {                                                                          \
+    hipError_t e__ = hipGetLastError();                                         \
+    if (e__ != hipSuccess) {                                                    \
+      simt_set_error(__FILE__, __LINE__, hipGetErrorString(e__));               \
+      return SIMT_ERR_LAUNCH;                                                   \
+    }                                                                           \
+  } while (0)
+void simt_set_error(const char* file, int line, const char* msg);

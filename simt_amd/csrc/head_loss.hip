@@ -1,0 +1,654 @@
+// Fused SimT head: bilinear(align_corners) upsample + softmax + every per-pixel loss term of one training
+// sub-iteration, and their gradients w.r.t. the LOW-RES logits and the transition matrices.
+//
+// Replaces the inline loss body of the reference, tools/trainV2_simt.py:351-409 (plus :202-230 Placeholder_loss and
+// utils/loss.py:14-40 CrossEntropy2d(is_softmax=False)): ~50 full-resolution eager passes (about 10 GB/step at
+// 4x768x768) become two streaming passes over the pixels that only read the low-res logits (L2-resident) and the
+// labels.  Per pixel everything (2 x Q logits, C fixed-model probabilities) lives in registers; Q = C+K <= 40.
+//
+//   pass1 : loss sums / counts, anchor arg-max keys (first-index tie-break), Exist bitmasks, dL_y/dT partials
+//   final : fixed-order reduction of the block partials (double), anchors gathered, scalar losses
+//   pass2 : per-pixel dL/d(upsampled logits) with the now-known 1/N factors, reduced along x inside the block
+//           (exact adjoint of the interpolation, gather form -> deterministic, no float atomics)
+//   yred  : reduction along y -> dL/d(low-res logits), written fp32 and in the conv dtype (padded for the dgrad GEMM)
+//
+// Quirks of the reference that are reproduced on purpose:
+//   * Placeholder_loss replaces the arg-max logit by -0.0 (not -1000)            (trainV2_simt.py:207-209)
+//   * Placeholder_y = argmax([0]*C ++ open logits) -> class 0 when all open logits <= 0   (:219-222)
+//   * CE over zero valid pixels gives NaN loss and zero gradient
+#include "common.h"
+#include <math.h>
+
+#define QMAX 40
+#define NSCAL 12
+
+struct HeadGeom {
+  int B, h, w, H, W, C, Q, ldp, ldf;
+  float sy, sx;  // (h-1)/(H-1), (w-1)/(W-1) computed in float like ATen area_pixel_compute_scale
+};
+
+struct Taps {
+  int o00, o01, o10, o11;  // pixel indices (b*h + iy)*w + ix
+  float wy0, wy1, wx0, wx1;
+};
+
+__device__ __forceinline__ Taps make_taps(const HeadGeom& g, int b, int y, int x) {
+  Taps t;
+  float fy = g.sy * (float)y, fx = g.sx * (float)x;
+  int iy0 = (int)fy, ix0 = (int)fx;
+  if (iy0 > g.h - 1) iy0 = g.h - 1;
+  if (ix0 > g.w - 1) ix0 = g.w - 1;
+  int iy1 = iy0 + (iy0 < g.h - 1 ? 1 : 0), ix1 = ix0 + (ix0 < g.w - 1 ? 1 : 0);
+  t.wy1 = fy - (float)iy0; t.wy0 = 1.f - t.wy1;
+  t.wx1 = fx - (float)ix0; t.wx0 = 1.f - t.wx1;
+  int base = b * g.h;
+  t.o00 = (base + iy0) * g.w + ix0; t.o01 = (base + iy0) * g.w + ix1;
+  t.o10 = (base + iy1) * g.w + ix0; t.o11 = (base + iy1) * g.w + ix1;
+  return t;
+}
+
+// ATen order: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
+__device__ __forceinline__ float lerp4(const Taps& t, float v00, float v01, float v10, float v11) {
+  return t.wy0 * (t.wx0 * v00 + t.wx1 * v01) + t.wy1 * (t.wx0 * v10 + t.wx1 * v11);
+}
+
+template <int NMAX>
+__device__ __forceinline__ void interp_vec(const float* src, int ld, int n, const Taps& t, float* out) {
+  const float* p00 = src + (long)t.o00 * ld;
+  const float* p01 = src + (long)t.o01 * ld;
+  const float* p10 = src + (long)t.o10 * ld;
+  const float* p11 = src + (long)t.o11 * ld;
+#pragma unroll
+  for (int j4 = 0; j4 < NMAX / 4; ++j4) {
+    if (j4 * 4 < n) {
+      float4 a = *(const float4*)(p00 + j4 * 4), b = *(const float4*)(p01 + j4 * 4);
+      float4 c = *(const float4*)(p10 + j4 * 4), d = *(const float4*)(p11 + j4 * 4);
+      out[j4 * 4 + 0] = lerp4(t, a.x, b.x, c.x, d.x);
+      out[j4 * 4 + 1] = lerp4(t, a.y, b.y, c.y, d.y);
+      out[j4 * 4 + 2] = lerp4(t, a.z, b.z, c.z, d.z);
+      out[j4 * 4 + 3] = lerp4(t, a.w, b.w, c.w, d.w);
+    }
+  }
+}
+
+struct HeadEval {
+  int arg;       // argmax_j v[j], first index
+  float vmax, sum, lse;
+  int pseudo1;   // arg if (arg < C && 1/sum > th_high) else 255
+  int yopen;     // Placeholder_y (valid only when pseudo1 != 255)
+  float m2, sum2, lse2;  // log-sum-exp of `predict` (arg-max logit replaced by -0.0)
+};
+
+__device__ __forceinline__ void eval_head(const float* v, int Q, int C, float th_high, HeadEval& e) {
+  float vmax = v[0];
+  int arg = 0;
+#pragma unroll
+  for (int j = 1; j < QMAX; ++j)
+    if (j < Q && v[j] > vmax) { vmax = v[j]; arg = j; }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < QMAX; ++j)
+    if (j < Q) sum += expf(v[j] - vmax);
+  e.arg = arg; e.vmax = vmax; e.sum = sum; e.lse = vmax + logf(sum);
+  float pm = 1.0f / sum;
+  e.pseudo1 = (arg < C && pm > th_high) ? arg : 255;
+  // predict = v with v[arg] := -0.0 ; Placeholder_y over [0]*C ++ predict[C:]
+  float best = 0.f;
+  int y = 0;
+  float m2 = 0.f;  // the replaced entry contributes the value 0
+#pragma unroll
+  for (int j = 0; j < QMAX; ++j)
+    if (j < Q && j != arg) {
+      m2 = fmaxf(m2, v[j]);
+      if (j >= C && v[j] > best) { best = v[j]; y = j; }
+    }
+  float s2 = expf(0.f - m2);
+#pragma unroll
+  for (int j = 0; j < QMAX; ++j)
+    if (j < Q && j != arg) s2 += expf(v[j] - m2);
+  e.yopen = y; e.m2 = m2; e.sum2 = s2; e.lse2 = m2 + logf(s2);
+}
+
+__device__ __forceinline__ unsigned int f32_ord(float f) {
+  unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_unord(unsigned int o) {
+  unsigned int u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+
+// --------------------------------------------------------------------------------------------------------
+// low-res softmax of the fixed model's logits (reference :354 softmax BEFORE interp_target)
+// --------------------------------------------------------------------------------------------------------
+__global__ void softmax_rows_kernel(const float* in, int ldi, float* out, int ldo, long M, int C) {
+  long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float* p = in + m * ldi;
+  float mx = p[0];
+  for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += expf(p[c] - mx);
+  float inv = 1.0f / s;
+  float* o = out + m * ldo;
+  for (int c = 0; c < C; ++c) o[c] = expf(p[c] - mx) * inv;
+  for (int c = C; c < ldo; ++c) o[c] = 0.f;
+}
+
+extern "C" int simt_softmax_rows(const float* in, int ldi, float* out, int ldo, long M, int C, simt_stream_t stream) {
+  SIMT_CHECK(in && out && C <= ldi && C <= ldo);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, ldi,
+                     out, ldo, M, C);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+// --------------------------------------------------------------------------------------------------------
+// pass 1
+// --------------------------------------------------------------------------------------------------------
+struct HeadArgs {
+  HeadGeom g;
+  const float* pred1;
+  const float* pred2;
+  const float* fixp;
+  const long long* label;
+  const float* T1;
+  const float* T2;
+  float th_high, th_low, lambda_seg, lambda_place;
+  float* part;                 // [nblk][NSCAL + 2*Q*C]
+  unsigned long long* keys;    // [2*QMAX] anchor keys, [2*QMAX .. 2*QMAX+1] exist masks (zeroed per call)
+  float* hout;                 // finalize output (see simt_head_out_* offsets)
+  float* g1;                   // [2][B][H][w][QP] x-reduced gradients
+  int QP;
+  float gscale;
+};
+
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void head_pass1_kernel(HeadArgs a) {
+  const HeadGeom g = a.g;
+  const int Q = g.Q, C = g.C, QC = Q * C;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sT = (float*)smem;                                        // [2][QC]
+  float* sdT = sT + 2 * QC;                                        // [4 waves][2][QC]
+  unsigned long long* sKey = (unsigned long long*)(sdT + 8 * QC);  // [2*QMAX]  (8-byte aligned: QC even or not -> pad)
+  sKey = (unsigned long long*)(((uintptr_t)sKey + 7) & ~(uintptr_t)7);
+  unsigned long long* sEx = sKey + 2 * QMAX;                       // [2]
+  float* sRed = (float*)(sEx + 2);                                 // [4][NSCAL]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < QC; i += 256) { sT[i] = a.T1[i]; sT[QC + i] = a.T2[i]; }
+  for (int i = tid; i < 8 * QC; i += 256) sdT[i] = 0.f;
+  if (tid < 2 * QMAX) sKey[tid] = 0ull;
+  if (tid < 2) sEx[tid] = 0ull;
+  __syncthreads();
+
+  float acc[NSCAL];
+#pragma unroll
+  for (int i = 0; i < NSCAL; ++i) acc[i] = 0.f;
+
+  const long P = (long)g.B * g.H * g.W;
+  const long ngroups = (P + 255) / 256;
+  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const long p = grp * 256 + tid;
+    const bool live = p < P;
+    int b = 0, y = 0, x = 0;
+    if (live) {
+      x = (int)(p % g.W);
+      long t = p / g.W;
+      y = (int)(t % g.H);
+      b = (int)(t / g.H);
+    }
+    Taps tp = make_taps(g, b, y, x);
+    // ---- fixed-model posterior -> confidence label (reference :354-361)
+    float fm = -INFINITY;
+    int fa = 0;
+    {
+      float buf[QMAX];
+      interp_vec<QMAX>(a.fixp, g.ldf, C, tp, buf);
+#pragma unroll
+      for (int c = 0; c < QMAX; ++c)
+        if (c < C && buf[c] > fm) { fm = buf[c]; fa = c; }
+    }
+    int conf = (fm > a.th_high) ? fa : 255;
+    if (fm < a.th_low) conf = C;
+
+    float v2[QMAX], v1[QMAX];
+    interp_vec<QMAX>(a.pred2, g.ldp, Q, tp, v2);
+    interp_vec<QMAX>(a.pred1, g.ldp, Q, tp, v1);
+    HeadEval e2, e1;
+    eval_head(v2, Q, C, a.th_high, e2);
+    eval_head(v1, Q, C, a.th_high, e1);
+    if (conf == C) conf = (e2.arg >= C) ? e2.arg : 255;  // reference :387-393
+
+    long long lab = live ? a.label[p] : 255;
+    const bool lab_ok = live && lab >= 0 && lab != 255 && lab < C;
+    const int labi = lab_ok ? (int)lab : 0;
+
+    if (live) {
+      if (conf != 255) {
+        float l1 = 0.f, l2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j)
+          if (j == conf) { l1 = e1.lse - v1[j]; l2 = e2.lse - v2[j]; }
+        acc[0] += l1; acc[1] += l2; acc[8] += 1.f;
+      }
+      if (e1.pseudo1 != 255) {
+        acc[2] += e1.lse - e1.vmax;
+        float vy = 0.f;
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j)
+          if (j == e1.yopen && j != e1.arg) vy = v1[j];
+        acc[4] += e1.lse2 - vy;
+        acc[9] += 1.f;
+      }
+      if (e2.pseudo1 != 255) {
+        acc[3] += e2.lse - e2.vmax;
+        float vy = 0.f;
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j)
+          if (j == e2.yopen && j != e2.arg) vy = v2[j];
+        acc[5] += e2.lse2 - vy;
+        acc[10] += 1.f;
+      }
+    }
+    // ---- noise-posterior loss: q = softmax(v); r = q.T[:,label]  (reference :402-409, utils/loss.py:29-39)
+    float r1 = 0.f, r2 = 0.f;
+    const float inv1 = 1.0f / e1.sum, inv2 = 1.0f / e2.sum;
+    if (lab_ok) {
+#pragma unroll
+      for (int j = 0; j < QMAX; ++j)
+        if (j < Q) {
+          r1 += (expf(v1[j] - e1.vmax) * inv1) * sT[j * C + labi];
+          r2 += (expf(v2[j] - e2.vmax) * inv2) * sT[QC + j * C + labi];
+        }
+      acc[6] += -logf(r1);
+      acc[7] += -logf(r2);
+      acc[11] += 1.f;
+    }
+    // dL_y/dT partials: per wave, one label value at a time (labels are spatially coherent -> few rounds)
+    {
+      unsigned long long todo = __ballot(lab_ok);
+      while (todo) {
+        int src = __ffsll((long long)todo) - 1;
+        int c = __shfl(labi, src, 64);
+        bool mine = lab_ok && labi == c;
+        todo &= ~__ballot(mine);
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j)
+          if (j < Q) {
+            float c1 = mine ? (expf(v1[j] - e1.vmax) * inv1) / r1 : 0.f;
+            float c2 = mine ? (expf(v2[j] - e2.vmax) * inv2) / r2 : 0.f;
+            c1 = wave_sum(c1);
+            c2 = wave_sum(c2);
+            if (lane == 0) {
+              sdT[(wave * 2 + 0) * QC + j * C + c] += c1;
+              sdT[(wave * 2 + 1) * QC + j * C + c] += c2;
+            }
+          }
+      }
+    }
+    // ---- anchors: arg-max over all pixels of each channel's upsampled logit (first index), Exist masks (:375-384)
+    {
+      unsigned long long ex1 = live ? (1ull << e1.arg) : 0ull, ex2 = live ? (1ull << e2.arg) : 0ull;
+      ex1 = wave_or_u64(ex1);
+      ex2 = wave_or_u64(ex2);
+      if (lane == 0) { atomicOr(&sEx[0], ex1); atomicOr(&sEx[1], ex2); }
+#pragma unroll
+      for (int j = 0; j < QMAX; ++j)
+        if (j < Q) {
+          float a1 = live ? v1[j] : -INFINITY, a2 = live ? v2[j] : -INFINITY;
+          float m1 = wave_max_f(a1), m2 = wave_max_f(a2);
+          unsigned long long b1 = __ballot(live && a1 == m1), b2 = __ballot(live && a2 == m2);
+          if (lane == 0) {
+            if (b1) {
+              long pp = grp * 256 + wave * 64 + (__ffsll((long long)b1) - 1);
+              unsigned long long key = ((unsigned long long)f32_ord(m1) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)pp);
+              atomicMax(&sKey[j], key);
+            }
+            if (b2) {
+              long pp = grp * 256 + wave * 64 + (__ffsll((long long)b2) - 1);
+              unsigned long long key = ((unsigned long long)f32_ord(m2) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)pp);
+              atomicMax(&sKey[QMAX + j], key);
+            }
+          }
+        }
+    }
+  }
+
+  // ---- block reduction (fixed order) and publication
+#pragma unroll
+  for (int i = 0; i < NSCAL; ++i) {
+    float s = wave_sum(acc[i]);
+    if (lane == 0) sRed[wave * NSCAL + i] = s;
+  }
+  __syncthreads();
+  float* part = a.part + (long)blockIdx.x * (NSCAL + 2 * QC);
+  if (tid < NSCAL) part[tid] = sRed[tid] + sRed[NSCAL + tid] + sRed[2 * NSCAL + tid] + sRed[3 * NSCAL + tid];
+  for (int i = tid; i < 2 * QC; i += 256)
+    part[NSCAL + i] = sdT[i] + sdT[2 * QC + i] + sdT[4 * QC + i] + sdT[6 * QC + i];
+  if (tid < 2 * QMAX && sKey[tid]) atomicMax(&a.keys[tid], sKey[tid]);
+  if (tid < 2 && sEx[tid]) atomicOr(&a.keys[2 * QMAX + tid], sEx[tid]);
+}
+
+// --------------------------------------------------------------------------------------------------------
+// finalize (one block)
+// hout layout (floats):
+//   [0] loss_p1 [1] loss_p2 [2] place1 [3] place2 [4] loss_y1 [5] loss_y2
+//   [6] N_p [7] N_known1 [8] N_known2 [9] N_y [10] known1 [11] known2 [12] unk1 [13] unk2
+//   [16            .. 16+QC)      anchor1 [Q][C]      [16+QC   .. 16+2QC)  anchor2
+//   [16+2QC        .. +QMAX)      exist1 (0/1)        then exist2 [QMAX]
+//   [16+2QC+2QMAX  .. +QMAX)      anchor pixel index1 (as float bits of int), then index2 [QMAX]
+//   [16+2QC+4QMAX  .. +QC)        dTy1 = d(loss_y1)/dT1 (mean-normalised, unweighted), then dTy2
+// --------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_finalize_kernel(HeadArgs a, int nblk) {
+  const HeadGeom g = a.g;
+  const int Q = g.Q, C = g.C, QC = Q * C;
+  const int tid = threadIdx.x;
+  __shared__ double sc[NSCAL];
+  const int stride = NSCAL + 2 * QC;
+  if (tid < NSCAL) {
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)a.part[(long)b * stride + tid];
+    sc[tid] = s;
+  }
+  __syncthreads();
+  float* o = a.hout;
+  const double Np = sc[8], Nk1 = sc[9], Nk2 = sc[10], Ny = sc[11];
+  if (tid == 0) {
+    o[0] = (float)(sc[0] / Np); o[1] = (float)(sc[1] / Np);
+    float k1 = (float)(sc[2] / Nk1), k2 = (float)(sc[3] / Nk2), u1 = (float)(sc[4] / Nk1), u2 = (float)(sc[5] / Nk2);
+    o[2] = k1 + a.lambda_place * u1; o[3] = k2 + a.lambda_place * u2;
+    o[4] = (float)(sc[6] / Ny); o[5] = (float)(sc[7] / Ny);
+    o[6] = (float)Np; o[7] = (float)Nk1; o[8] = (float)Nk2; o[9] = (float)Ny;
+    o[10] = k1; o[11] = k2; o[12] = u1; o[13] = u2; o[14] = 0.f; o[15] = 0.f;
+  }
+  // dTy: -(1/Ny) * sum_p [label=c] q_j / r
+  float* dTy = o + 16 + 2 * QC + 4 * QMAX;
+  for (int i = tid; i < 2 * QC; i += 256) {
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)a.part[(long)b * stride + NSCAL + i];
+    dTy[i] = (float)(-s / Ny);
+  }
+  // anchors
+  float* ex = o + 16 + 2 * QC;
+  float* ai = ex + 2 * QMAX;
+  const unsigned long long e1 = a.keys[2 * QMAX], e2 = a.keys[2 * QMAX + 1];
+  if (tid < 2 * QMAX) {
+    int hd = tid / QMAX, j = tid % QMAX;
+    ex[tid] = (j < Q && (((hd ? e2 : e1) >> j) & 1ull)) ? 1.f : 0.f;
+    unsigned long long key = a.keys[tid];
+    int pidx = (j < Q) ? (int)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull)) : 0;
+    ai[tid] = __int_as_float(pidx);
+  }
+  for (int i = tid; i < 2 * QC; i += 256) {
+    int hd = i / QC, r = i % QC, j = r / C, c = r % C;
+    unsigned long long key = a.keys[hd * QMAX + j];
+    long p = (long)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
+    int x = (int)(p % g.W);
+    long t = p / g.W;
+    int y = (int)(t % g.H);
+    int b = (int)(t / g.H);
+    if (b >= g.B) { b = 0; y = 0; x = 0; }
+    Taps tp = make_taps(g, b, y, x);
+    const float* f = a.fixp;
+    o[16 + i] = lerp4(tp, f[(long)tp.o00 * g.ldf + c], f[(long)tp.o01 * g.ldf + c], f[(long)tp.o10 * g.ldf + c],
+                      f[(long)tp.o11 * g.ldf + c]);
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------
+// pass 2: gradient w.r.t. the upsampled logits, reduced along x inside the block.  One block per (b, y) row.
+// --------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_pass2_kernel(HeadArgs a) {
+  const HeadGeom g = a.g;
+  const int Q = g.Q, C = g.C, QC = Q * C, QP = a.QP;
+  const int GP = Q + 1;  // LDS pitch of the per-pixel gradient rows
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sT = (float*)smem;          // [2][QC]
+  float* sG = sT + 2 * QC;           // [2][256][GP]
+  float* sAcc = sG + 2 * 256 * GP;   // [2][w][Q]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / g.H, y = blockIdx.x % g.H;
+  for (int i = tid; i < QC; i += 256) { sT[i] = a.T1[i]; sT[QC + i] = a.T2[i]; }
+  for (int i = tid; i < 2 * g.w * Q; i += 256) sAcc[i] = 0.f;
+  const float* o = a.hout;
+  const float Np = o[6], Nk1 = o[7], Nk2 = o[8], Ny = o[9];
+  const float gs = a.gscale;
+  const float gp1 = gs * a.lambda_seg / Np, gp2 = gs / Np;
+  const float gk1 = gs * a.lambda_seg / Nk1, gk2 = gs / Nk2;
+  const float gu1 = gk1 * a.lambda_place, gu2 = gk2 * a.lambda_place;
+  const float gy1 = gs * a.lambda_seg / Ny, gy2 = gs / Ny;
+  __syncthreads();
+
+  for (int x0 = 0; x0 < g.W; x0 += 256) {
+    const int x = x0 + tid;
+    const bool live = x < g.W;
+    {
+      Taps tp = make_taps(g, b, y, live ? x : 0);
+      float fm = -INFINITY;
+      int fa = 0;
+      {
+        float buf[QMAX];
+        interp_vec<QMAX>(a.fixp, g.ldf, C, tp, buf);
+#pragma unroll
+        for (int c = 0; c < QMAX; ++c)
+          if (c < C && buf[c] > fm) { fm = buf[c]; fa = c; }
+      }
+      int conf = (fm > a.th_high) ? fa : 255;
+      if (fm < a.th_low) conf = C;
+      float v2[QMAX], v1[QMAX];
+      interp_vec<QMAX>(a.pred2, g.ldp, Q, tp, v2);
+      interp_vec<QMAX>(a.pred1, g.ldp, Q, tp, v1);
+      HeadEval e2, e1;
+      eval_head(v2, Q, C, a.th_high, e2);
+      eval_head(v1, Q, C, a.th_high, e1);
+      if (conf == C) conf = (e2.arg >= C) ? e2.arg : 255;
+      long long lab = live ? a.label[((long)b * g.H + y) * g.W + x] : 255;
+      const bool lab_ok = live && lab >= 0 && lab != 255 && lab < C;
+      const int labi = lab_ok ? (int)lab : 0;
+      const float inv1 = 1.0f / e1.sum, inv2 = 1.0f / e2.sum;
+      float r1 = 0.f, r2 = 0.f;
+      if (lab_ok) {
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j)
+          if (j < Q) {
+            r1 += (expf(v1[j] - e1.vmax) * inv1) * sT[j * C + labi];
+            r2 += (expf(v2[j] - e2.vmax) * inv2) * sT[QC + j * C + labi];
+          }
+      }
+      const float is1 = 1.0f / e1.sum2, is2 = 1.0f / e2.sum2;
+#pragma unroll
+      for (int j = 0; j < QMAX; ++j)
+        if (j < Q) {
+          float q1 = expf(v1[j] - e1.vmax) * inv1, q2 = expf(v2[j] - e2.vmax) * inv2;
+          float G1 = 0.f, G2 = 0.f;
+          if (live) {
+            if (conf != 255) {
+              float oh = (j == conf) ? 1.f : 0.f;
+              G1 += gp1 * (q1 - oh);
+              G2 += gp2 * (q2 - oh);
+            }
+            if (e1.pseudo1 != 255) {
+              G1 += gk1 * (q1 - ((j == e1.arg) ? 1.f : 0.f));
+              if (j != e1.arg) G1 += gu1 * (expf(v1[j] - e1.m2) * is1 - ((j == e1.yopen) ? 1.f : 0.f));
+            }
+            if (e2.pseudo1 != 255) {
+              G2 += gk2 * (q2 - ((j == e2.arg) ? 1.f : 0.f));
+              if (j != e2.arg) G2 += gu2 * (expf(v2[j] - e2.m2) * is2 - ((j == e2.yopen) ? 1.f : 0.f));
+            }
+            if (lab_ok) {
+              G1 += gy1 * (q1 - q1 * sT[j * C + labi] / r1);
+              G2 += gy2 * (q2 - q2 * sT[QC + j * C + labi] / r2);
+            }
+          }
+          sG[(0 * 256 + tid) * GP + j] = G1;
+          sG[(1 * 256 + tid) * GP + j] = G2;
+        }
+    }
+    __syncthreads();
+    // x-reduction: out[hd][xl][j] += sum_x wgt(x, xl) * G[hd][x][j]
+    const int xend = min(x0 + 256, g.W);
+    for (int idx = tid; idx < 2 * g.w * Q; idx += 256) {
+      int hd = idx / (g.w * Q);
+      int r = idx - hd * g.w * Q;
+      int xl = r / Q, j = r - xl * Q;
+      int lo, hi;
+      if (g.sx > 0.f) {
+        lo = (int)floorf((float)(xl - 1) / g.sx) - 1;
+        hi = (int)ceilf((float)(xl + 1) / g.sx) + 1;
+      } else {
+        lo = 0; hi = g.W - 1;
+      }
+      lo = max(lo, x0);
+      hi = min(hi, xend - 1);
+      float s = 0.f;
+      for (int xx = lo; xx <= hi; ++xx) {
+        float fx = g.sx * (float)xx;
+        int i0 = (int)fx;
+        if (i0 > g.w - 1) i0 = g.w - 1;
+        int i1 = i0 + (i0 < g.w - 1 ? 1 : 0);
+        float l1 = fx - (float)i0, l0 = 1.f - l1;
+        float wgt = (i0 == xl ? l0 : 0.f) + (i1 == xl ? l1 : 0.f);
+        if (wgt != 0.f) s += wgt * sG[(hd * 256 + (xx - x0)) * GP + j];
+      }
+      sAcc[idx] += s;
+    }
+    __syncthreads();
+  }
+  // write g1[hd][b][y][xl][0..QP)
+  for (int idx = tid; idx < 2 * g.w * QP; idx += 256) {
+    int hd = idx / (g.w * QP);
+    int r = idx - hd * g.w * QP;
+    int xl = r / QP, j = r - xl * QP;
+    float v = (j < Q) ? sAcc[(hd * g.w + xl) * Q + j] : 0.f;
+    a.g1[((((long)hd * g.B + b) * g.H + y) * g.w + xl) * QP + j] = v;
+  }
+}
+
+// y-reduction: d[hd][b][yl][xl][j] = sum_y wgt(y, yl) * g1[hd][b][y][xl][j]
+template <typename T>
+__global__ void head_yreduce_kernel(const float* g1, float* d32_1, float* d32_2, T* dT_1, T* dT_2, HeadGeom g, int QP,
+                                    int ldo32, int ldoT, long total) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int j = (int)(idx % QP);
+  long t = idx / QP;
+  int xl = (int)(t % g.w); t /= g.w;
+  int yl = (int)(t % g.h); t /= g.h;
+  int b = (int)(t % g.B);
+  int hd = (int)(t / g.B);
+  int lo, hi;
+  if (g.sy > 0.f) {
+    lo = (int)floorf((float)(yl - 1) / g.sy) - 1;
+    hi = (int)ceilf((float)(yl + 1) / g.sy) + 1;
+  } else {
+    lo = 0; hi = g.H - 1;
+  }
+  lo = max(lo, 0);
+  hi = min(hi, g.H - 1);
+  float s = 0.f;
+  for (int yy = lo; yy <= hi; ++yy) {
+    float fy = g.sy * (float)yy;
+    int i0 = (int)fy;
+    if (i0 > g.h - 1) i0 = g.h - 1;
+    int i1 = i0 + (i0 < g.h - 1 ? 1 : 0);
+    float l1 = fy - (float)i0, l0 = 1.f - l1;
+    float wgt = (i0 == yl ? l0 : 0.f) + (i1 == yl ? l1 : 0.f);
+    if (wgt != 0.f) s += wgt * g1[((((long)hd * g.B + b) * g.H + yy) * g.w + xl) * QP + j];
+  }
+  long m = ((long)b * g.h + yl) * g.w + xl;
+  float* d32 = hd ? d32_2 : d32_1;
+  T* dT = hd ? dT_2 : dT_1;
+  if (d32 && j < ldo32) d32[m * ldo32 + j] = s;
+  if (dT && j < ldoT) Elem<T>::st(dT + m * ldoT + j, s);
+}
+
+static size_t pass1_lds(int Q, int C) {
+  size_t QC = (size_t)Q * C;
+  return (2 * QC + 8 * QC) * 4 + 8 + (2 * QMAX + 2) * 8 + 4 * NSCAL * 4 + 16;
+}
+static size_t pass2_lds(int Q, int C, int w) {
+  size_t QC = (size_t)Q * C;
+  return (2 * QC + 2 * 256 * (size_t)(Q + 1) + 2 * (size_t)w * Q) * 4;
+}
+
+static int fill_args(const simt_head_desc* d, HeadArgs& a) {
+  SIMT_CHECK(d && d->pred1 && d->pred2 && d->fixp && d->label && d->T1 && d->T2 && d->part && d->keys && d->hout);
+  SIMT_CHECK(d->Q <= QMAX && d->C < d->Q + 1 && d->C >= 1 && d->Q <= 64);
+  SIMT_CHECK(d->ldp % 4 == 0 && d->ldf % 4 == 0 && d->ldp >= ((d->Q + 3) / 4) * 4 && d->ldf >= ((d->C + 3) / 4) * 4);
+  SIMT_CHECK((long)d->B * d->H * d->W < 0xFFFFFFFFl);
+  a.g.B = d->B; a.g.h = d->h; a.g.w = d->w; a.g.H = d->H; a.g.W = d->W; a.g.C = d->C; a.g.Q = d->Q;
+  a.g.ldp = d->ldp; a.g.ldf = d->ldf;
+  a.g.sy = d->H > 1 ? (float)(d->h - 1) / (float)(d->H - 1) : 0.f;
+  a.g.sx = d->W > 1 ? (float)(d->w - 1) / (float)(d->W - 1) : 0.f;
+  a.pred1 = d->pred1; a.pred2 = d->pred2; a.fixp = d->fixp; a.label = (const long long*)d->label;
+  a.T1 = d->T1; a.T2 = d->T2;
+  a.th_high = d->th_high; a.th_low = d->th_low; a.lambda_seg = d->lambda_seg; a.lambda_place = d->lambda_place;
+  a.part = d->part; a.keys = (unsigned long long*)d->keys; a.hout = d->hout; a.g1 = d->g1; a.QP = d->QP;
+  a.gscale = d->gscale;
+  return SIMT_OK;
+}
+
+extern "C" int simt_head_nblk(int B, int H, int W) {
+  long P = (long)B * H * W;
+  long n = (P + 255) / 256;
+  if (n > 2048) n = 2048;
+  return (int)n;
+}
+extern "C" int simt_head_part_floats(int Q, int C) { return NSCAL + 2 * Q * C; }
+extern "C" int simt_head_hout_floats(int Q, int C) { return 16 + 4 * Q * C + 4 * QMAX; }
+extern "C" int simt_head_keys_count(void) { return 2 * QMAX + 2; }
+
+// losses (pass 1 + finalize).  keys must be zeroed by this call: done here with a memset node on the stream.
+extern "C" int simt_head_loss(const simt_head_desc* d, simt_stream_t stream) {
+  HeadArgs a;
+  int rc = fill_args(d, a);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = simt_head_nblk(d->B, d->H, d->W);
+  (void)hipMemsetAsync(d->keys, 0, (2 * QMAX + 2) * sizeof(unsigned long long), st);
+  size_t lds1 = pass1_lds(d->Q, d->C);
+  hipLaunchKernelGGL(head_pass1_kernel, dim3(nblk), dim3(256), lds1, st, a);
+  SIMT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, st, a, nblk);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+// gradients w.r.t. the low-res logits (pass 2 + y reduction); needs hout from simt_head_loss of the same inputs.
+extern "C" int simt_head_grad(const simt_head_desc* d, simt_stream_t stream) {
+  HeadArgs a;
+  int rc = fill_args(d, a);
+  if (rc) return rc;
+  SIMT_CHECK(d->g1 && d->QP >= d->Q);
+  hipStream_t st = (hipStream_t)stream;
+  size_t lds2 = pass2_lds(d->Q, d->C, d->w);
+  SIMT_CHECK(lds2 <= 160 * 1024);
+  static size_t lds2_set = 0;
+  if (lds2 > lds2_set) {
+    (void)hipFuncSetAttribute((const void*)head_pass2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    lds2_set = lds2;
+  }
+  hipLaunchKernelGGL(head_pass2_kernel, dim3(d->B * d->H), dim3(256), lds2, st, a);
+  SIMT_LAUNCH_CHECK();
+  long total = 2l * d->B * d->h * d->w * d->QP;
+  unsigned grid = (unsigned)((total + 255) / 256);
+  if (d->grad_dtype == SIMT_BF16)
+    hipLaunchKernelGGL(head_yreduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, d->g1, d->dpred1_f32, d->dpred2_f32,
+                       (bf16_t*)d->dpred1_t, (bf16_t*)d->dpred2_t, a.g, d->QP, d->ld_f32, d->ld_t, total);
+  else
+    hipLaunchKernelGGL(head_yreduce_kernel<float>, dim3(grid), dim3(256), 0, st, d->g1, d->dpred1_f32, d->dpred2_f32,
+                       (float*)d->dpred1_t, (float*)d->dpred2_t, a.g, d->QP, d->ld_f32, d->ld_t, total);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}

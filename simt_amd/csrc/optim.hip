@@ -1,0 +1,60 @@
+// Fused multi-tensor SGD (momentum, weight decay) with the reference's duplicate-parameter semantics.
+//
+// Replaces torch.optim.SGD(model.optim_parameters(args)).step() (tools/trainV2_simt.py:296-297,434).  The reference's
+// parameter generator lists every layer3/layer4 tensor 3-4 times (model/deeplab_multi.py:211-217) and
+// the optimiser it ran (single-tensor loop, foreach=False) applies the update once PER LISTING, sequentially, sharing one
+// momentum buffer.  Here the `mult` listings of an element are replayed in registers, so the whole 43 M-parameter
+// update is ONE launch instead of ~3000.
+#include "common.h"
+
+struct SgdSeg {
+  float* p;
+  const float* g;
+  float* buf;
+  long long n;
+  int mult;
+  int group;
+};
+
+struct SgdArgs {
+  const SgdSeg* segs;
+  const int* chunks;  // [nchunks][2] = (segment, first element / chunk)
+  int nchunks, chunk;
+  float lr[4], wd[4];
+  float momentum, dampening;
+  int first_step;
+};
+
+__global__ __launch_bounds__(256) void sgd_multi_kernel(SgdArgs a) {
+  const int ch = blockIdx.x;
+  const SgdSeg s = a.segs[a.chunks[2 * ch]];
+  const long long start = (long long)a.chunks[2 * ch + 1] * a.chunk;
+  long long end = start + a.chunk;
+  if (end > s.n) end = s.n;
+  const float lr = a.lr[s.group], wd = a.wd[s.group];
+  for (long long i = start + threadIdx.x; i < end; i += 256) {
+    float p = s.p[i], g = s.g[i];
+    float buf = a.first_step ? 0.f : s.buf[i];
+    for (int r = 0; r < s.mult; ++r) {
+      float d = wd != 0.f ? g + wd * p : g;
+      if (a.momentum != 0.f) {
+        buf = a.first_step ? d : a.momentum * buf + (1.f - a.dampening) * d;
+        d = buf;
+      }
+      p = p - lr * d;
+    }
+    s.p[i] = p;
+    if (a.momentum != 0.f) s.buf[i] = buf;
+  }
+}
+
+extern "C" int simt_sgd_multi(const simt_sgd_desc* d, simt_stream_t stream) {
+  SIMT_CHECK(d && d->segs && d->chunks && d->nchunks > 0 && d->chunk > 0);
+  SgdArgs a;
+  a.segs = (const SgdSeg*)d->segs; a.chunks = (const int*)d->chunks; a.nchunks = d->nchunks; a.chunk = d->chunk;
+  for (int i = 0; i < 4; ++i) { a.lr[i] = d->lr[i]; a.wd[i] = d->wd[i]; }
+  a.momentum = d->momentum; a.dampening = d->dampening; a.first_step = d->first_step;
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3(d->nchunks), dim3(256), 0, (hipStream_t)stream, a);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}

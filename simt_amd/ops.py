@@ -1,0 +1,189 @@
+"""Tensor-level wrappers over the C ABI (include/simt_hip.h).
+
+PyTorch is used only for device memory and streams: every function takes CUDA(=HIP) tensors, passes raw device
+pointers + the current stream to libsimt_hip.so and returns without synchronising.  No function here computes
+anything in torch; there is no CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+F32, BF16 = L.SIMT_F32, L.SIMT_BF16
+
+
+def dt_code(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "libsimt_hip needs device tensors (no CPU fallback)"
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def conv_taps(R, S, dil, pad):
+    """(dy, dx) per filter tap, r-major."""
+    return [(r * dil - pad, s * dil - pad) for r in range(R) for s in range(S)]
+
+
+def _fill_taps(arr_dy, arr_dx, taps):
+    assert len(taps) <= L.MAX_TAPS
+    for i, (a, b) in enumerate(taps):
+        arr_dy[i] = a
+        arr_dx[i] = b
+
+
+def pick_tile_n(cout):
+    if cout <= 32:
+        return 32
+    if cout <= 64:
+        return 64
+    return 128
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+def packed_rows(cout, tile_n=None):
+    tile_n = tile_n or pick_tile_n(cout)
+    return round_up(cout, tile_n)
+
+
+def make_conv_desc(x, w, y, *, B, H, W, Cin, Ho, Wo, Cout, taps, stride=1, bias=None, res=None, stats=None, relu=False,
+                   Npad=None, Nstore=None, ldy=None, ldr=None, tile_n=None):
+    d = L.ConvDesc()
+    tile_n = tile_n or pick_tile_n(Cout)
+    d.x, d.w, d.y = _p(x), _p(w), _p(y)
+    d.bias, d.res, d.stats = _p(bias), _p(res), _p(stats)
+    d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, Cin, Ho, Wo, Cout
+    d.Npad = Npad if Npad is not None else round_up(Cout, tile_n)
+    d.ldy = ldy if ldy is not None else y.shape[-1]
+    d.Nstore = Nstore if Nstore is not None else min(round_up(Cout, 8), d.ldy)
+    d.ldr = ldr if ldr is not None else (res.shape[-1] if res is not None else 0)
+    d.stride, d.ntaps, d.relu = stride, len(taps), int(relu)
+    d.dtype_in, d.dtype_out, d.tile_n = dt_code(x.dtype), dt_code(y.dtype), tile_n
+    _fill_taps(d.dy, d.dx, taps)
+    return d
+
+
+def conv_fprop_desc(d):
+    L.call("simt_conv_fprop", C.byref(d), stream_ptr())
+
+
+def make_wgrad_desc(dy, x, slab, *, B, H, W, Cin, Ho, Wo, Cd, taps, stride=1, nsplit=1, ldd=None):
+    d = L.WgradDesc()
+    d.dy, d.x, d.slab = _p(dy), _p(x), _p(slab)
+    d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cd = B, H, W, Cin, Ho, Wo, Cd
+    d.ldd = ldd if ldd is not None else dy.shape[-1]
+    d.stride, d.ntaps, d.nsplit, d.dtype = stride, len(taps), nsplit, dt_code(x.dtype)
+    _fill_taps(d.dy_, d.dx_, taps)
+    return d
+
+
+def conv_wgrad_desc(d):
+    L.call("simt_conv_wgrad", C.byref(d), stream_ptr())
+
+
+def wgrad_nsplit(M, Cd, Ktot, dtype, target_wg=768):
+    tiles = ((Cd + 127) // 128) * ((Ktot + 127) // 128)
+    bp = 64 if dtype == torch.bfloat16 else 32
+    max_split = max(1, M // (bp * 4))
+    return int(max(1, min(max_split, (target_wg + tiles - 1) // tiles, 64)))
+
+
+def wgrad_reduce(slab, dst, *, nsplit, Cd, Ktot, Cin, co_off, tap_off, Cout, RS, accumulate=False):
+    L.call("simt_wgrad_reduce", _p(slab), _p(dst), nsplit, Cd, Ktot, Cin, co_off, tap_off, Cout, RS, int(accumulate),
+           stream_ptr())
+
+
+def pack_weight(w, dst, *, Cout, Cin, RS, row_off=0, tap_off=0, ldk, Ck=0, mode=0, cscale=None):
+    """w: OIHW fp32 master ([Cout][Cin][RS]); dst: packed operand in its own dtype (zero-initialised by caller)."""
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    L.call("simt_pack_weight", _p(w), _p(dst), Cout, Cin, RS, row_off, tap_off, ldk, Ck, mode, _p(cscale),
+           dt_code(dst.dtype), stream_ptr())
+
+
+def bn_fold(gamma, beta, rm, rv, eps, scale, shift):
+    L.call("simt_bn_fold", _p(gamma), _p(beta), _p(rm), _p(rv), eps, _p(scale), _p(shift), gamma.numel(), stream_ptr())
+
+
+def bn_finalize(part, nblk, Cn, count, gamma, beta, running_mean, running_var, momentum, eps, mean, rstd, scale, shift):
+    L.call("simt_bn_finalize", _p(part), nblk, Cn, count, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+           momentum, eps, _p(mean), _p(rstd), _p(scale), _p(shift), stream_ptr())
+
+
+def bn_apply(y, scale, shift, z, *, M, Cn, relu=True, res=None, y2=None, scale2=None, shift2=None):
+    L.call("simt_bn_apply", _p(y), _p(scale), _p(shift), _p(res), _p(y2), _p(scale2), _p(shift2), _p(z), M, Cn,
+           int(relu), dt_code(y.dtype), stream_ptr())
+
+
+def bn_bwd_nblk(M, Cn):
+    return L.load().simt_bn_bwd_nblk(M, Cn)
+
+
+def make_bn_bwd_desc(*, dz, y, mean, rstd, scale, shift, part, coef, dy, M, Cn, mask_mode, z=None, y2=None, mean2=None,
+                     rstd2=None, scale2=None, dy2=None, gout=None):
+    d = L.BnBwdDesc()
+    d.dz, d.z, d.y = _p(dz), _p(z), _p(y)
+    d.mean, d.rstd, d.scale, d.shift = _p(mean), _p(rstd), _p(scale), _p(shift)
+    d.y2, d.mean2, d.rstd2, d.scale2 = _p(y2), _p(mean2), _p(rstd2), _p(scale2)
+    d.part, d.coef, d.dy, d.dy2, d.gout = _p(part), _p(coef), _p(dy), _p(dy2), _p(gout)
+    d.M, d.C, d.mask_mode, d.dtype = M, Cn, mask_mode, dt_code(y.dtype)
+    return d
+
+
+def bn_bwd_desc(d):
+    L.call("simt_bn_bwd", C.byref(d), stream_ptr())
+
+
+def im2col_stem(x_nchw, A, *, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, ldk):
+    assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
+    L.call("simt_im2col_stem", _p(x_nchw), _p(A), B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, ldk, dt_code(A.dtype),
+           stream_ptr())
+
+
+def bn_relu_maxpool(y, scale, shift, p, idx, *, B, H, W, Cn, Hp, Wp):
+    L.call("simt_bn_relu_maxpool", _p(y), _p(scale), _p(shift), _p(p), _p(idx), B, H, W, Cn, Hp, Wp, dt_code(y.dtype),
+           stream_ptr())
+
+
+def maxpool_bwd(dp, idx, da, *, B, H, W, Cn, Hp, Wp):
+    L.call("simt_maxpool_bwd", _p(dp), _p(idx), _p(da), B, H, W, Cn, Hp, Wp, dt_code(dp.dtype), stream_ptr())
+
+
+def scatter_stride(src, dx, *, B, H, W, Cn, Ho, Wo, stride):
+    L.call("simt_scatter_stride", _p(src), _p(dx), B, H, W, Cn, Ho, Wo, stride, dt_code(src.dtype), stream_ptr())
+
+
+def colsum(src, out, *, M, ld, Cn, accumulate=False):
+    L.call("simt_colsum", _p(src), _p(out), M, ld, Cn, int(accumulate), dt_code(src.dtype), stream_ptr())
+
+
+def softmax_rows(src, ldi, out, ldo, M, Cn):
+    L.call("simt_softmax_rows", _p(src), ldi, _p(out), ldo, M, Cn, stream_ptr())
+
+
+def adam_step(p, g, m, v, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, step):
+    L.call("simt_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, stream_ptr())
+
+
+def sig_ntm(ntm, class_dist, T_out=None, dT=None, dN_out=None):
+    Q, Cn = ntm.shape
+    L.call("simt_sig_ntm", _p(ntm), _p(class_dist), _p(dT), _p(T_out), _p(dN_out), Q, Cn, stream_ptr())
+
+
+def sig_w(weight, W_out=None, dW=None, dweight_out=None):
+    Q = weight.shape[0]
+    L.call("simt_sig_w", _p(weight), _p(dW), _p(W_out), _p(dweight_out), Q, stream_ptr())

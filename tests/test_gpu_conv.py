@@ -1,0 +1,154 @@
+"""GPU parity of the implicit-GEMM conv kernels (fprop / dgrad / wgrad) through the C ABI.
+
+Checker: torch CPU fp32 conv2d + autograd (oracle/ops_ref.py), same seeded inputs.
+Tolerances: fp32 mode 2e-5 relative to max|ref| (accumulation-order noise only);
+bf16 mode compares against the fp32 reference evaluated on bf16-rounded inputs, 1e-2 relative to max|ref|.
+"""
+import pytest
+import torch
+
+from oracle import ops_ref
+from simt_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # B, H, W, Cin, Cout, k, dil, stride
+    (2, 13, 13, 64, 64, 1, 1, 1),
+    (2, 13, 17, 128, 256, 1, 1, 1),
+    (1, 23, 21, 64, 64, 3, 1, 1),
+    (2, 17, 19, 128, 128, 3, 2, 1),
+    (1, 19, 19, 64, 192, 3, 4, 1),
+    (2, 21, 21, 256, 128, 1, 1, 2),
+    (3, 9, 9, 64, 24, 3, 2, 1),
+]
+
+
+def _tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1e-2
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fprop_dgrad_wgrad(dev, dtype, case):
+    B, H, W, Cin, Cout, k, dil, stride = case
+    g = torch.Generator().manual_seed(1234 + Cin + Cout + k + dil)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+    pad = dil * (k // 2)
+    xq = x.to(dtype).float()
+    wq = w.to(dtype).float()
+    y_ref, dx_ref, dw_ref, dy = ops_ref.conv2d_fwd_bwd(xq, wq, stride=stride, pad=pad, dil=dil, seed=7, grad_dtype=dtype)
+    Ho, Wo = y_ref.shape[2], y_ref.shape[3]
+    taps = ops.conv_taps(k, k, dil, pad)
+
+    x_d = x.permute(0, 2, 3, 1).contiguous().to(dev, dtype)
+    tile = ops.pick_tile_n(Cout)
+    Npad = ops.round_up(Cout, tile)
+    wp = torch.zeros(Npad, len(taps) * Cin, device=dev, dtype=dtype)
+    ops.pack_weight(w.to(dev).contiguous(), wp, Cout=Cout, Cin=Cin, RS=k * k, ldk=len(taps) * Cin, mode=0)
+    ldy = ops.round_up(Cout, 8)
+    y_d = torch.full((B, Ho, Wo, ldy), float("nan"), device=dev, dtype=dtype)
+    M = B * Ho * Wo
+    mt = (M + 127) // 128
+    stats = torch.zeros(mt, 2, Cout, device=dev)
+    d = ops.make_conv_desc(x_d, wp, y_d, B=B, H=H, W=W, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, taps=taps, stride=stride,
+                           stats=stats)
+    ops.conv_fprop_desc(d)
+    torch.cuda.synchronize()
+    y_got = y_d[..., :Cout].float().cpu().permute(0, 3, 1, 2)
+    assert _rel(y_got, y_ref) < _tol(dtype), f"fprop rel err {_rel(y_got, y_ref)}"
+    # BN statistics partials (computed from the fp32 accumulators)
+    s = stats.sum(0).cpu()
+    s1_ref = y_ref.sum(dim=(0, 2, 3))
+    s2_ref = (y_ref * y_ref).sum(dim=(0, 2, 3))
+    assert _rel(s[0], s1_ref) < 5 * _tol(dtype) + 1e-4
+    assert _rel(s[1], s2_ref) < 5 * _tol(dtype)
+
+    # ---- wgrad
+    dy_d = dy.permute(0, 2, 3, 1).contiguous().to(dev, dtype)
+    Cd = ops.round_up(Cout, 8)
+    if Cd != Cout:
+        pad_t = torch.zeros(B, Ho, Wo, Cd, device=dev, dtype=dtype)
+        pad_t[..., :Cout] = dy_d
+        dy_d = pad_t
+    Ktot = len(taps) * Cin
+    for nsplit in (1, 3):
+        slab = torch.full((nsplit, Cd, Ktot), float("nan"), device=dev)
+        wd = ops.make_wgrad_desc(dy_d, x_d, slab, B=B, H=H, W=W, Cin=Cin, Ho=Ho, Wo=Wo, Cd=Cd, taps=taps, stride=stride,
+                                 nsplit=nsplit)
+        ops.conv_wgrad_desc(wd)
+        dw_d = torch.full((Cout, Cin, k, k), float("nan"), device=dev)
+        ops.wgrad_reduce(slab, dw_d, nsplit=nsplit, Cd=Cd, Ktot=Ktot, Cin=Cin, co_off=0, tap_off=0, Cout=Cout, RS=k * k)
+        torch.cuda.synchronize()
+        assert _rel(dw_d.cpu(), dw_ref) < _tol(dtype), f"wgrad rel err {_rel(dw_d.cpu(), dw_ref)} nsplit={nsplit}"
+
+    # ---- dgrad (stride 1 only; the stride-2 1x1 goes through scatter_stride)
+    esz = 2 if dtype == torch.bfloat16 else 4
+    Ck = ops.round_up(Cout, 128 // esz)
+    tile_b = ops.pick_tile_n(Cin)
+    wb = torch.zeros(ops.round_up(Cin, tile_b), len(taps) * Ck, device=dev, dtype=dtype)
+    ops.pack_weight(w.to(dev).contiguous(), wb, Cout=Cout, Cin=Cin, RS=k * k, ldk=len(taps) * Ck, Ck=Ck, mode=1)
+    dyk = torch.zeros(B, Ho, Wo, Ck, device=dev, dtype=dtype)
+    dyk[..., :Cout] = dy.permute(0, 2, 3, 1).to(dev, dtype)
+    ntaps = [(-a, -b) for (a, b) in taps]
+    if stride == 1:
+        dx_d = torch.full((B, H, W, Cin), float("nan"), device=dev, dtype=dtype)
+        dd = ops.make_conv_desc(dyk, wb, dx_d, B=B, H=Ho, W=Wo, Cin=Ck, Ho=H, Wo=W, Cout=Cin, taps=ntaps, stride=1)
+        ops.conv_fprop_desc(dd)
+    else:
+        dxs = torch.full((B, Ho, Wo, Cin), float("nan"), device=dev, dtype=dtype)
+        dd = ops.make_conv_desc(dyk, wb, dxs, B=B, H=Ho, W=Wo, Cin=Ck, Ho=Ho, Wo=Wo, Cout=Cin, taps=ntaps, stride=1)
+        ops.conv_fprop_desc(dd)
+        dx_d = torch.full((B, H, W, Cin), float("nan"), device=dev, dtype=dtype)
+        ops.scatter_stride(dxs, dx_d, B=B, H=H, W=W, Cn=Cin, Ho=Ho, Wo=Wo, stride=stride)
+    torch.cuda.synchronize()
+    dx_got = dx_d.float().cpu().permute(0, 3, 1, 2)
+    assert _rel(dx_got, dx_ref) < _tol(dtype), f"dgrad rel err {_rel(dx_got, dx_ref)}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_epilogue_bias_res_relu_and_aspp_taps(dev, dtype):
+    """Classifier_Module: two dilated 3x3 branches summed in ONE launch (18 taps), bias, Cout=22 -> fp32 logits."""
+    B, H, W, Cin, Cout = 2, 15, 15, 128, 22
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w6 = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    w12 = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    b6 = torch.randn(Cout, generator=g)
+    b12 = torch.randn(Cout, generator=g)
+    xq = x.to(dtype).float()
+    y_ref = ops_ref.conv2d(xq, w6.to(dtype).float(), b6, pad=6, dil=6) + ops_ref.conv2d(xq, w12.to(dtype).float(), b12, pad=12, dil=12)
+    taps = ops.conv_taps(3, 3, 6, 6) + ops.conv_taps(3, 3, 12, 12)
+    x_d = x.permute(0, 2, 3, 1).contiguous().to(dev, dtype)
+    wp = torch.zeros(32, 18 * Cin, device=dev, dtype=dtype)
+    ops.pack_weight(w6.to(dev), wp, Cout=Cout, Cin=Cin, RS=9, tap_off=0, ldk=18 * Cin)
+    ops.pack_weight(w12.to(dev), wp, Cout=Cout, Cin=Cin, RS=9, tap_off=9, ldk=18 * Cin)
+    bias = (b6 + b12).to(dev)
+    y_d = torch.full((B, H, W, 32), float("nan"), device=dev, dtype=torch.float32)
+    d = ops.make_conv_desc(x_d, wp, y_d, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=Cout, taps=taps, bias=bias, tile_n=32,
+                           Nstore=32)
+    ops.conv_fprop_desc(d)
+    torch.cuda.synchronize()
+    got = y_d[..., :Cout].cpu().permute(0, 3, 1, 2)
+    assert _rel(got, y_ref) < _tol(dtype)
+    assert torch.all(y_d[..., Cout:] == 0)  # padded logits columns are exact zeros
+
+    # residual + relu epilogue
+    w1 = torch.randn(64, Cin, 1, 1, generator=g) * 0.1
+    r = torch.randn(B, 64, H, W, generator=g)
+    bb = torch.randn(64, generator=g)
+    ref = torch.relu(ops_ref.conv2d(xq, w1.to(dtype).float(), bb) + r.to(dtype).float())
+    wp1 = torch.zeros(64, Cin, device=dev, dtype=dtype)
+    ops.pack_weight(w1.to(dev), wp1, Cout=64, Cin=Cin, RS=1, ldk=Cin)
+    r_d = r.permute(0, 2, 3, 1).contiguous().to(dev, dtype)
+    z_d = torch.empty(B, H, W, 64, device=dev, dtype=dtype)
+    d = ops.make_conv_desc(x_d, wp1, z_d, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=64, taps=[(0, 0)], bias=bb.to(dev),
+                           res=r_d, relu=True)
+    ops.conv_fprop_desc(d)
+    torch.cuda.synchronize()
+    assert _rel(z_d.float().cpu().permute(0, 3, 1, 2), ref) < _tol(dtype)
