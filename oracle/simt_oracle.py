@@ -1,0 +1,480 @@
+"""CPU restatement of SimT's per-iteration hot path -- TEST INFRASTRUCTURE, never imported by the product.
+
+Plain PyTorch-CPU fp32, functional style (parameters live in dicts keyed like the reference's state_dict).
+Every function cites the reference lines it restates (paths relative to /root/reference).  The restatement is
+pinned against the reference itself: oracle/gen_golden.py imports the reference in the build container, drives both
+on identical seeded inputs and writes tests/golden/*.npz; tests/test_oracle_golden.py re-checks this file against
+those vectors on every run (no GPU needed).  Known reference quirks are reproduced on purpose.
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+LAYERS = (3, 4, 23, 3)
+IMG_MEAN = (104.00698793, 116.66876762, 122.67891434)  # tools/trainV2_simt.py:34 (BGR)
+# ClassDist/ClassDist_bapa.npy (float64 [19], public data file of the reference; model/deeplab_multi.py:255)
+CLASS_DIST_BAPA = None  # filled lazily from tests/golden/class_dist_bapa.npy
+
+
+# ------------------------------------------------------------------------------------------------------------
+# architecture description (model/deeplab_multi.py:122-167)
+# ------------------------------------------------------------------------------------------------------------
+def block_specs(layers=LAYERS):
+    """[(name, inplanes, planes, stride, dilation, has_downsample)] for layer1..layer4."""
+    out = []
+    inpl = 64
+    for li, (planes, nblk, stride, dil) in enumerate(zip((64, 128, 256, 512), layers, (1, 2, 1, 1), (1, 1, 2, 4)), 1):
+        for b in range(nblk):
+            out.append((f"layer{li}.{b}", inpl, planes, stride if b == 0 else 1, dil, b == 0))
+            inpl = planes * 4
+    return out
+
+
+def head_names(openset):
+    return ["layer5", "layer6"] + (["layer5_1", "layer6_1"] if openset else [])
+
+
+def state_shapes(num_classes, open_classes=0, openset=False, layers=LAYERS, single_head=False):
+    """Ordered {key: shape} equal to DeeplabMulti(...).state_dict() (656 keys for openset).
+    single_head=True gives model/deeplab.py's ResNet (one 4-branch head named layer5 on layer4)."""
+    sh = {}
+
+    def bn(prefix, c):
+        sh[prefix + ".weight"] = (c,)
+        sh[prefix + ".bias"] = (c,)
+        sh[prefix + ".running_mean"] = (c,)
+        sh[prefix + ".running_var"] = (c,)
+        sh[prefix + ".num_batches_tracked"] = ()
+
+    sh["conv1.weight"] = (64, 3, 7, 7)
+    bn("bn1", 64)
+    for name, inpl, planes, stride, dil, down in block_specs(layers):
+        sh[f"{name}.conv1.weight"] = (planes, inpl, 1, 1)
+        bn(f"{name}.bn1", planes)
+        sh[f"{name}.conv2.weight"] = (planes, planes, 3, 3)
+        bn(f"{name}.bn2", planes)
+        sh[f"{name}.conv3.weight"] = (planes * 4, planes, 1, 1)
+        bn(f"{name}.bn3", planes * 4)
+        if down:
+            sh[f"{name}.downsample.0.weight"] = (planes * 4, inpl, 1, 1)
+            bn(f"{name}.downsample.1", planes * 4)
+    if single_head:
+        for i in range(4):
+            sh[f"layer5.conv2d_list.{i}.weight"] = (num_classes, 2048, 3, 3)
+            sh[f"layer5.conv2d_list.{i}.bias"] = (num_classes,)
+        return sh
+    for hname in head_names(openset):
+        cin = 1024 if hname.startswith("layer5") else 2048
+        cout = open_classes if hname.endswith("_1") else num_classes
+        for i in range(4):
+            sh[f"{hname}.conv2d_list.{i}.weight"] = (cout, cin, 3, 3)
+            sh[f"{hname}.conv2d_list.{i}.bias"] = (cout,)
+    return sh
+
+
+def recipe_state(shapes, seed=1234, trained_like=True, head_scale=1.0):
+    """Build-owned deterministic weights: one torch.Generator per key (seed ^ crc32(key)).
+    conv ~ N(0, 0.01) like model/deeplab_multi.py:144-150; trained_like=True also randomises the BN affine and
+    running statistics (a released checkpoint has non-trivial ones) so that folding / frozen-affine paths are exercised."""
+    st = {}
+    for k, shp in shapes.items():
+        g = torch.Generator().manual_seed((seed ^ zlib.crc32(k.encode())) & 0x7FFFFFFF)
+        if k.endswith("num_batches_tracked"):
+            st[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith("running_mean"):
+            st[k] = torch.randn(shp, generator=g) * 0.05 if trained_like else torch.zeros(shp)
+        elif k.endswith("running_var"):
+            st[k] = torch.rand(shp, generator=g) * 0.5 + 0.75 if trained_like else torch.ones(shp)
+        elif ".bn" in k or k.startswith("bn1") or "downsample.1" in k:
+            if k.endswith("weight"):
+                st[k] = torch.rand(shp, generator=g) * 0.6 + 0.7 if trained_like else torch.ones(shp)
+            else:
+                st[k] = torch.randn(shp, generator=g) * 0.1 if trained_like else torch.zeros(shp)
+        elif k.endswith("bias"):
+            st[k] = torch.randn(shp, generator=g) * 0.01
+        else:
+            st[k] = torch.randn(shp, generator=g) * 0.01 * (head_scale if "conv2d_list" in k else 1.0)
+    return st
+
+
+# ------------------------------------------------------------------------------------------------------------
+# forward (model/deeplab_multi.py:81-101 Bottleneck, :115-119 Classifier_Module, :172-192 ResNetMulti.forward)
+# ------------------------------------------------------------------------------------------------------------
+def _bn(st, prefix, x, train):
+    # BatchNorm2d with frozen affine: train mode uses batch statistics AND updates the running ones (quirk 5)
+    return F.batch_norm(x, st[prefix + ".running_mean"], st[prefix + ".running_var"], st[prefix + ".weight"],
+                        st[prefix + ".bias"], training=train, momentum=BN_MOMENTUM, eps=BN_EPS)
+
+
+def _bottleneck(st, name, x, stride, dil, down, train):
+    out = F.conv2d(x, st[f"{name}.conv1.weight"], stride=stride)            # stride sits on the first 1x1 (:62)
+    out = F.relu(_bn(st, f"{name}.bn1", out, train))
+    out = F.conv2d(out, st[f"{name}.conv2.weight"], padding=dil, dilation=dil)
+    out = F.relu(_bn(st, f"{name}.bn2", out, train))
+    out = _bn(st, f"{name}.bn3", F.conv2d(out, st[f"{name}.conv3.weight"]), train)
+    if down:
+        x = _bn(st, f"{name}.downsample.1", F.conv2d(x, st[f"{name}.downsample.0.weight"], stride=stride), train)
+    return F.relu(out + x)
+
+
+def _aspp(st, hname, x, branches):
+    # deeplab_multi.py:115-119 returns inside the loop -> only dilations 6 and 12 are live (quirk 1);
+    # deeplab.py:112-116 sums all four.
+    out = None
+    for i, d in list(enumerate((6, 12, 18, 24)))[:branches]:
+        y = F.conv2d(x, st[f"{hname}.conv2d_list.{i}.weight"], st[f"{hname}.conv2d_list.{i}.bias"], padding=d, dilation=d)
+        out = y if out is None else out + y
+    return out
+
+
+def trunk(st, x, train, layers=LAYERS, upto=4):
+    x = F.conv2d(x, st["conv1.weight"], stride=2, padding=3)
+    x = F.relu(_bn(st, "bn1", x, train))
+    x = F.max_pool2d(x, 3, 2, 1, ceil_mode=True)
+    feats = {}
+    for name, inpl, planes, stride, dil, down in block_specs(layers):
+        li = int(name[5])
+        if li > upto:
+            break
+        x = _bottleneck(st, name, x, stride, dil, down, train)
+        feats[li] = x
+    return feats
+
+
+def deeplab_multi_forward(st, x, train, openset, layers=LAYERS):
+    """-> (x1, x2): aux head on layer3, main head on layer4; open-set heads concatenated on dim 1."""
+    f = trunk(st, x, train, layers)
+    x1 = _aspp(st, "layer5", f[3], 2)
+    x2 = _aspp(st, "layer6", f[4], 2)
+    if openset:
+        x1 = torch.cat([x1, _aspp(st, "layer5_1", f[3], 2)], 1)
+        x2 = torch.cat([x2, _aspp(st, "layer6_1", f[4], 2)], 1)
+    return x1, x2
+
+
+def deeplab_single_forward(st, x, train, layers=LAYERS):
+    """model/deeplab.py ResNet.forward: one 4-branch head, returned twice."""
+    f = trunk(st, x, train, layers)
+    y = _aspp(st, "layer5", f[4], 4)
+    return y, y
+
+
+def optim_param_names(shapes, warmup=False, openset=True):
+    """Listing order AND multiplicity of ResNetMulti.optim_parameters (model/deeplab_multi.py:194-237, quirk 4):
+    group 0 walks j.parameters() for EVERY sub-module j of layer3/layer4 (requires_grad filter commented out),
+    so a conv weight inside a Bottleneck inside a Sequential is listed 3x (downsample members 4x)."""
+    keys = [k for k in shapes if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))]
+    roots = (["conv1", "bn1", "layer1", "layer2"] if warmup else []) + ["layer3", "layer4"]
+
+    def modules_of(root):
+        # module paths in nn.Module.modules() pre-order
+        mods = [root]
+        if root.startswith("layer"):
+            blocks = sorted({k.split(".")[1] for k in keys if k.startswith(root + ".")}, key=int)
+            for b in blocks:
+                bp = f"{root}.{b}"
+                mods.append(bp)
+                for sub in ("conv1", "bn1", "conv2", "bn2", "conv3", "bn3", "relu"):
+                    mods.append(f"{bp}.{sub}")
+                if any(k.startswith(bp + ".downsample.") for k in keys):
+                    mods += [f"{bp}.downsample", f"{bp}.downsample.0", f"{bp}.downsample.1"]
+        return mods
+
+    g0 = []
+    for root in roots:
+        for m in modules_of(root):
+            g0 += [k for k in keys if k.startswith(m + ".")]
+    g1 = []
+    for h in head_names(openset):
+        g1 += [k for k in keys if k.startswith(h + ".")]
+    # reference order of heads: layer5, layer6, layer5_1, layer6_1 (:224-229)
+    return g0, g1
+
+
+# ------------------------------------------------------------------------------------------------------------
+# NTM modules (model/deeplab_multi.py:244-286)
+# ------------------------------------------------------------------------------------------------------------
+def sig_ntm_forward(ntm, class_dist, num_classes):
+    """T = L1-row-normalise( sigmoid(NTM) * tile(class_dist) + [I_C; 0_K] )   (:259-263)"""
+    q = ntm.shape[0]
+    prior = torch.cat([torch.eye(num_classes), torch.zeros(q - num_classes, num_classes)], 0)
+    t = torch.sigmoid(ntm) * class_dist.to(torch.float32).unsqueeze(0) + prior
+    return F.normalize(t, p=1, dim=1)
+
+
+def sig_w_forward(weight):
+    """diag(weight) := -1e4 in place (no grad), W = softmax(weight, 1) - I   (:278-286)"""
+    q = weight.shape[0]
+    with torch.no_grad():
+        weight[torch.arange(q), torch.arange(q)] = -10000.0
+    return torch.softmax(weight, dim=1) - torch.eye(q)
+
+
+def ntm_init(num_classes, open_classes, seed):
+    """kaiming_normal_(fan_out, relu) on a [Q, C] tensor (:248-252): std = sqrt(2 / fan_out), fan_out = Q."""
+    q = num_classes + open_classes
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(q, num_classes, generator=g) * math.sqrt(2.0 / q)
+
+
+def w_init(num_classes, open_classes):
+    q = num_classes + open_classes
+    return torch.full((q, q), 1.0 / (q - 1.0))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# loss block (tools/trainV2_simt.py:351-424, :202-230; utils/loss.py:14-40)
+# ------------------------------------------------------------------------------------------------------------
+class Hyper:
+    def __init__(self, num_classes=19, open_classes=15, th_high=0.8, th_low=0.2, lambda_seg=0.1, lambda_place=0.1,
+                 lambda_convex=0.5, lambda_volume=0.1, lambda_anchor=0.5, iter_size=1, lr=2.5e-4, lr_T=2.5e-4,
+                 momentum=0.9, weight_decay=5e-4, power=0.9, num_steps=250000):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+
+def upsample(x, size):
+    return F.interpolate(x, size=size, mode="bilinear", align_corners=True)   # interp_target, :301
+
+
+def confidence_labels(fixed_lr2, size, hp):
+    """Pseudo-label generation from the frozen model (:351-361). Returns (Conf0 [B,H,W] long, labelC_flat [P,C])."""
+    prob = upsample(torch.softmax(fixed_lr2, 1), size)
+    m, a = prob.max(1)
+    conf = torch.where(m > hp.th_high, a, torch.full_like(a, 255))
+    conf = torch.where(m < hp.th_low, torch.full_like(a, hp.num_classes), conf)
+    return conf, prob.permute(0, 2, 3, 1).reshape(-1, hp.num_classes)
+
+
+def placeholder_loss(pred, hp):
+    """Placeholder_loss (:202-230) incl. quirk 2: the arg-max logit is replaced by -0.0 (`-1000 * zeros`)."""
+    c = hp.num_classes
+    arg = pred.argmax(1)
+    onehot = F.one_hot(arg, pred.shape[1]).permute(0, 3, 1, 2).bool()
+    predict = torch.where(onehot, torch.full_like(pred, -0.0), pred)
+    pmax = torch.softmax(pred.detach(), 1).max(1)[0]
+    pseudo1 = torch.where((arg < c) & (pmax > hp.th_high), arg, torch.full_like(arg, 255))
+    known = F.cross_entropy(pred, pseudo1, ignore_index=255)
+    opened = torch.zeros_like(predict)
+    opened[:, c:] = predict[:, c:].detach()
+    y = opened.argmax(1)
+    y = torch.where(pseudo1 == 255, torch.full_like(y, 255), y)
+    unknown = F.cross_entropy(predict, y, ignore_index=255)
+    return known + hp.lambda_place * unknown, known, unknown
+
+
+def noisy_nll(pred_up, T, label):
+    """softmax -> @T -> log -> masked NLL mean (:402-409, utils/loss.py:29-39; no epsilon inside the log)."""
+    b, q, h, w = pred_up.shape
+    prob = torch.softmax(pred_up, 1).permute(0, 2, 3, 1).reshape(-1, q)
+    r = prob @ T
+    lab = label.reshape(-1)
+    valid = (lab >= 0) & (lab != 255)
+    return F.nll_loss(torch.log(r[valid]), lab[valid], reduction="mean")
+
+
+def anchor_loss(pred_up, T, labelC_flat):
+    """Anchor term for one head (:375-379): rows of T for classes that are some pixel's arg-max are pulled towards the
+    frozen model's posterior at that channel's global arg-max pixel (first index)."""
+    q = pred_up.shape[1]
+    flat = pred_up.detach().permute(0, 2, 3, 1).reshape(-1, q)
+    idx = flat.argmax(0)
+    exist = torch.unique(flat.argmax(1))
+    anchor = labelC_flat[idx]
+    return ((T[exist] - anchor[exist]) ** 2).sum(), idx, exist
+
+
+def simt_losses(pred_lr1, pred_lr2, fixed_lr2, label, T1, T2, W1, W2, hp, size):
+    """All loss terms of one sub-iteration. pred_lr*: [B,Q,h,w] low-res logits (require grad upstream), label [B,H,W]."""
+    c = hp.num_classes
+    conf0, labelC_flat = confidence_labels(fixed_lr2.detach(), size, hp)
+    p1, p2 = upsample(pred_lr1, size), upsample(pred_lr2, size)
+    a1, idx1, ex1 = anchor_loss(p1, T1, labelC_flat)
+    a2, idx2, ex2 = anchor_loss(p2, T2, labelC_flat)
+    anchor = a1 + a2
+    # class-posterior constraint (:387-395): low-confidence pixels follow the main head iff it predicts an open class
+    pseudo = p2.detach().argmax(1)
+    repl = torch.where(pseudo >= c, pseudo, torch.full_like(pseudo, 255))
+    conf = torch.where(conf0 == c, repl, conf0)
+    loss_p1 = F.cross_entropy(p1, conf, ignore_index=255)
+    loss_p2 = F.cross_entropy(p2, conf, ignore_index=255)
+    pl1, k1, u1 = placeholder_loss(p1, hp)
+    pl2, k2, u2 = placeholder_loss(p2, hp)
+    place = hp.lambda_seg * pl1 + pl2
+    loss_y1 = noisy_nll(p1, T1, label)
+    loss_y2 = noisy_nll(p2, T2, label)
+    convex = 0.0 - ((W1 @ T1) ** 2).sum() - ((W2 @ T2) ** 2).sum()
+    vol = torch.log(torch.sqrt(torch.abs(torch.linalg.det(T1.t() @ T1)))) + \
+        torch.log(torch.sqrt(torch.abs(torch.linalg.det(T2.t() @ T2))))
+    if torch.isinf(vol) or torch.isnan(vol):
+        vol = 0.0                                                             # :420-421
+    target = loss_p2 + loss_y2 + hp.lambda_seg * loss_p1 + hp.lambda_seg * loss_y1
+    total = place + target + hp.lambda_convex * convex + hp.lambda_volume * vol + hp.lambda_anchor * anchor
+    return {"total": total / hp.iter_size, "loss_p1": loss_p1, "loss_p2": loss_p2, "loss_y1": loss_y1, "loss_y2": loss_y2,
+            "place": place, "convex": convex, "volume": vol if torch.is_tensor(vol) else torch.tensor(vol),
+            "anchor": anchor, "conf": conf, "conf0": conf0, "anchor_idx1": idx1, "anchor_idx2": idx2,
+            "exist1": ex1, "exist2": ex2, "known1": k1, "known2": k2, "unknown1": u1, "unknown2": u2}
+
+
+def adam_step_(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam (weight_decay 0, amsgrad False), single-tensor formulation; in place on p, m, v."""
+    m.lerp_(g, 1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+def inner_w_loop(ntm1, ntm2, w1, w2, state, class_dist, hp, lr_T, steps=10):
+    """The 10-step W optimisation (:326-339).  ntm*/w*: leaf tensors with .grad (NTM grads ACCUMULATE: quirk 3).
+    state: dict with exp_avg/exp_avg_sq per W and the shared step counter."""
+    c = hp.num_classes
+    for _ in range(steps):
+        T1 = sig_ntm_forward(ntm1, class_dist, c)
+        T2 = sig_ntm_forward(ntm2, class_dist, c)
+        W1 = sig_w_forward(w1)
+        W2 = sig_w_forward(w2)
+        w1.grad = None
+        w2.grad = None
+        loss = ((W1 @ T1) ** 2).sum() + ((W2 @ T2) ** 2).sum()
+        loss.backward()
+        state["step"] += 1
+        with torch.no_grad():
+            adam_step_(w1, w1.grad, state["m1"], state["v1"], state["step"], lr_T)
+            adam_step_(w2, w2.grad, state["m2"], state["v2"], state["step"], lr_T)
+
+
+def sgd_step_(params, grads, bufs, mults, lr, wd, momentum, first):
+    """torch.optim.SGD(foreach=False) with a parameter listed `mult` times (quirk 4): the update is applied once per
+    listing, sequentially; on the very first step every listing starts its own buffer (= d_p), later steps share one."""
+    for p, g, b, mult in zip(params, grads, bufs, mults):
+        for _ in range(mult):
+            d = g + wd * p if wd != 0 else g
+            if momentum != 0:
+                if first:
+                    b.copy_(d)
+                else:
+                    b.mul_(momentum).add_(d)
+                d = b
+            p.sub_(lr * d)
+
+
+def lr_poly(base_lr, it, max_iter, power):
+    return base_lr * ((1 - float(it) / max_iter) ** power)                    # :174-175
+
+
+# ------------------------------------------------------------------------------------------------------------
+# evaluation metric (tools/evaluate_cityscapes.py:81-87)
+# ------------------------------------------------------------------------------------------------------------
+def fast_hist(gt, pred, n):
+    k = (gt >= 0) & (gt < n)
+    return np.bincount(n * gt[k].astype(int) + pred[k], minlength=n * n).reshape(n, n)
+
+
+def per_class_iu(hist):
+    d = np.diag(hist)
+    return d / (hist.sum(1) + hist.sum(0) - d)
+
+
+def miou(hist):
+    return round(float(np.nanmean(per_class_iu(hist))) * 100, 2)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# synthetic inputs shared by bench.py / tests: Cityscapes-shaped image + blocky noisy labels
+# ------------------------------------------------------------------------------------------------------------
+def synthetic_batch(B, H, W, class_dist, seed=1234, block=16):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randint(0, 256, (B, 3, H, W), generator=g).float()
+    img = img - torch.tensor(IMG_MEAN).view(1, 3, 1, 1)
+    hb, wb = (H + block - 1) // block, (W + block - 1) // block
+    p = torch.as_tensor(np.asarray(class_dist), dtype=torch.float64)
+    lab = torch.multinomial(p / p.sum(), B * hb * wb, replacement=True, generator=g).view(B, hb, wb)
+    ign = torch.rand(B, hb, wb, generator=g) < 0.1
+    lab = torch.where(ign, torch.full_like(lab, 255), lab)
+    lab = lab.repeat_interleave(block, 1).repeat_interleave(block, 2)[:, :H, :W].contiguous()
+    return img, lab.long()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# full training iteration (tools/trainV2_simt.py:308-436) on top of the pieces above
+# ------------------------------------------------------------------------------------------------------------
+def load_class_dist(name="bapa"):
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    return torch.as_tensor(np.load(os.path.join(here, "..", "tests", "golden", f"class_dist_{name}.npy")))
+
+
+class OracleTrainer:
+    """State + one-iteration step of the SimT stage, CPU fp32.  Mirrors what main() keeps between iterations."""
+
+    def __init__(self, st, fixed_st, ntm1, ntm2, hp, class_dist, openset=True):
+        self.hp = hp
+        self.cd = class_dist
+        self.openset = openset
+        self.st = {k: (v.clone().float().requires_grad_(True) if v.dtype != torch.long and not
+                       (k.endswith("running_mean") or k.endswith("running_var")) else v.clone()) for k, v in st.items()}
+        # BN affine is frozen (deeplab_multi.py:64-76,130-131,159-160)
+        for k, v in self.st.items():
+            if (".bn" in k or k.startswith("bn1") or "downsample.1" in k) and v.dtype != torch.long and v.requires_grad:
+                v.requires_grad_(False)
+        self.fixed = {k: v.clone() for k, v in fixed_st.items()}
+        self.ntm = [ntm1.clone().requires_grad_(True), ntm2.clone().requires_grad_(True)]
+        q = ntm1.shape[0]
+        self.w = [w_init(hp.num_classes, q - hp.num_classes).requires_grad_(True) for _ in range(2)]
+        self.wstate = {"step": 0, "m1": torch.zeros(q, q), "v1": torch.zeros(q, q), "m2": torch.zeros(q, q),
+                       "v2": torch.zeros(q, q)}
+        self.tstate = [{"step": 0, "m": torch.zeros_like(ntm1), "v": torch.zeros_like(ntm1)} for _ in range(2)]
+        shapes = {k: tuple(v.shape) for k, v in st.items()}
+        g0, g1 = optim_param_names(shapes, warmup=False, openset=openset)
+        self.groups = []
+        for names, lr_mult in ((g0, 1.0), (g1, 10.0)):
+            uniq = list(dict.fromkeys(names))
+            self.groups.append({"names": uniq, "mult": [names.count(n) for n in uniq], "lr_mult": lr_mult})
+        self.bufs = {}
+        self.first = True
+
+    def step(self, image, label, it):
+        hp = self.hp
+        c = hp.num_classes
+        lr = lr_poly(hp.lr, it, hp.num_steps, hp.power)
+        lr_T = lr_poly(hp.lr_T, it, hp.num_steps, hp.power)
+        for v in self.st.values():
+            if v.dtype != torch.long:
+                v.grad = None
+        for t in self.ntm:
+            t.grad = None
+        inner_w_loop(self.ntm[0], self.ntm[1], self.w[0], self.w[1], self.wstate, self.cd, hp, lr_T)
+        T1 = sig_ntm_forward(self.ntm[0], self.cd, c)
+        T2 = sig_ntm_forward(self.ntm[1], self.cd, c)
+        size = tuple(label.shape[1:])
+        with torch.no_grad():
+            _, f2 = deeplab_multi_forward(self.fixed, image, False, False)
+        x1, x2 = deeplab_multi_forward(self.st, image, True, self.openset)
+        W1 = sig_w_forward(self.w[0])
+        W2 = sig_w_forward(self.w[1])
+        out = simt_losses(x1, x2, f2, label, T1, T2, W1, W2, hp, size)
+        out["total"].backward()
+        with torch.no_grad():
+            for g in self.groups:
+                ps, gs, bs, ms = [], [], [], []
+                for n, m in zip(g["names"], g["mult"]):
+                    p = self.st[n]
+                    if p.grad is None:
+                        continue
+                    if n not in self.bufs:
+                        self.bufs[n] = torch.zeros_like(p)
+                    ps.append(p); gs.append(p.grad); bs.append(self.bufs[n]); ms.append(m)
+                sgd_step_(ps, gs, bs, ms, lr * g["lr_mult"], hp.weight_decay, hp.momentum, self.first)
+            self.first = False
+            for k in range(2):
+                s = self.tstate[k]
+                s["step"] += 1
+                adam_step_(self.ntm[k], self.ntm[k].grad, s["m"], s["v"], s["step"], lr_T)
+        return out
