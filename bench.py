@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the SimT training iteration on MI355X (BASELINE.json metric: training images/sec at
+768x768, DeepLabv2-R101+SimT).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one full SimT iteration (tools/trainV2_simt.py:308-436 of the reference) on one synthetic batch per GPU:
+10-step W inner loop, frozen-model forward, trainable forward (train-mode BN), fused head losses, backward (dgrad +
+wgrad of all 104 trunk convs and the heads), gradient all-reduce (N>1), SGD with duplicate listings + Adam on NTM,
+weight re-packing.  Inputs are resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+
+Extra objects: "roofline" (dominant kernel class = the implicit-GEMM conv, algorithmic FLOPs / HIP-event time measured
+live in a separate, untimed replay) and "cpu_baseline" (the CPU oracle -- a port of the reference -- timed on the
+host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense, /opt/skills/guides/MI355X_MICROARCH.md
+FLOP_PER_IMAGE_768 = 3.33e12                            # conv MACs x2, fixed fwd + fwd + bwd
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE config 2: 4)")
+    ap.add_argument("--size", type=int, nargs=2, default=[768, 768], metavar=("H", "W"))
+    ap.add_argument("--open-classes", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=768, help="H=W of the CPU-baseline sample (B=1)")
+    return ap.parse_args()
+
+
+def cpu_baseline(K, size):
+    """The oracle (CPU restatement of the reference, pinned by tests/golden) on the host cores: one full iteration at
+    B=1 after a small warm-up.  Checker-as-baseline only; never part of the product path."""
+    from oracle import simt_oracle as so
+    cd = so.load_class_dist()
+    st = so.recipe_state(so.state_shapes(19, K, True), seed=1234, trained_like=False)
+    fst = so.recipe_state(so.state_shapes(19, 0, False), seed=1234, trained_like=False)
+    hp = so.Hyper(open_classes=K, lr=6e-4, lr_T=6e-3)
+    tr = so.OracleTrainer(st, fst, so.ntm_init(19, K, 1), so.ntm_init(19, K, 2), hp, cd)
+    img, lab = so.synthetic_batch(1, 129, 129, cd.numpy(), seed=1)
+    tr.step(img, lab, 0)                                  # thread-pool / allocator warm-up
+    img, lab = so.synthetic_batch(1, size, size, cd.numpy(), seed=2)
+    t0 = time.perf_counter()
+    tr.step(img, lab, 1)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 iteration, B=1, {size}x{size}, K={K}, fp32, torch CPU ({dt:.1f} s)"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+    from simt_amd import model_spec as ms
+    from simt_amd.step import Hyper, SimTTrainer
+
+    H, W = a.size
+    K = a.open_classes
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    cd = ms.load_class_dist("bapa")
+    st = ms.reference_init(ms.state_shapes(19, K, True), seed=1234)
+    fst = ms.reference_init(ms.state_shapes(19, 0, False), seed=1234)
+    hp = Hyper(open_classes=K, lr=6e-4, lr_T=6e-3)       # sh_simt.sh:16
+    tr = SimTTrainer(st, fst, ms.ntm_init(19, K, 1), ms.ntm_init(19, K, 2), hp, cd, a.batch, H, W, dtype=dtype, device=dev,
+                     process_group=pg)
+    img, lab = ms.synthetic_batch(a.batch, H, W, cd, seed=1234 + rank, device=dev)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        tr.step(img, lab)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step(img, lab)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_step = dt / a.steps * 1e3
+    value = a.batch * world * a.steps / dt
+
+    roof = None
+    if not a.no_roofline:
+        acc = {}
+        for _ in range(2):
+            acc.clear()
+            tr.fixed.fwd_list.run_timed(acc)
+            tr.plan.fwd_list.run_timed(acc)
+            tr.plan.bwd_list.run_timed(acc)
+        conv = {k: v for k, v in acc.items() if k.startswith("conv_")}
+        dom = max(conv, key=lambda k: conv[k][0])
+        ms_k, fl, by, n = conv[dom]
+        ach = fl / (ms_k * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[a.dtype]
+        tot_ms = sum(v[0] for v in acc.values())
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": n,
+                "avg_launch_us": round(ms_k / n * 1e3, 2), "alg_gflop_per_launch": round(fl / n / 1e9, 3),
+                "share_of_step_kernel_time": round(ms_k / tot_ms, 3),
+                "classes": {k: {"ms": round(v[0], 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[1] else None,
+                                "n": v[3]} for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])[:12]}}
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(K, a.cpu_size)
+    if rank == 0:
+        flop_img = FLOP_PER_IMAGE_768 * (H * W) / (768.0 * 768.0)
+        line = {"metric": "training images/sec at 768x768, DeepLabv2-R101+SimT", "value": round(value, 3),
+                "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                "config": {"workload": f"DeepLabv2-ResNet101 + SimT(C=19,K={K}) full training iteration, batch={a.batch}/GPU, "
+                                       f"{H}x{W}, {a.dtype}, {world}xMI355X" + (" DP RCCL all-reduce" if world > 1 else ""),
+                           "global_batch": a.batch * world, "baseline_config": "configs[1]" if world == 1 else "configs[2]",
+                           "step_tflops_conv_algorithmic": round(value * flop_img / 1e12, 1),
+                           "frac_of_conv_roofline": round(value * flop_img / 1e12 / (world * MFMA_PEAK_TFLOPS[a.dtype]), 4)},
+                "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -203,7 +203,7 @@ def sig_ntm_forward(ntm, class_dist, num_classes):
     """T = L1-row-normalise( sigmoid(NTM) * tile(class_dist) + [I_C; 0_K] )   (:259-263)"""
     q = ntm.shape[0]
     prior = torch.cat([torch.eye(num_classes), torch.zeros(q - num_classes, num_classes)], 0)
-    t = torch.sigmoid(ntm) * class_dist.to(torch.float32).unsqueeze(0) + prior
+    t = torch.sigmoid(ntm) * class_dist.to(ntm.dtype).unsqueeze(0) + prior.to(ntm.dtype)
     return F.normalize(t, p=1, dim=1)
 
 
@@ -212,7 +212,7 @@ def sig_w_forward(weight):
     q = weight.shape[0]
     with torch.no_grad():
         weight[torch.arange(q), torch.arange(q)] = -10000.0
-    return torch.softmax(weight, dim=1) - torch.eye(q)
+    return torch.softmax(weight, dim=1) - torch.eye(q, dtype=weight.dtype)
 
 
 def ntm_init(num_classes, open_classes, seed):
@@ -414,11 +414,17 @@ def load_class_dist(name="bapa"):
 class OracleTrainer:
     """State + one-iteration step of the SimT stage, CPU fp32.  Mirrors what main() keeps between iterations."""
 
-    def __init__(self, st, fixed_st, ntm1, ntm2, hp, class_dist, openset=True):
+    def __init__(self, st, fixed_st, ntm1, ntm2, hp, class_dist, openset=True, dtype=torch.float32):
+        """dtype=torch.float64 gives the "exact arithmetic" run used to measure how far fp32 implementations
+        (the reference's CPU path included) sit from the true value of an ill-conditioned quantity."""
         self.hp = hp
         self.cd = class_dist
         self.openset = openset
-        self.st = {k: (v.clone().float().requires_grad_(True) if v.dtype != torch.long and not
+        self.dtype = dtype
+        st = {k: (v.to(dtype) if v.dtype != torch.long else v) for k, v in st.items()}
+        fixed_st = {k: (v.to(dtype) if v.dtype != torch.long else v) for k, v in fixed_st.items()}
+        ntm1, ntm2 = ntm1.to(dtype), ntm2.to(dtype)
+        self.st = {k: (v.clone().requires_grad_(True) if v.dtype != torch.long and not
                        (k.endswith("running_mean") or k.endswith("running_var")) else v.clone()) for k, v in st.items()}
         # BN affine is frozen (deeplab_multi.py:64-76,130-131,159-160)
         for k, v in self.st.items():
@@ -427,9 +433,9 @@ class OracleTrainer:
         self.fixed = {k: v.clone() for k, v in fixed_st.items()}
         self.ntm = [ntm1.clone().requires_grad_(True), ntm2.clone().requires_grad_(True)]
         q = ntm1.shape[0]
-        self.w = [w_init(hp.num_classes, q - hp.num_classes).requires_grad_(True) for _ in range(2)]
-        self.wstate = {"step": 0, "m1": torch.zeros(q, q), "v1": torch.zeros(q, q), "m2": torch.zeros(q, q),
-                       "v2": torch.zeros(q, q)}
+        self.w = [w_init(hp.num_classes, q - hp.num_classes).to(dtype).requires_grad_(True) for _ in range(2)]
+        self.wstate = {"step": 0, "m1": torch.zeros(q, q, dtype=dtype), "v1": torch.zeros(q, q, dtype=dtype),
+                       "m2": torch.zeros(q, q, dtype=dtype), "v2": torch.zeros(q, q, dtype=dtype)}
         self.tstate = [{"step": 0, "m": torch.zeros_like(ntm1), "v": torch.zeros_like(ntm1)} for _ in range(2)]
         shapes = {k: tuple(v.shape) for k, v in st.items()}
         g0, g1 = optim_param_names(shapes, warmup=False, openset=openset)
@@ -443,6 +449,7 @@ class OracleTrainer:
     def step(self, image, label, it):
         hp = self.hp
         c = hp.num_classes
+        image = image.to(self.dtype)
         lr = lr_poly(hp.lr, it, hp.num_steps, hp.power)
         lr_T = lr_poly(hp.lr_T, it, hp.num_steps, hp.power)
         for v in self.st.values():

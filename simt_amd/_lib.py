@@ -119,6 +119,10 @@ def load():
         raise SimtHipError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
             "Run `python -c 'import __graft_entry__ as g; g.build()'`.")
+    # PyTorch-ROCm ships its own libamdhip64 (same soname); it must be mapped first so that this library binds to
+    # the SAME HIP runtime instance that owns torch's streams and allocations (two runtimes in one process cannot
+    # share stream handles: launches fail with "no ROCm-capable device").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

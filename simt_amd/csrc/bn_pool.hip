@@ -13,18 +13,58 @@
 //   part [nblk][2][C] (sum, sum of squares)  ->  mean, rstd, scale = gamma*rstd, shift = beta - mean*scale
 //   running_mean/var updated like PyTorch (momentum 0.1, unbiased var), if running != null.
 // ---------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* part, int nblk, int C, long count, const float* gamma, const float* beta,
-                                   float* running_mean, float* running_var, float momentum, float eps, float* mean_out,
-                                   float* rstd_out, float* scale_out, float* shift_out) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s1 += (double)part[((long)b * 2 + 0) * C + c];
-    s2 += (double)part[((long)b * 2 + 1) * C + c];
+// One block = 32 channels x 8 row lanes: lane r sums partial rows r, r+8, ... (128-B coalesced rows), then the 8 lanes are
+// combined in fixed order through LDS -> bitwise reproducible, and nblk = 4608 (stem) costs 576 loads per thread
+// instead of 9216 dependent ones.
+template <int NJ>
+__device__ __forceinline__ void part_colsum32(const float* part, int nblk, int C, int c0, double* out /*[NJ]*/, double (*red)[32][NJ]) {
+  const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int c = c0 + cl;
+  double s[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) s[j] = 0.0;
+  if (c < C) {
+    int b = r;
+    for (; b + 24 < nblk; b += 32) {
+      float v[4][NJ];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) v[u][j] = part[((long)(b + 8 * u) * NJ + j) * C + c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) s[j] += (double)v[u][j];
+    }
+    for (; b < nblk; b += 8)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) s[j] += (double)part[((long)b * NJ + j) * C + c];
   }
-  double mean = s1 / (double)count;
-  double var = s2 / (double)count - mean * mean;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) red[r][cl][j] = s[j];
+  __syncthreads();
+  if (r == 0) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += red[q][cl][j];
+      out[j] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* part, int nblk, int C, long count, const float* gamma,
+                                                         const float* beta, float* running_mean, float* running_var,
+                                                         float momentum, float eps, float* mean_out, float* rstd_out,
+                                                         float* scale_out, float* shift_out) {
+  __shared__ double red[8][32][2];
+  double s[2];
+  part_colsum32<2>(part, nblk, C, blockIdx.x * 32, s, red);
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  if ((threadIdx.x >> 5) != 0 || c >= C) return;
+  double mean = s[0] / (double)count;
+  double var = s[1] / (double)count - mean * mean;
   if (var < 0.0) var = 0.0;
   float rstd = (float)(1.0 / sqrt(var + (double)eps));
   float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
@@ -44,7 +84,7 @@ extern "C" int simt_bn_finalize(const float* part, int nblk, int C, long count, 
                                 float* running_mean, float* running_var, float momentum, float eps, float* mean,
                                 float* rstd, float* scale, float* shift, simt_stream_t stream) {
   SIMT_CHECK(part && mean && rstd && scale && shift && C > 0 && nblk > 0);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, nblk, C, count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, nblk, C, count,
                      gamma, beta, running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
@@ -181,13 +221,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dz, const T
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* part, int nblk, int C, long count, float* coef) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 3 * C) return;
-  int j = idx / C, c = idx - j * C;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[((long)b * 3 + j) * C + c];
-  coef[j * C + c] = (float)(s / (double)count);
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, long count, float* coef) {
+  __shared__ double red[8][32][3];
+  double s[3];
+  part_colsum32<3>(part, nblk, C, blockIdx.x * 32, s, red);
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  if ((threadIdx.x >> 5) != 0 || c >= C) return;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) coef[j * C + c] = (float)(s[j] / (double)count);
 }
 
 template <typename T>
@@ -270,8 +311,7 @@ extern "C" int simt_bn_bwd(const simt_bn_bwd_desc* d, simt_stream_t stream) {
                        (const float*)d->y2, d->mean2, d->rstd2, d->part, d->M, d->C, rpb, d->mask_mode);
   }
   SIMT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((3 * d->C + 255) / 256), dim3(256), 0, st, d->part, nblk, d->C, d->M,
-                     d->coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 31) / 32), dim3(256), 0, st, d->part, nblk, d->C, d->M, d->coef);
   SIMT_LAUNCH_CHECK();
   if (d->dtype == SIMT_BF16) {
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)d->dz,
@@ -543,31 +583,41 @@ extern "C" int simt_scatter_stride(const void* src, void* dx, int B, int H, int 
   return SIMT_OK;
 }
 
-// out[c] (+)= sum_m src[m*ld + c]   (bias gradients of the head convs; c < C <= 64, one block)
+// out[c] (+)= sum_m src[m*ld + c]   (bias gradients of the head convs; c < C <= 64).  Two stages, fixed order:
+// COLSUM_G blocks each sum a contiguous row range into a library-owned scratch, then one block combines them.
+#define COLSUM_G 128
+__device__ double g_colsum_ws[COLSUM_G * 64];
+
 template <typename T>
-__global__ __launch_bounds__(1024) void colsum_kernel(const T* src, float* out, long M, int ld, int C, int accumulate) {
-  __shared__ double red[1024];
-  int c = threadIdx.x % 64, lane_r = threadIdx.x / 64;  // 16 row lanes
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* src, long M, int ld, int C) {
+  __shared__ double red[4][64];
+  const int c = threadIdx.x & 63, lr = threadIdx.x >> 6;
+  long rows = (M + COLSUM_G - 1) / COLSUM_G;
+  long m0 = (long)blockIdx.x * rows, m1 = m0 + rows;
+  if (m1 > M) m1 = M;
   double s = 0.0;
   if (c < C)
-    for (long m = lane_r; m < M; m += 16) s += (double)Elem<T>::ld(src + m * ld + c);
-  red[threadIdx.x] = s;
+    for (long m = m0 + lr; m < m1; m += 4) s += (double)Elem<T>::ld(src + m * ld + c);
+  red[lr][c] = s;
   __syncthreads();
-  if (threadIdx.x < 64 && c < C) {
-    double t = 0.0;
-    for (int q = 0; q < 16; ++q) t += red[q * 64 + c];
-    out[c] = accumulate ? out[c] + (float)t : (float)t;
-  }
+  if (lr == 0) g_colsum_ws[blockIdx.x * 64 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+__global__ void colsum_final_kernel(float* out, int C, int accumulate) {
+  int c = threadIdx.x;
+  if (c >= C) return;
+  double t = 0.0;
+  for (int b = 0; b < COLSUM_G; ++b) t += g_colsum_ws[b * 64 + c];
+  out[c] = accumulate ? out[c] + (float)t : (float)t;
 }
 extern "C" int simt_colsum(const void* src, float* out, long M, int ld, int C, int accumulate, int dtype,
                            simt_stream_t stream) {
   SIMT_CHECK(src && out && C <= 64);
   if (dtype == SIMT_BF16)
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)src, out, M, ld,
-                       C, accumulate);
+    hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(COLSUM_G), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, M, ld, C);
   else
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)src, out, M, ld, C,
-                       accumulate);
+    hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(COLSUM_G), dim3(256), 0, (hipStream_t)stream, (const float*)src, M, ld, C);
+  SIMT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out, C, accumulate);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }

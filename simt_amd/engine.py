@@ -1,0 +1,661 @@
+"""Static execution plans for the DeepLab-v2 ResNet trunk + ASPP heads on gfx950.
+
+A plan is built once for a fixed (B, H, W, dtype): every activation / gradient / workspace buffer is allocated up
+front in HBM (NHWC), every kernel launch is pre-described (ctypes descriptors of include/simt_hip.h), and a step is a
+replay of that launch list on the current HIP stream -- no allocation, no host sync, capturable in a hipGraph.
+
+Mirrors (reference, read-only): model/deeplab_multi.py:57-101 Bottleneck, :104-119 Classifier_Module (two live
+branches), :122-192 ResNetMulti; model/deeplab.py:101-177 (single 4-branch head).  BatchNorm runs in train mode with
+frozen affine in the trainable net and is folded into the conv weights in eval plans.
+
+PyTorch is used for device memory and streams only; all arithmetic happens in libsimt_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+LAYERS = (3, 4, 23, 3)
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def block_specs(layers=LAYERS):
+    """[(name, inplanes, planes, stride, dilation, has_downsample)] (model/deeplab_multi.py:152-167)."""
+    out = []
+    inpl = 64
+    for li, (planes, nblk, stride, dil) in enumerate(zip((64, 128, 256, 512), layers, (1, 2, 1, 1), (1, 1, 2, 4)), 1):
+        for b in range(nblk):
+            out.append((f"layer{li}.{b}", inpl, planes, stride if b == 0 else 1, dil, b == 0))
+            inpl = planes * 4
+    return out
+
+
+def trunk_geometry(H, W):
+    """Spatial sizes after the stem conv (7x7 s2 p3), the ceil-mode max-pool (3,2,1) and layer2's stride 2."""
+    def pool_out(n):
+        o = -(-(n + 2 - 3) // 2) + 1
+        if (o - 1) * 2 >= n + 1:
+            o -= 1
+        return o
+    H0, W0 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = pool_out(H0), pool_out(W0)
+    H2, W2 = (Hp - 1) // 2 + 1, (Wp - 1) // 2 + 1
+    return (H0, W0), (Hp, Wp), (H2, W2)
+
+
+class HeadCfg:
+    """An ASPP classifier on a trunk feature: groups = [(prefix, cout)] concatenated on the channel axis."""
+
+    def __init__(self, name, feat_layer, cin, groups, dilations):
+        self.name, self.feat_layer, self.cin, self.groups, self.dilations = name, feat_layer, cin, groups, dilations
+        self.Q = sum(c for _, c in groups)
+
+
+def multi_heads(num_classes, open_classes, openset):
+    """model/deeplab_multi.py:138-142,181-190: layer5(+layer5_1) on layer3, layer6(+layer6_1) on layer4, dil (6, 12)."""
+    g1 = [("layer5", num_classes)] + ([("layer5_1", open_classes)] if openset else [])
+    g2 = [("layer6", num_classes)] + ([("layer6_1", open_classes)] if openset else [])
+    return [HeadCfg("x1", 3, 1024, g1, (6, 12)), HeadCfg("x2", 4, 2048, g2, (6, 12))]
+
+
+def single_head(num_classes):
+    """model/deeplab.py:112-116,139: one 4-branch head on layer4."""
+    return [HeadCfg("x", 4, 2048, [("layer5", num_classes)], (6, 12, 18, 24))]
+
+
+class _Launch:
+    __slots__ = ("fn", "args", "keep", "tag", "flops", "bytes")
+
+    def __init__(self, fn, args, keep, tag=None, flops=0.0, nbytes=0.0):
+        self.fn, self.args, self.keep, self.tag, self.flops, self.bytes = fn, args, keep, tag, flops, nbytes
+
+
+class LaunchList:
+    """A recorded sequence of C-ABI calls; run() replays it on the current stream."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, name, *args, keep=None, tag=None, flops=0.0, nbytes=0.0):
+        fn = getattr(L.load(), name)
+        self.items.append(_Launch(fn, args, keep, tag or name, flops, nbytes))
+
+    def add_desc(self, name, desc, **kw):
+        self.add(name, C.byref(desc), keep=desc, **kw)
+
+    def run_timed(self, acc):
+        """Replay with a HIP event pair around every launch (on the stream the kernels are launched on) and add
+        (milliseconds, algorithmic flops, algorithmic bytes, count) per tag into `acc`.  Measurement only."""
+        stream = torch.cuda.current_stream()
+        st = stream.cuda_stream
+        evs = []
+        for it in self.items:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            rc = it.fn(*it.args, st)
+            e1.record(stream)
+            if rc != 0:
+                L.check(rc)
+            evs.append((it, e0, e1))
+        torch.cuda.synchronize()
+        for it, e0, e1 in evs:
+            a = acc.setdefault(it.tag, [0.0, 0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1)
+            a[1] += it.flops
+            a[2] += it.bytes
+            a[3] += 1
+
+    def run(self):
+        st = torch.cuda.current_stream().cuda_stream
+        for it in self.items:
+            rc = it.fn(*it.args, st)
+            if rc != 0:
+                L.check(rc)
+
+    def __len__(self):
+        return len(self.items)
+
+
+class TrunkPlan:
+    """Forward (train or eval) and backward of ResNetMulti for one fixed input shape.
+
+    params: {state_dict key: fp32 CUDA tensor}  (the nn.Module's own storage: optimiser updates are seen by
+            repack()).  Buffers (running_mean/var) are updated in place in train mode.
+    grads : {key: fp32 CUDA tensor} written by backward() (views of one flat buffer, reverse-topological order so
+            that DP buckets become ready in order).
+    """
+
+    def __init__(self, params, B, H, W, heads, *, dtype=torch.bfloat16, train=True, layers=LAYERS, device=None,
+                 need_input_grads=True, grad_names=None):
+        self.p = params
+        self.B, self.H, self.W = B, H, W
+        self.heads = heads
+        self.dtype = dtype
+        self.train = train
+        self.layers = layers
+        self.dev = device or next(iter(params.values())).device
+        self.esz = 2 if dtype == torch.bfloat16 else 4
+        self.kq = 128 // self.esz            # channel quantum of the K dimension (one 128-B stage)
+        (self.H0, self.W0), (self.Hp, self.Wp), (self.H2, self.W2) = trunk_geometry(H, W)
+        self.blocks = block_specs(layers)
+        self._bufs = {}
+        self._keep = []
+        self.packed = {}      # conv name -> fprop operand
+        self.packed_t = {}    # conv name -> dgrad operand
+        self.fold = {}        # bn name -> (scale, shift) for eval plans
+        self.bn = {}          # bn name -> dict(mean, rstd, scale, shift, part, nblk, count)
+        self.pack_list = LaunchList()
+        self.fwd_list = LaunchList()
+        self.bwd_list = LaunchList()
+        self.out = {}         # head name -> fp32 logits [B, h, w, ldp]
+        self.ldp = {}
+        self._build_forward()
+        if train:
+            self._alloc_grads(grad_names)
+            self._build_backward()
+        self.repack()
+
+    # ------------------------------------------------------------------ buffers
+    def buf(self, role, *shape, dtype=None, zero=False):
+        dtype = dtype or self.dtype
+        key = (role,) + tuple(shape) + (dtype,)
+        t = self._bufs.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, device=self.dev, dtype=dtype)
+            self._bufs[key] = t
+        return t
+
+    def new(self, *shape, dtype=None, zero=False):
+        dtype = dtype or self.dtype
+        t = (torch.zeros if zero else torch.empty)(shape, device=self.dev, dtype=dtype)
+        self._keep.append(t)
+        return t
+
+    def bytes_allocated(self):
+        return sum(t.numel() * t.element_size() for t in list(self._bufs.values()) + self._keep)
+
+    # ------------------------------------------------------------------ weight packing
+    def _plan_pack(self, cname, cout, cin, k, *, scale_bn=None, K_cin=None):
+        """fprop operand [Npad][ntaps*Cin_k]; with scale_bn (eval) the BN scale is folded per output channel."""
+        tile = ops.pick_tile_n(cout)
+        npad = ops.round_up(cout, tile)
+        cin_k = K_cin or cin
+        wp = self.new(npad, cin_k if cname == "conv1" else k * k * cin_k, zero=True)
+        self.packed[cname] = (wp, tile, npad)
+        w = self.p[cname + ".weight"]
+        cs = self.fold[scale_bn][0] if scale_bn else None
+        if cname == "conv1":
+            # stem: K = ci*49 + r*7 + s (OIHW flattening), padded to cin_k; expressed as Cin=147, RS=1
+            self.pack_list.add("simt_pack_weight", w.data_ptr(), wp.data_ptr(), cout, 147, 1, 0, 0, cin_k, 0, 0,
+                               cs.data_ptr() if cs is not None else None, ops.dt_code(self.dtype))
+        else:
+            self.pack_list.add("simt_pack_weight", w.data_ptr(), wp.data_ptr(), cout, cin, k * k, 0, 0, k * k * cin, 0, 0,
+                               cs.data_ptr() if cs is not None else None, ops.dt_code(self.dtype))
+        return wp, tile, npad
+
+    def _plan_pack_t(self, cname, cout, cin, k):
+        """dgrad operand [Cin_pad][ntaps*Ck], Ck = cout rounded to the K quantum."""
+        ck = ops.round_up(cout, self.kq)
+        tile = ops.pick_tile_n(cin)
+        npad = ops.round_up(cin, tile)
+        wt = self.new(npad, k * k * ck, zero=True)
+        self.packed_t[cname] = (wt, tile, npad, ck)
+        w = self.p[cname + ".weight"]
+        self.pack_list.add("simt_pack_weight", w.data_ptr(), wt.data_ptr(), cout, cin, k * k, 0, 0, k * k * ck, ck, 1, None,
+                           ops.dt_code(self.dtype))
+        return wt, tile, npad, ck
+
+    def repack(self):
+        """Refresh every packed operand from the fp32 master weights (after an optimiser step / load_state_dict)."""
+        self.pack_list.run()
+
+    # ------------------------------------------------------------------ forward construction
+    def _conv(self, lst, x, wp_info, y, *, Bn, Hi, Wi, Cin, Ho, Wo, Cout, taps, stride=1, bias=None, res=None, stats=None,
+              relu=False, ldy=None, Nstore=None, alg_k=None):
+        """alg_k: algorithmic reduction length per output element (defaults to ntaps*Cin; the K-padded head dgrad and
+        the stem pass their true value) -> algorithmic FLOPs = 2 * M * Cout * alg_k."""
+        wp, tile, npad = wp_info
+        d = ops.make_conv_desc(x, wp, y, B=Bn, H=Hi, W=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, taps=taps, stride=stride,
+                               bias=bias, res=res, stats=stats, relu=relu, Npad=npad, tile_n=tile, ldy=ldy,
+                               Nstore=Nstore)
+        M = Bn * Ho * Wo
+        k = alg_k if alg_k is not None else len(taps) * Cin
+        tn = {torch.bfloat16: "bf16", torch.float32: "f32"}
+        tag = f"conv_igemm<{tn[x.dtype]},{tn[y.dtype]},{tile}>"
+        nbytes = (Bn * Hi * Wi * Cin + npad * len(taps) * Cin) * x.element_size() + M * Cout * y.element_size()
+        lst.add_desc("simt_conv_fprop", d, tag=tag, flops=2.0 * M * Cout * k, nbytes=float(nbytes))
+
+    def _bn_train(self, lst, bname, y, M, Cn):
+        """stats partials were written by the conv epilogue into self.bn[bname]['part']."""
+        s = self.bn[bname]
+        lst.add("simt_bn_finalize", s["part"].data_ptr(), s["nblk"], Cn, M, self.p[bname + ".weight"].data_ptr(),
+                self.p[bname + ".bias"].data_ptr(), self.p[bname + ".running_mean"].data_ptr(),
+                self.p[bname + ".running_var"].data_ptr(), BN_MOMENTUM, BN_EPS, s["mean"].data_ptr(),
+                s["rstd"].data_ptr(), s["scale"].data_ptr(), s["shift"].data_ptr())
+
+    def _new_bn(self, bname, M, Cn):
+        nblk = (M + 127) // 128
+        s = {"part": self.new(nblk, 2, Cn, dtype=torch.float32), "nblk": nblk, "count": M}
+        for k in ("mean", "rstd", "scale", "shift"):
+            s[k] = self.new(Cn, dtype=torch.float32)
+        self.bn[bname] = s
+        return s
+
+    def _plan_fold(self, bname, Cn):
+        sc, sh = self.new(Cn, dtype=torch.float32), self.new(Cn, dtype=torch.float32)
+        self.fold[bname] = (sc, sh)
+        self.pack_list.add("simt_bn_fold", self.p[bname + ".weight"].data_ptr(), self.p[bname + ".bias"].data_ptr(),
+                           self.p[bname + ".running_mean"].data_ptr(), self.p[bname + ".running_var"].data_ptr(), BN_EPS,
+                           sc.data_ptr(), sh.data_ptr(), Cn)
+        return sc, sh
+
+    def _build_forward(self):
+        B, dt = self.B, self.dtype
+        f = self.fwd_list
+        H0, W0, Hp, Wp = self.H0, self.W0, self.Hp, self.Wp
+        M0, Mp = B * H0 * W0, B * Hp * Wp
+        self.x_in = self.new(B, 3, self.H, self.W, dtype=torch.float32)
+        self.saved = {}
+        # ---- stem (model/deeplab_multi.py:127-133,172-176)
+        KS = 192
+        A = self.new(M0, KS)
+        self.saved["stem.A"] = A
+        f.add("simt_im2col_stem", self.x_in.data_ptr(), A.data_ptr(), B, 3, self.H, self.W, H0, W0, 7, 7, 2, 3, KS,
+              ops.dt_code(dt))
+        y0 = self.new(M0, 64)
+        pool = self.new(Mp, 64)
+        pidx = self.new(Mp, 64, dtype=torch.uint8)
+        self.saved["stem.y"], self.saved["stem.pool"], self.saved["stem.idx"] = y0, pool, pidx
+        if self.train:
+            wi = self._plan_pack("conv1", 64, 3, 7, K_cin=KS)
+            s = self._new_bn("bn1", M0, 64)
+            self._conv(f, A, wi, y0, Bn=1, Hi=1, Wi=M0, Cin=KS, Ho=1, Wo=M0, Cout=64, taps=[(0, 0)], stats=s["part"],
+                       alg_k=147)
+            self._bn_train(f, "bn1", y0, M0, 64)
+            f.add("simt_bn_relu_maxpool", y0.data_ptr(), s["scale"].data_ptr(), s["shift"].data_ptr(), pool.data_ptr(),
+                  pidx.data_ptr(), B, H0, W0, 64, Hp, Wp, ops.dt_code(dt))
+        else:
+            sc, sh = self._plan_fold("bn1", 64)
+            wi = self._plan_pack("conv1", 64, 3, 7, K_cin=KS, scale_bn="bn1")
+            self._conv(f, A, wi, y0, Bn=1, Hi=1, Wi=M0, Cin=KS, Ho=1, Wo=M0, Cout=64, taps=[(0, 0)], bias=sh, relu=True,
+                       alg_k=147)
+            one, zero = self.new(64, dtype=torch.float32), self.new(64, dtype=torch.float32, zero=True)
+            one.fill_(1.0)
+            f.add("simt_bn_relu_maxpool", y0.data_ptr(), one.data_ptr(), zero.data_ptr(), pool.data_ptr(),
+                  pidx.data_ptr(), B, H0, W0, 64, Hp, Wp, ops.dt_code(dt))
+        # ---- bottlenecks
+        x, Hc, Wc = pool, Hp, Wp
+        self.block_io = []
+        feats = {}
+        for (name, inpl, planes, stride, dil, down) in self.blocks:
+            Ho, Wo = ((Hc - 1) // stride + 1, (Wc - 1) // stride + 1)
+            Mi, Mo = B * Hc * Wc, B * Ho * Wo
+            c4 = planes * 4
+            rec = {"name": name, "x": x, "Hi": Hc, "Wi": Wc, "Ho": Ho, "Wo": Wo, "inpl": inpl, "planes": planes,
+                   "stride": stride, "dil": dil, "down": down, "Mi": Mi, "Mo": Mo}
+            t3 = ops.conv_taps(3, 3, dil, dil)
+            if self.train:
+                y1, a1 = self.new(Mo, planes), self.new(Mo, planes)
+                y2, a2 = self.new(Mo, planes), self.new(Mo, planes)
+                y3, z = self.new(Mo, c4), self.new(Mo, c4)
+                s1, s2, s3 = (self._new_bn(f"{name}.bn1", Mo, planes), self._new_bn(f"{name}.bn2", Mo, planes),
+                              self._new_bn(f"{name}.bn3", Mo, c4))
+                w1 = self._plan_pack(f"{name}.conv1", planes, inpl, 1)
+                w2 = self._plan_pack(f"{name}.conv2", planes, planes, 3)
+                w3 = self._plan_pack(f"{name}.conv3", c4, planes, 1)
+                self._conv(f, x, w1, y1, Bn=B, Hi=Hc, Wi=Wc, Cin=inpl, Ho=Ho, Wo=Wo, Cout=planes, taps=[(0, 0)],
+                           stride=stride, stats=s1["part"])
+                self._bn_train(f, f"{name}.bn1", y1, Mo, planes)
+                f.add("simt_bn_apply", y1.data_ptr(), s1["scale"].data_ptr(), s1["shift"].data_ptr(), None, None, None,
+                      None, a1.data_ptr(), Mo, planes, 1, ops.dt_code(dt))
+                self._conv(f, a1, w2, y2, Bn=B, Hi=Ho, Wi=Wo, Cin=planes, Ho=Ho, Wo=Wo, Cout=planes, taps=t3,
+                           stats=s2["part"])
+                self._bn_train(f, f"{name}.bn2", y2, Mo, planes)
+                f.add("simt_bn_apply", y2.data_ptr(), s2["scale"].data_ptr(), s2["shift"].data_ptr(), None, None, None,
+                      None, a2.data_ptr(), Mo, planes, 1, ops.dt_code(dt))
+                self._conv(f, a2, w3, y3, Bn=B, Hi=Ho, Wi=Wo, Cin=planes, Ho=Ho, Wo=Wo, Cout=c4, taps=[(0, 0)],
+                           stats=s3["part"])
+                self._bn_train(f, f"{name}.bn3", y3, Mo, c4)
+                rec.update(y1=y1, a1=a1, y2=y2, a2=a2, y3=y3, z=z)
+                if down:
+                    yd = self.new(Mo, c4)
+                    sd = self._new_bn(f"{name}.downsample.1", Mo, c4)
+                    wd = self._plan_pack(f"{name}.downsample.0", c4, inpl, 1)
+                    self._conv(f, x, wd, yd, Bn=B, Hi=Hc, Wi=Wc, Cin=inpl, Ho=Ho, Wo=Wo, Cout=c4, taps=[(0, 0)],
+                               stride=stride, stats=sd["part"])
+                    self._bn_train(f, f"{name}.downsample.1", yd, Mo, c4)
+                    f.add("simt_bn_apply", y3.data_ptr(), s3["scale"].data_ptr(), s3["shift"].data_ptr(), None,
+                          yd.data_ptr(), sd["scale"].data_ptr(), sd["shift"].data_ptr(), z.data_ptr(), Mo, c4, 1,
+                          ops.dt_code(dt))
+                    rec.update(yd=yd)
+                else:
+                    f.add("simt_bn_apply", y3.data_ptr(), s3["scale"].data_ptr(), s3["shift"].data_ptr(), x.data_ptr(),
+                          None, None, None, z.data_ptr(), Mo, c4, 1, ops.dt_code(dt))
+            else:
+                # eval: BN folded into weights (scale) and bias (shift); ReLU / residual in the conv epilogue
+                a1 = self.buf("e.a1", Mo, planes)
+                a2 = self.buf("e.a2", Mo, planes)
+                z = self.buf("e.z%d" % (len(self.block_io) & 1), Mo, c4)
+                _, sh1 = self._plan_fold(f"{name}.bn1", planes)
+                _, sh2 = self._plan_fold(f"{name}.bn2", planes)
+                _, sh3 = self._plan_fold(f"{name}.bn3", c4)
+                w1 = self._plan_pack(f"{name}.conv1", planes, inpl, 1, scale_bn=f"{name}.bn1")
+                w2 = self._plan_pack(f"{name}.conv2", planes, planes, 3, scale_bn=f"{name}.bn2")
+                w3 = self._plan_pack(f"{name}.conv3", c4, planes, 1, scale_bn=f"{name}.bn3")
+                self._conv(f, x, w1, a1, Bn=B, Hi=Hc, Wi=Wc, Cin=inpl, Ho=Ho, Wo=Wo, Cout=planes, taps=[(0, 0)],
+                           stride=stride, bias=sh1, relu=True)
+                self._conv(f, a1, w2, a2, Bn=B, Hi=Ho, Wi=Wo, Cin=planes, Ho=Ho, Wo=Wo, Cout=planes, taps=t3, bias=sh2,
+                           relu=True)
+                res = x
+                if down:
+                    yd = self.buf("e.yd", Mo, c4)
+                    _, shd = self._plan_fold(f"{name}.downsample.1", c4)
+                    wd = self._plan_pack(f"{name}.downsample.0", c4, inpl, 1, scale_bn=f"{name}.downsample.1")
+                    self._conv(f, x, wd, yd, Bn=B, Hi=Hc, Wi=Wc, Cin=inpl, Ho=Ho, Wo=Wo, Cout=c4, taps=[(0, 0)],
+                               stride=stride, bias=shd)
+                    res = yd
+                self._conv(f, a2, w3, z, Bn=B, Hi=Ho, Wi=Wo, Cin=planes, Ho=Ho, Wo=Wo, Cout=c4, taps=[(0, 0)], bias=sh3,
+                           res=res, relu=True)
+            rec["z"] = z
+            self.block_io.append(rec)
+            x, Hc, Wc = z, Ho, Wo
+            li = int(name[5])
+            feats[li] = (z, Ho, Wo, c4)
+            # heads hang off the LAST block of their layer: emit them right after it so that eval ping-pong
+            # buffers are still intact
+            last_of_layer = (len(self.block_io) == sum(self.layers[:li]))
+            if last_of_layer:
+                for hd in self.heads:
+                    if hd.feat_layer == li:
+                        self._build_head_fwd(hd, z, Ho, Wo, c4)
+        self.feat_hw = (Hc, Wc)
+
+    def _build_head_fwd(self, hd, feat, h, w, cin):
+        """Classifier_Module (+ torch.cat of the open-set head): ONE implicit GEMM, K = len(dil)*9*Cin, N = Q."""
+        B, f = self.B, self.fwd_list
+        Q = hd.Q
+        nd = len(hd.dilations)
+        taps = []
+        for d in hd.dilations:
+            taps += ops.conv_taps(3, 3, d, d)
+        tile = ops.pick_tile_n(Q)
+        npad = ops.round_up(Q, tile)
+        ldp = ops.round_up(Q, 8) if Q > 32 else 32
+        ldp = max(ldp, ops.round_up(Q, 4))
+        wp = self.new(npad, len(taps) * cin, zero=True)
+        bias = self.new(npad, dtype=torch.float32, zero=True)
+        self.packed["head." + hd.name] = (wp, tile, npad)
+        row = 0
+        bias_parts = []
+        for prefix, cout in hd.groups:
+            for i in range(nd):
+                wt = self.p[f"{prefix}.conv2d_list.{i}.weight"]
+                self.pack_list.add("simt_pack_weight", wt.data_ptr(), wp.data_ptr(), cout, cin, 9, row, 9 * i,
+                                   len(taps) * cin, 0, 0, None, ops.dt_code(self.dtype))
+                bias_parts.append((row, cout, self.p[f"{prefix}.conv2d_list.{i}.bias"]))
+            row += cout
+        hd.bias, hd.bias_parts = bias, bias_parts
+        logits = self.new(B * h * w, ldp, dtype=torch.float32, zero=True)
+        self.out[hd.name] = logits.view(B, h, w, ldp)
+        self.ldp[hd.name] = ldp
+        hd.feat, hd.h, hd.w, hd.cin, hd.taps = feat, h, w, cin, taps
+        self._conv(f, feat, (wp, tile, npad), logits, Bn=B, Hi=h, Wi=w, Cin=cin, Ho=h, Wo=w, Cout=Q, taps=taps, bias=bias,
+                   ldy=ldp, Nstore=min(ldp, npad))
+
+    def _refresh_head_bias(self):
+        # bias of the summed branches = sum of the branch biases (tiny; device-side torch adds on raw fp32 params)
+        for hd in self.heads:
+            hd.bias.zero_()
+            for row, cout, b in hd.bias_parts:
+                hd.bias[row:row + cout] += b.detach()
+
+    # ------------------------------------------------------------------ gradients
+    def grad_param_names(self):
+        """Every tensor that receives a gradient (104 trunk convs + live head branches)."""
+        names = ["conv1.weight"]
+        for (name, *_r, down) in self.blocks:
+            names += [f"{name}.conv1.weight", f"{name}.conv2.weight", f"{name}.conv3.weight"]
+            if down:
+                names.append(f"{name}.downsample.0.weight")
+        for hd in self.heads:
+            for prefix, _ in hd.groups:
+                for i in range(len(hd.dilations)):
+                    names += [f"{prefix}.conv2d_list.{i}.weight", f"{prefix}.conv2d_list.{i}.bias"]
+        return names
+
+    def _alloc_grads(self, grad_names=None):
+        names = grad_names or self.grad_param_names()
+        # reverse-topological order: heads of layer4, layer4 ..., heads of layer3, layer3, ..., stem
+        order = []
+        by_layer = {}
+        for n in names:
+            if n.startswith("conv1"):
+                li = 0
+            elif n.startswith("layer") and n[5].isdigit() and "." in n and n.split(".")[0] in ("layer1", "layer2", "layer3",
+                                                                                               "layer4"):
+                li = int(n[5])
+            else:
+                li = None
+            by_layer.setdefault(li, []).append(n)
+        head_names = by_layer.get(None, [])
+        head_feat = {}
+        for hd in self.heads:
+            for prefix, _ in hd.groups:
+                head_feat[prefix] = hd.feat_layer
+        for li in (4, 3, 2, 1, 0):
+            order += [n for n in head_names if head_feat.get(n.split(".")[0]) == li]
+            blk = by_layer.get(li, [])
+            # blocks in reverse order
+            order += sorted(blk, key=lambda n: -int(n.split(".")[1]) if li else 0)
+        total = sum(self.p[n].numel() for n in order)
+        self.flat_grad = torch.zeros(total, device=self.dev, dtype=torch.float32)
+        self.grads, self.grad_order, self.grad_offsets = {}, order, {}
+        off = 0
+        for n in order:
+            k = self.p[n].numel()
+            self.grads[n] = self.flat_grad[off:off + k].view(self.p[n].shape)
+            self.grad_offsets[n] = (off, k)
+            off += k
+
+    # ------------------------------------------------------------------ backward construction
+    def _wgrad(self, lst, dy, x, gname, *, Bn, Hi, Wi, Cin, Ho, Wo, Cd, ldd, taps, stride, parts):
+        """parts: [(param name, co_off, tap_off, Cout, RS, Cin_dst)] slices of the slab reduced into OIHW gradients."""
+        M = Bn * Ho * Wo
+        Ktot = len(taps) * Cin
+        nsplit = ops.wgrad_nsplit(M, Cd, Ktot, self.dtype)
+        assert nsplit * Cd * Ktot <= self._slab_cap
+        slab = self.buf("wgrad.slab", self._slab_cap, dtype=torch.float32)
+        d = ops.make_wgrad_desc(dy, x, slab, B=Bn, H=Hi, W=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cd=Cd, taps=taps, stride=stride,
+                                nsplit=nsplit, ldd=ldd)
+        alg_cd = sum(pt[3] for pt in parts) // max(1, len({pt[2] for pt in parts}))
+        lst.add_desc("simt_conv_wgrad", d, tag=f"conv_wgrad<{'bf16' if self.dtype == torch.bfloat16 else 'f32'}>",
+                     flops=2.0 * M * alg_cd * (147 if parts[0][0] == "conv1.weight" else Ktot),
+                     nbytes=float((M * ldd + Bn * Hi * Wi * Cin) * self.esz + nsplit * Cd * Ktot * 4))
+        for (pname, co_off, tap_off, cout, rs, cin_dst) in parts:
+            lst.add("simt_wgrad_reduce", slab.data_ptr(), self.grads[pname].data_ptr(), nsplit, Cd, Ktot, cin_dst, co_off,
+                    tap_off, cout, rs, 0)
+
+    def _bn_bwd(self, lst, *, dz, y, bname, dy, M, Cn, mask_mode, z=None, y2=None, bname2=None, dy2=None, gout=None):
+        s = self.bn[bname]
+        s2 = self.bn[bname2] if bname2 else None
+        nblk = ops.bn_bwd_nblk(M, Cn)
+        part = self.buf("bnb.part", self._bnb_cap, dtype=torch.float32)
+        coef = self.buf("bnb.coef", 3 * 2048, dtype=torch.float32)
+        assert nblk * 3 * Cn <= self._bnb_cap
+        d = ops.make_bn_bwd_desc(dz=dz, y=y, mean=s["mean"], rstd=s["rstd"], scale=s["scale"], shift=s["shift"], part=part,
+                                 coef=coef, dy=dy, M=M, Cn=Cn, mask_mode=mask_mode, z=z, y2=y2,
+                                 mean2=s2["mean"] if s2 else None, rstd2=s2["rstd"] if s2 else None,
+                                 scale2=s2["scale"] if s2 else None, dy2=dy2, gout=gout)
+        lst.add_desc("simt_bn_bwd", d)
+
+    def _build_backward(self):
+        B, dt, kq = self.B, self.dtype, self.kq
+        b = self.bwd_list
+        # workspace capacities
+        self._slab_cap = 1
+        self._bnb_cap = 1
+        for rec in self.block_io:
+            Mo, p, inpl = rec["Mo"], rec["planes"], rec["inpl"]
+            for (cd, kt) in ((p, inpl), (p, 9 * p), (4 * p, p), (4 * p, inpl)):
+                ns = ops.wgrad_nsplit(Mo, cd, kt, dt)
+                self._slab_cap = max(self._slab_cap, ns * cd * kt)
+            for cn in (p, 4 * p):
+                self._bnb_cap = max(self._bnb_cap, ops.bn_bwd_nblk(Mo, cn) * 3 * cn)
+        M0 = B * self.H0 * self.W0
+        self._slab_cap = max(self._slab_cap, ops.wgrad_nsplit(M0, 64, 192, dt) * 64 * 192)
+        self._bnb_cap = max(self._bnb_cap, ops.bn_bwd_nblk(M0, 64) * 3 * 64)
+        for hd in self.heads:
+            Mh = B * hd.h * hd.w
+            cd = ops.round_up(hd.Q, 8)
+            kt = len(hd.taps) * hd.cin
+            self._slab_cap = max(self._slab_cap, ops.wgrad_nsplit(Mh, cd, kt, dt) * cd * kt)
+
+        # upstream gradients of the head logits, in the conv dtype, K-padded for the dgrad GEMM
+        self.dlogits = {}
+        for hd in self.heads:
+            ck = ops.round_up(hd.Q, kq)
+            self.dlogits[hd.name] = self.new(B * hd.h * hd.w, ck, zero=True)
+            hd.ck = ck
+
+        heads_by_layer = {}
+        for hd in self.heads:
+            heads_by_layer.setdefault(hd.feat_layer, []).append(hd)
+
+        n_blocks = len(self.block_io)
+        self.bwd_marks = {}   # block name -> (first launch, end launch, dz buffer, dx buffer): debugging / DP buckets
+        dz = None  # gradient w.r.t. the current block's output z
+        for bi in range(n_blocks - 1, -1, -1):
+            rec = self.block_io[bi]
+            name, Mo, Mi, p, inpl = rec["name"], rec["Mo"], rec["Mi"], rec["planes"], rec["inpl"]
+            c4 = 4 * p
+            Ho, Wo, Hi, Wi, stride, dil, down = rec["Ho"], rec["Wo"], rec["Hi"], rec["Wi"], rec["stride"], rec["dil"], rec["down"]
+            li = int(name[5])
+            last_of_layer = (bi + 1 == sum(self.layers[:li]))
+            if last_of_layer and li in heads_by_layer:
+                for hd in heads_by_layer[li]:
+                    dz = self._build_head_bwd(hd, dz, Mo, c4, bi)
+            assert dz is not None, "no gradient reaches the last block (a head must sit on the last layer)"
+            blk_start = len(b)
+            # ---- z = relu(bn3(y3) + shortcut)
+            dy3 = self.buf("g.dy3", Mo, c4)
+            g = self.buf("g.g", Mo, c4)
+            dyd = self.buf("g.dyd", Mo, c4) if down else None
+            self._bn_bwd(b, dz=dz, z=rec["z"], y=rec["y3"], bname=f"{name}.bn3", dy=dy3, M=Mo, Cn=c4, mask_mode=1,
+                         y2=rec.get("yd"), bname2=f"{name}.downsample.1" if down else None, dy2=dyd,
+                         gout=None if down else g)
+            # conv3
+            self._wgrad(b, dy3, rec["a2"], None, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4, taps=[(0, 0)],
+                        stride=1, parts=[(f"{name}.conv3.weight", 0, 0, c4, 1, p)])
+            wt3 = self._plan_pack_t(f"{name}.conv3", c4, p, 1)
+            da2 = self.buf("g.da", Mo, p)
+            self._conv(b, dy3, wt3[:3], da2, Bn=B, Hi=Ho, Wi=Wo, Cin=wt3[3], Ho=Ho, Wo=Wo, Cout=p, taps=[(0, 0)])
+            dy2 = self.buf("g.dyp", Mo, p)
+            self._bn_bwd(b, dz=da2, y=rec["y2"], bname=f"{name}.bn2", dy=dy2, M=Mo, Cn=p, mask_mode=2)
+            # conv2 (3x3 dilated)
+            t3 = ops.conv_taps(3, 3, dil, dil)
+            self._wgrad(b, dy2, rec["a1"], None, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cd=p, ldd=p, taps=t3, stride=1,
+                        parts=[(f"{name}.conv2.weight", 0, 0, p, 9, p)])
+            wt2 = self._plan_pack_t(f"{name}.conv2", p, p, 3)
+            da1 = self.buf("g.da", Mo, p)
+            # dy2 has p channels; the dgrad operand is K-padded to ck >= p: equal here because p % kq == 0
+            assert wt2[3] == p and wt3[3] == c4
+            self._conv(b, dy2, wt2[:3], da1, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cout=p,
+                       taps=[(-a, -c) for (a, c) in t3])
+            dy1 = self.buf("g.dyp", Mo, p)
+            self._bn_bwd(b, dz=da1, y=rec["y1"], bname=f"{name}.bn1", dy=dy1, M=Mo, Cn=p, mask_mode=2)
+            # conv1 (+ downsample) wgrads
+            self._wgrad(b, dy1, rec["x"], None, Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Ho, Wo=Wo, Cd=p, ldd=p, taps=[(0, 0)],
+                        stride=stride, parts=[(f"{name}.conv1.weight", 0, 0, p, 1, inpl)])
+            if down:
+                self._wgrad(b, dyd, rec["x"], None, Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4,
+                            taps=[(0, 0)], stride=stride, parts=[(f"{name}.downsample.0.weight", 0, 0, c4, 1, inpl)])
+            # input gradient
+            wt1 = self._plan_pack_t(f"{name}.conv1", p, inpl, 1)
+            assert wt1[3] == p
+            dx = self.buf("g.dx%d" % (bi & 1), Mi, inpl)
+            if stride == 1:
+                if down:
+                    wtd = self._plan_pack_t(f"{name}.downsample.0", c4, inpl, 1)
+                    dxd = self.buf("g.dxd", Mo, inpl)
+                    self._conv(b, dyd, wtd[:3], dxd, Bn=B, Hi=Ho, Wi=Wo, Cin=c4, Ho=Ho, Wo=Wo, Cout=inpl, taps=[(0, 0)])
+                    res = dxd
+                else:
+                    res = g
+                self._conv(b, dy1, wt1[:3], dx, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cout=inpl, taps=[(0, 0)], res=res)
+            else:
+                assert down
+                wtd = self._plan_pack_t(f"{name}.downsample.0", c4, inpl, 1)
+                dxd = self.buf("g.dxd", Mo, inpl)
+                dxl = self.buf("g.dxl", Mo, inpl)
+                self._conv(b, dyd, wtd[:3], dxd, Bn=B, Hi=Ho, Wi=Wo, Cin=c4, Ho=Ho, Wo=Wo, Cout=inpl, taps=[(0, 0)])
+                self._conv(b, dy1, wt1[:3], dxl, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cout=inpl, taps=[(0, 0)], res=dxd)
+                b.add("simt_scatter_stride", dxl.data_ptr(), dx.data_ptr(), B, Hi, Wi, inpl, Ho, Wo, stride, ops.dt_code(dt))
+            self.bwd_marks[name] = (blk_start, len(b), dz, dx)
+            dz = dx
+        # ---- stem: maxpool -> relu/bn -> conv1 wgrad (computed like the reference does)
+        H0, W0, Hp, Wp = self.H0, self.W0, self.Hp, self.Wp
+        da0 = self.buf("g.da0", M0, 64)
+        b.add("simt_maxpool_bwd", dz.data_ptr(), self.saved["stem.idx"].data_ptr(), da0.data_ptr(), B, H0, W0, 64, Hp, Wp,
+              ops.dt_code(dt))
+        dy0 = self.buf("g.dy0", M0, 64)
+        self._bn_bwd(b, dz=da0, y=self.saved["stem.y"], bname="bn1", dy=dy0, M=M0, Cn=64, mask_mode=2)
+        self._wgrad(b, dy0, self.saved["stem.A"], None, Bn=1, Hi=1, Wi=M0, Cin=192, Ho=1, Wo=M0, Cd=64, ldd=64,
+                    taps=[(0, 0)], stride=1, parts=[("conv1.weight", 0, 0, 64, 1, 147)])
+
+    def _build_head_bwd(self, hd, dz_prev, Mo, c4, bi):
+        """wgrad/bias grads of the fused ASPP GEMM and its dgrad into the feature gradient (added to dz_prev)."""
+        B, b = self.B, self.bwd_list
+        dl = self.dlogits[hd.name]
+        Mh = B * hd.h * hd.w
+        nd = len(hd.dilations)
+        cd = ops.round_up(hd.Q, 8)
+        parts = []
+        row = 0
+        for prefix, cout in hd.groups:
+            for i in range(nd):
+                parts.append((f"{prefix}.conv2d_list.{i}.weight", row, 9 * i, cout, 9, hd.cin))
+            row += cout
+        self._wgrad(b, dl, hd.feat, None, Bn=B, Hi=hd.h, Wi=hd.w, Cin=hd.cin, Ho=hd.h, Wo=hd.w, Cd=cd, ldd=hd.ck,
+                    taps=hd.taps, stride=1, parts=parts)
+        # bias gradients: column sums of dlogits; both branches of a group share them
+        bsum = self.new(64, dtype=torch.float32, zero=True)
+        b.add("simt_colsum", dl.data_ptr(), bsum.data_ptr(), Mh, hd.ck, hd.Q, 0, ops.dt_code(self.dtype))
+        hd.bsum = bsum
+        # dgrad: operand [Cin][ntaps*ck] assembled from every branch / group
+        tile = ops.pick_tile_n(hd.cin)
+        npad = ops.round_up(hd.cin, tile)
+        wt = self.new(npad, len(hd.taps) * hd.ck, zero=True)
+        row = 0
+        for prefix, cout in hd.groups:
+            for i in range(nd):
+                w = self.p[f"{prefix}.conv2d_list.{i}.weight"]
+                self.pack_list.add("simt_pack_weight", w.data_ptr(), wt.data_ptr(), cout, hd.cin, 9, row, 9 * i,
+                                   len(hd.taps) * hd.ck, hd.ck, 1, None, ops.dt_code(self.dtype))
+            row += cout
+        dfeat = self.buf("g.dfeat%d" % hd.feat_layer, Mo, c4)
+        self._conv(b, dl, (wt, tile, npad), dfeat, Bn=B, Hi=hd.h, Wi=hd.w, Cin=hd.ck, Ho=hd.h, Wo=hd.w, Cout=hd.cin,
+                   taps=[(-a, -c) for (a, c) in hd.taps], res=dz_prev, alg_k=len(hd.taps) * hd.Q)
+        return dfeat
+
+    # ------------------------------------------------------------------ run
+    def forward(self, x_nchw=None):
+        """x: [B,3,H,W] fp32 CUDA (BGR, mean-subtracted).  Returns {head name: logits [B,h,w,ldp] fp32 (NHWC)}."""
+        if x_nchw is not None:
+            self.x_in.copy_(x_nchw)
+        self._refresh_head_bias()
+        self.fwd_list.run()
+        return self.out
+
+    def backward(self):
+        """Consumes self.dlogits[*] (conv dtype, K-padded); fills self.grads."""
+        self.bwd_list.run()
+        for hd in self.heads:
+            row = 0
+            for prefix, cout in hd.groups:
+                for i in range(len(hd.dilations)):
+                    self.grads[f"{prefix}.conv2d_list.{i}.bias"].copy_(hd.bsum[row:row + cout])
+                row += cout
+        return self.grads

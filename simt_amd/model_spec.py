@@ -1,0 +1,116 @@
+"""Architecture description + initialisation of the DeepLab-v2 ResNet(-101) with SimT heads, as state_dict-keyed
+tensors (the on-disk contract of the reference: 656 keys for DeeplabMulti(19, K, openset=True), NCHW fp32).
+
+Mirrors model/deeplab_multi.py:122-167 (constructor), :144-150 (init: conv ~ N(0, 0.01), BN weight 1 / bias 0),
+model/deeplab.py:120-177 (single 4-branch head), sig_NTM / sig_W parameter init (:248-252, :270-272).
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from .engine import LAYERS, block_specs
+
+IMG_MEAN = (104.00698793, 116.66876762, 122.67891434)      # tools/trainV2_simt.py:34 (BGR)
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def head_names(openset):
+    return ["layer5", "layer6"] + (["layer5_1", "layer6_1"] if openset else [])
+
+
+def state_shapes(num_classes, open_classes=0, openset=False, layers=LAYERS, single_head=False):
+    """Ordered {key: shape}, equal to the reference module's state_dict()."""
+    sh = {}
+
+    def bn(prefix, c):
+        for k, s in (("weight", (c,)), ("bias", (c,)), ("running_mean", (c,)), ("running_var", (c,)),
+                     ("num_batches_tracked", ())):
+            sh[f"{prefix}.{k}"] = s
+
+    sh["conv1.weight"] = (64, 3, 7, 7)
+    bn("bn1", 64)
+    for name, inpl, planes, stride, dil, down in block_specs(layers):
+        sh[f"{name}.conv1.weight"] = (planes, inpl, 1, 1)
+        bn(f"{name}.bn1", planes)
+        sh[f"{name}.conv2.weight"] = (planes, planes, 3, 3)
+        bn(f"{name}.bn2", planes)
+        sh[f"{name}.conv3.weight"] = (planes * 4, planes, 1, 1)
+        bn(f"{name}.bn3", planes * 4)
+        if down:
+            sh[f"{name}.downsample.0.weight"] = (planes * 4, inpl, 1, 1)
+            bn(f"{name}.downsample.1", planes * 4)
+    if single_head:
+        for i in range(4):
+            sh[f"layer5.conv2d_list.{i}.weight"] = (num_classes, 2048, 3, 3)
+            sh[f"layer5.conv2d_list.{i}.bias"] = (num_classes,)
+        return sh
+    for hname in head_names(openset):
+        cin = 1024 if hname.startswith("layer5") else 2048
+        cout = open_classes if hname.endswith("_1") else num_classes
+        for i in range(4):
+            sh[f"{hname}.conv2d_list.{i}.weight"] = (cout, cin, 3, 3)
+            sh[f"{hname}.conv2d_list.{i}.bias"] = (cout,)
+    return sh
+
+
+def reference_init(shapes, seed=1234, device="cpu"):
+    """The reference's constructor init (model/deeplab_multi.py:144-150): every conv weight ~ N(0, 0.01), BN weight 1,
+    bias 0, running stats 0 / 1; head conv biases keep nn.Conv2d's default U(-1/sqrt(fan_in), 1/sqrt(fan_in))."""
+    g = torch.Generator().manual_seed(seed)
+    st = {}
+    for k, shp in shapes.items():
+        if k.endswith("num_batches_tracked"):
+            st[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith("running_var") or (k.endswith(".weight") and len(shp) == 1):
+            st[k] = torch.ones(shp)
+        elif k.endswith("running_mean") or (k.endswith(".bias") and ("bn" in k or "downsample.1" in k)):
+            st[k] = torch.zeros(shp)
+        elif k.endswith(".bias"):
+            wshape = shapes[k[:-4] + "weight"]
+            bound = 1.0 / math.sqrt(wshape[1] * wshape[2] * wshape[3])
+            st[k] = (torch.rand(shp, generator=g) * 2 - 1) * bound
+        else:
+            st[k] = torch.randn(shp, generator=g) * 0.01
+    return {k: v.to(device) for k, v in st.items()}
+
+
+def load_class_dist(name="bapa", path=None):
+    """ClassDist/ClassDist_<name>.npy: float64 [19] class prior of the black-box model's pseudo labels
+    (model/deeplab_multi.py:255 reads ../ClassDist/ClassDist_bapa.npy relative to cwd)."""
+    if path is None:
+        for cand in (os.path.join("..", "ClassDist", f"ClassDist_{name}.npy"),
+                     os.path.join(_HERE, "ClassDist", f"ClassDist_{name}.npy")):
+            if os.path.exists(cand):
+                path = cand
+                break
+    return np.load(path)
+
+
+def ntm_init(num_classes, open_classes, seed):
+    """sig_NTM.NTM: kaiming_normal_(mode='fan_out', nonlinearity='relu') on [Q, C] -> std = sqrt(2 / Q)  (:248-252)."""
+    q = num_classes + open_classes
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(q, num_classes, generator=g) * math.sqrt(2.0 / q)
+
+
+def w_init(num_classes, open_classes):
+    """sig_W.weight: constant 1/(Q-1)  (:270-272)."""
+    q = num_classes + open_classes
+    return torch.full((q, q), 1.0 / (q - 1.0))
+
+
+def synthetic_batch(B, H, W, class_dist, seed=1234, block=16, device="cpu"):
+    """Cityscapes-shaped synthetic input: uint8 image -> BGR minus IMG_MEAN (dataset/cityscapes_dataset.py:
+    97-120 contract), noisy pseudo labels = 16x16 blocks drawn from the class prior, 10 % of blocks ignored (255)."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randint(0, 256, (B, 3, H, W), generator=g).float()
+    img = img - torch.tensor(IMG_MEAN).view(1, 3, 1, 1)
+    hb, wb = (H + block - 1) // block, (W + block - 1) // block
+    p = torch.as_tensor(np.asarray(class_dist), dtype=torch.float64)
+    lab = torch.multinomial(p / p.sum(), B * hb * wb, replacement=True, generator=g).view(B, hb, wb)
+    ign = torch.rand(B, hb, wb, generator=g) < 0.1
+    lab = torch.where(ign, torch.full_like(lab, 255), lab)
+    lab = lab.repeat_interleave(block, 1).repeat_interleave(block, 2)[:, :H, :W].contiguous()
+    return img.to(device), lab.long().to(device)

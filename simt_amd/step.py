@@ -1,0 +1,221 @@
+"""One SimT training iteration on gfx950: the seam the reference lacks (its loss body is inline in
+tools/trainV2_simt.py:308-436).  `SimTTrainer.step(image, label, it)` runs, on the current HIP stream and without a
+host sync:
+
+  1. the 10-step W inner loop incl. Adam and the gradient leak into NTM      (trainV2_simt.py:326-339)  simt_ntm_inner_loop
+  2. the frozen model forward (eval BN folded) -> low-res posterior          (:351-354)               TrunkPlan(train=False)
+  3. the trainable forward (train-mode BN, frozen affine)                     (:370)                   TrunkPlan(train=True)
+  4. the fused head: upsample + softmax + every loss term + anchors           (:354-409)               simt_head_loss
+     Convex / Volume / Anchor + total + d/dNTM                                (:412-424)               simt_ntm_post
+     d/d(low-res logits)                                                      (:428)                   simt_head_grad
+  5. the trunk backward (dgrad + wgrad + BN backward)                         (:428)                   TrunkPlan.backward
+  6. [DP] RCCL all-reduce (mean) of the flat gradient buffer and of dNTM      (new capability)
+  7. SGD with duplicate-listing semantics + Adam on NTM1/NTM2                 (:434-436)               simt_sgd_multi / simt_adam_step
+
+All state lives on the device; scalars are read back only when the caller asks (`losses()`).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+from .engine import LaunchList, TrunkPlan, multi_heads
+
+
+class Hyper:
+    """Hyper-parameters of tools/trainV2_simt.py:34-70 (flag defaults) / sh_simt.sh:16."""
+
+    def __init__(self, num_classes=19, open_classes=15, th_high=0.8, th_low=0.2, lambda_seg=0.1, lambda_place=0.1,
+                 lambda_convex=0.5, lambda_volume=0.1, lambda_anchor=0.5, iter_size=1, lr=2.5e-4, lr_T=2.5e-4,
+                 momentum=0.9, weight_decay=5e-4, power=0.9, num_steps=250000):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+
+def lr_poly(base_lr, it, max_iter, power):
+    return base_lr * ((1 - float(it) / max_iter) ** power)            # trainV2_simt.py:174-175
+
+
+def optim_listing(names, layers_root=("layer3", "layer4"), head_prefixes=("layer5", "layer6", "layer5_1", "layer6_1")):
+    """Multiplicity of each tensor in ResNetMulti.optim_parameters (model/deeplab_multi.py:194-237).
+
+    get_1x_lr_params_NOscale walks `for j in layer.modules(): for k in j.parameters()` -- every sub-module yields the
+    parameters of its whole subtree, so a tensor is listed once per ancestor module inside the layer (the layer
+    itself, its Bottleneck, the leaf; plus the `downsample` Sequential for its members).  group 0 = those, group 1
+    (10x lr) = the heads, listed once."""
+    g0, g1 = {}, {}
+    for n in names:
+        root = n.split(".")[0]
+        if root in layers_root:
+            depth = len(n.split(".")) - 1          # layer3.0.conv1.weight -> 3 ancestors; downsample.0.weight -> 4
+            g0[n] = depth
+        elif root in head_prefixes:
+            g1[n] = 1
+    return g0, g1
+
+
+class SimTTrainer:
+    def __init__(self, state, fixed_state, ntm1, ntm2, hp, class_dist, B, H, W, *, dtype=torch.bfloat16, device="cuda:0",
+                 openset=True, process_group=None, w_init=None, layers=None):
+        self.hp, self.B, self.H, self.W, self.dtype = hp, B, H, W, dtype
+        dev = self.dev = torch.device(device)
+        self.pg = process_group
+        Cn, K = hp.num_classes, hp.open_classes
+        self.C, self.Q = Cn, Cn + K
+        f32 = torch.float32
+        self.params = {k: v.detach().to(dev, f32 if v.dtype != torch.long else torch.long).clone() for k, v in state.items()}
+        self.fixed_params = {k: v.detach().to(dev, f32 if v.dtype != torch.long else torch.long).clone()
+                             for k, v in fixed_state.items()}
+        kw = {"layers": layers} if layers is not None else {}
+        self.plan = TrunkPlan(self.params, B, H, W, multi_heads(Cn, K, openset), dtype=dtype, train=True, **kw)
+        self.fixed = TrunkPlan(self.fixed_params, B, H, W, multi_heads(Cn, 0, False), dtype=dtype, train=False, **kw)
+        h, w = self.plan.heads[1].h, self.plan.heads[1].w
+        self.h, self.w = h, w
+        Q = self.Q
+        # ---- NTM / W state (model/deeplab_multi.py:244-286)
+        self.ntm = [ntm1.detach().to(dev, f32).clone(), ntm2.detach().to(dev, f32).clone()]
+        self.ntm_grad = [torch.zeros(Q, Cn, device=dev) for _ in range(2)]
+        self.ntm_m = [torch.zeros(Q, Cn, device=dev) for _ in range(2)]
+        self.ntm_v = [torch.zeros(Q, Cn, device=dev) for _ in range(2)]
+        wi = w_init if w_init is not None else torch.full((Q, Q), 1.0 / (Q - 1.0))
+        self.wraw = [wi.detach().to(dev, f32).clone() for _ in range(2)]
+        self.w_m = [torch.zeros(Q, Q, device=dev) for _ in range(2)]
+        self.w_v = [torch.zeros(Q, Q, device=dev) for _ in range(2)]
+        self.T = [torch.zeros(Q, Cn, device=dev) for _ in range(2)]
+        self.cd = torch.as_tensor(np.asarray(class_dist), dtype=f32).to(dev)
+        self.inner_steps = 10
+        # ---- head workspaces
+        lib = L.load()
+        self.nblk = lib.simt_head_nblk(B, H, W)
+        self.part = torch.zeros(self.nblk, lib.simt_head_part_floats(Q, Cn), device=dev)
+        self.keys = torch.zeros(lib.simt_head_keys_count(), device=dev, dtype=torch.int64)
+        self.hout = torch.zeros(lib.simt_head_hout_floats(Q, Cn), device=dev)
+        self.lout = torch.zeros(16, device=dev)
+        self.QP = ops.round_up(Q, 8)
+        self.g1 = torch.zeros(2, B, H, w, self.QP, device=dev)
+        self.ldf = self.fixed.ldp["x2"]
+        self.fixp = torch.zeros(B * h * w, self.ldf, device=dev)
+        self.label = torch.zeros(B, H, W, device=dev, dtype=torch.int64)
+        hd = L.HeadDesc()
+        p1, p2 = self.plan.out["x1"], self.plan.out["x2"]
+        hd.pred1, hd.pred2, hd.fixp, hd.label = p1.data_ptr(), p2.data_ptr(), self.fixp.data_ptr(), self.label.data_ptr()
+        hd.T1, hd.T2 = self.T[0].data_ptr(), self.T[1].data_ptr()
+        hd.part, hd.keys, hd.hout, hd.g1 = self.part.data_ptr(), self.keys.data_ptr(), self.hout.data_ptr(), self.g1.data_ptr()
+        hd.dpred1_f32, hd.dpred2_f32 = None, None
+        d1, d2 = self.plan.dlogits["x1"], self.plan.dlogits["x2"]
+        hd.dpred1_t, hd.dpred2_t = d1.data_ptr(), d2.data_ptr()
+        hd.B, hd.h, hd.w, hd.H, hd.W, hd.C, hd.Q = B, h, w, H, W, Cn, Q
+        hd.ldp, hd.ldf, hd.QP, hd.ld_f32, hd.ld_t = self.plan.ldp["x1"], self.ldf, self.QP, 0, d1.shape[1]
+        hd.grad_dtype = ops.dt_code(dtype)
+        hd.th_high, hd.th_low, hd.lambda_seg, hd.lambda_place = hp.th_high, hp.th_low, hp.lambda_seg, hp.lambda_place
+        hd.gscale = 1.0 / hp.iter_size
+        self.head_desc = hd
+        # ---- NTM descriptors
+        ni = L.NtmInnerDesc()
+        for k in range(2):
+            ni.ntm[k], ni.w[k], ni.ntm_grad[k] = self.ntm[k].data_ptr(), self.wraw[k].data_ptr(), self.ntm_grad[k].data_ptr()
+            ni.w_m[k], ni.w_v[k], ni.T_out[k] = self.w_m[k].data_ptr(), self.w_v[k].data_ptr(), self.T[k].data_ptr()
+        ni.class_dist, ni.Q, ni.C, ni.steps = self.cd.data_ptr(), Q, Cn, self.inner_steps
+        ni.beta1, ni.beta2, ni.eps = 0.9, 0.999, 1e-8
+        self.inner_desc = ni
+        npd = L.NtmPostDesc()
+        for k in range(2):
+            npd.ntm[k], npd.w[k], npd.ntm_grad[k] = self.ntm[k].data_ptr(), self.wraw[k].data_ptr(), self.ntm_grad[k].data_ptr()
+        npd.class_dist, npd.hout, npd.lout, npd.Q, npd.C = self.cd.data_ptr(), self.hout.data_ptr(), self.lout.data_ptr(), Q, Cn
+        npd.lambda_seg, npd.lambda_convex, npd.lambda_volume = hp.lambda_seg, hp.lambda_convex, hp.lambda_volume
+        npd.lambda_anchor, npd.gscale = hp.lambda_anchor, 1.0 / hp.iter_size
+        self.post_desc = npd
+        # ---- SGD segments (duplicate listings replayed in registers)
+        self._build_sgd()
+        self.it_done = 0
+
+    # ------------------------------------------------------------------ optimiser plumbing
+    def _build_sgd(self):
+        g0, g1 = optim_listing(self.plan.grads.keys())
+        recs = []
+        self.mom = {}
+        for group, listing in ((0, g0), (1, g1)):
+            for n, mult in listing.items():
+                p, g = self.params[n], self.plan.grads[n]
+                buf = torch.zeros_like(p)
+                self.mom[n] = buf
+                recs.append((p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), mult, group))
+        self.sgd_names = list(g0) + list(g1)
+        seg_dt = np.dtype([("p", "<u8"), ("g", "<u8"), ("buf", "<u8"), ("n", "<i8"), ("mult", "<i4"), ("group", "<i4")])
+        segs = np.array(recs, dtype=seg_dt)
+        chunk = 65536
+        chunks = []
+        for si, r in enumerate(recs):
+            for ci in range((r[3] + chunk - 1) // chunk):
+                chunks.append((si, ci))
+        self.sgd_segs = torch.from_numpy(segs.view(np.uint8).copy()).to(self.dev)
+        self.sgd_chunks = torch.tensor(chunks, dtype=torch.int32).to(self.dev)
+        d = L.SgdDesc()
+        d.segs, d.chunks, d.nchunks, d.chunk = self.sgd_segs.data_ptr(), self.sgd_chunks.data_ptr(), len(chunks), chunk
+        d.momentum, d.dampening = self.hp.momentum, 0.0
+        self.sgd_desc = d
+
+    # ------------------------------------------------------------------ one iteration
+    def step(self, image, label, it=None):
+        """image [B,3,H,W] fp32 (device or host), label [B,H,W] int64.  Returns the device tensor `lout`
+        (total, loss_p1, loss_p2, loss_y1, loss_y2, Place, Convex, Volume, Anchor, vol_ok, ...)."""
+        hp = self.hp
+        it = self.it_done if it is None else it
+        lr = lr_poly(hp.lr, it, hp.num_steps, hp.power)
+        lr_T = lr_poly(hp.lr_T, it, hp.num_steps, hp.power)
+        st = ops.stream_ptr()
+        self.plan.x_in.copy_(image, non_blocking=True)
+        self.label.copy_(label, non_blocking=True)
+        # 1. inner W loop (NTM grads start from zero each iteration: optimizer_t*.zero_grad(), :314-318)
+        for g in self.ntm_grad:
+            g.zero_()
+        ni = self.inner_desc
+        ni.step0, ni.lr = self.inner_steps * self.it_done, lr_T
+        L.call("simt_ntm_inner_loop", C.byref(ni), st)
+        # 2. frozen model -> low-res posterior
+        self.fixed.forward(self.plan.x_in)
+        fl = self.fixed.out["x2"]
+        ops.softmax_rows(fl, self.ldf, self.fixp, self.ldf, self.B * self.h * self.w, self.C)
+        # 3. trainable forward
+        self.plan.forward()
+        # 4. fused head + NTM regularisers + gradients of the low-res logits
+        L.call("simt_head_loss", C.byref(self.head_desc), st)
+        L.call("simt_ntm_post", C.byref(self.post_desc), st)
+        L.call("simt_head_grad", C.byref(self.head_desc), st)
+        # 5. trunk backward
+        self.plan.backward()
+        # 6. data-parallel mean of the gradients (one flat buffer + the two tiny NTM gradients)
+        if self.pg is not None:
+            self._allreduce()
+        # 7. optimisers
+        d = self.sgd_desc
+        d.lr[0], d.lr[1] = lr, lr * 10.0
+        d.wd[0], d.wd[1] = hp.weight_decay, hp.weight_decay
+        d.first_step = 1 if self.it_done == 0 else 0
+        L.call("simt_sgd_multi", C.byref(d), st)
+        for k in range(2):
+            ops.adam_step(self.ntm[k], self.ntm_grad[k], self.ntm_m[k], self.ntm_v[k], lr=lr_T, step=self.it_done + 1)
+        self.plan.repack()
+        self.it_done += 1
+        return self.lout
+
+    def _allreduce(self):
+        import torch.distributed as dist
+        ws = dist.get_world_size(self.pg)
+        if ws == 1:
+            return
+        flat = self.plan.flat_grad
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+        flat.mul_(1.0 / ws)
+        for g in self.ntm_grad:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+            g.mul_(1.0 / ws)
+
+    def losses(self):
+        """Host copy of the scalars of the last step (synchronises)."""
+        v = self.lout.cpu().tolist()
+        keys = ["total", "loss_p1", "loss_p2", "loss_y1", "loss_y2", "place", "convex", "volume", "anchor", "vol_ok"]
+        return dict(zip(keys, v))
