@@ -67,10 +67,10 @@ def single_head(num_classes):
 
 
 class _Launch:
-    __slots__ = ("fn", "args", "keep", "tag", "flops", "bytes")
+    __slots__ = ("fn", "args", "keep", "tag", "flops", "bytes", "shape")
 
-    def __init__(self, fn, args, keep, tag=None, flops=0.0, nbytes=0.0):
-        self.fn, self.args, self.keep, self.tag, self.flops, self.bytes = fn, args, keep, tag, flops, nbytes
+    def __init__(self, fn, args, keep, tag=None, flops=0.0, nbytes=0.0, shape=None):
+        self.fn, self.args, self.keep, self.tag, self.flops, self.bytes, self.shape = fn, args, keep, tag, flops, nbytes, shape
 
 
 class LaunchList:
@@ -79,14 +79,14 @@ class LaunchList:
     def __init__(self):
         self.items = []
 
-    def add(self, name, *args, keep=None, tag=None, flops=0.0, nbytes=0.0):
+    def add(self, name, *args, keep=None, tag=None, flops=0.0, nbytes=0.0, shape=None):
         fn = getattr(L.load(), name)
-        self.items.append(_Launch(fn, args, keep, tag or name, flops, nbytes))
+        self.items.append(_Launch(fn, args, keep, tag or name, flops, nbytes, shape))
 
     def add_desc(self, name, desc, **kw):
         self.add(name, C.byref(desc), keep=desc, **kw)
 
-    def run_timed(self, acc):
+    def run_timed(self, acc, by_shape=None):
         """Replay with a HIP event pair around every launch (on the stream the kernels are launched on) and add
         (milliseconds, algorithmic flops, algorithmic bytes, count) per tag into `acc`.  Measurement only."""
         stream = torch.cuda.current_stream()
@@ -107,6 +107,12 @@ class LaunchList:
             a[1] += it.flops
             a[2] += it.bytes
             a[3] += 1
+            if by_shape is not None and it.shape is not None:
+                b = by_shape.setdefault((it.tag, it.shape), [0.0, 0.0, 0.0, 0])
+                b[0] += e0.elapsed_time(e1)
+                b[1] += it.flops
+                b[2] += it.bytes
+                b[3] += 1
 
     def run(self):
         st = torch.cuda.current_stream().cuda_stream
@@ -226,7 +232,8 @@ class TrunkPlan:
         tn = {torch.bfloat16: "bf16", torch.float32: "f32"}
         tag = f"conv_igemm<{tn[x.dtype]},{tn[y.dtype]},{tile}>"
         nbytes = (Bn * Hi * Wi * Cin + npad * len(taps) * Cin) * x.element_size() + M * Cout * y.element_size()
-        lst.add_desc("simt_conv_fprop", d, tag=tag, flops=2.0 * M * Cout * k, nbytes=float(nbytes))
+        lst.add_desc("simt_conv_fprop", d, tag=tag, flops=2.0 * M * Cout * k, nbytes=float(nbytes),
+                     shape=f"M{M} N{Cout} K{len(taps) * Cin} taps{len(taps)} s{stride}")
 
     def _bn_train(self, lst, bname, y, M, Cn):
         """stats partials were written by the conv epilogue into self.bn[bname]['part']."""
@@ -473,7 +480,8 @@ class TrunkPlan:
         alg_cd = sum(pt[3] for pt in parts) // max(1, len({pt[2] for pt in parts}))
         lst.add_desc("simt_conv_wgrad", d, tag=f"conv_wgrad<{'bf16' if self.dtype == torch.bfloat16 else 'f32'}>",
                      flops=2.0 * M * alg_cd * (147 if parts[0][0] == "conv1.weight" else Ktot),
-                     nbytes=float((M * ldd + Bn * Hi * Wi * Cin) * self.esz + nsplit * Cd * Ktot * 4))
+                     nbytes=float((M * ldd + Bn * Hi * Wi * Cin) * self.esz + nsplit * Cd * Ktot * 4),
+                     shape=f"M{M} Cd{Cd} K{Ktot} taps{len(taps)} split{nsplit}")
         for (pname, co_off, tap_off, cout, rs, cin_dst) in parts:
             lst.add("simt_wgrad_reduce", slab.data_ptr(), self.grads[pname].data_ptr(), nsplit, Cd, Ktot, cin_dst, co_off,
                     tap_off, cout, rs, 0)
