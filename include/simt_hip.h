@@ -176,6 +176,18 @@ typedef struct {
 } simt_sgd_desc;
 int simt_sgd_multi(const simt_sgd_desc* d, simt_stream_t stream);
 
+/* ---- utils/loss.py: CrossEntropy2d (:6-40) and EntropyLoss (:42-49) on NCHW fp32 predictions ----------------------
+ * ws: simt_loss_ws_bytes() bytes of device scratch.  out[0] = loss (mean over valid pixels, weighted like
+ * F.cross_entropy / F.nll_loss with reduction='mean'), out[1] = denominator.  Zero valid pixels -> NaN (reference). */
+int simt_loss_ws_bytes(void);
+int simt_ce2d_fwd(const float* pred, const int64_t* target, const float* weight, int n, int c, int h, int w,
+                  int ignore_label, int is_softmax, void* ws, float* out, simt_stream_t stream);
+int simt_ce2d_bwd(const float* pred, const int64_t* target, const float* weight, int n, int c, int h, int w,
+                  int ignore_label, int is_softmax, const float* out, const float* grad_out, float* dpred,
+                  simt_stream_t stream);
+int simt_entropy2d(const float* x, int n, int c, int h, int w, void* ws, float* out, const float* grad_out, float* dx,
+                   simt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
