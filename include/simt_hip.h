@@ -175,6 +175,8 @@ typedef struct {
   int32_t first_step;  /* 1: momentum buffers are created (= d_p) like torch's first step */
 } simt_sgd_desc;
 int simt_sgd_multi(const simt_sgd_desc* d, simt_stream_t stream);
+/* dst[i] (+)= src[i], fp32: bias of the fused 2-branch ASPP GEMM = sum of the branch biases (deeplab_multi.py:115-119) */
+int simt_vec_acc(float* dst, const float* src, int n, int accumulate, simt_stream_t stream);
 
 /* ---- utils/loss.py: CrossEntropy2d (:6-40) and EntropyLoss (:42-49) on NCHW fp32 predictions ----------------------
  * ws: simt_loss_ws_bytes() bytes of device scratch.  out[0] = loss (mean over valid pixels, weighted like

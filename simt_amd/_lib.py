@@ -101,6 +101,7 @@ SIGNATURES = {
     "simt_sig_w": (_I, [c_p, c_p, c_p, c_p, _I, c_p]),
     "simt_adam_step": (_I, [c_p, c_p, c_p, c_p, _L, f32, f32, f32, f32, _I, c_p]),
     "simt_sgd_multi": (_I, [C.POINTER(SgdDesc), c_p]),
+    "simt_vec_acc": (_I, [c_p, c_p, _I, _I, c_p]),
     "simt_loss_ws_bytes": (_I, []),
     "simt_ce2d_fwd": (_I, [c_p, c_p, c_p, _I, _I, _I, _I, _I, _I, c_p, c_p, c_p]),
     "simt_ce2d_bwd": (_I, [c_p, c_p, c_p, _I, _I, _I, _I, _I, _I, c_p, c_p, c_p, c_p]),

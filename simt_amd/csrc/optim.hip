@@ -58,3 +58,16 @@ extern "C" int simt_sgd_multi(const simt_sgd_desc* d, simt_stream_t stream) {
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
+
+// dst[i] (+)= src[i]   (tiny fp32 vectors: the bias of the fused ASPP GEMM is the sum of its branches' biases,
+// model/deeplab_multi.py:115-119)
+__global__ void vec_acc_kernel(float* dst, const float* src, int n, int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
+}
+extern "C" int simt_vec_acc(float* dst, const float* src, int n, int accumulate, simt_stream_t stream) {
+  SIMT_CHECK(dst && src && n > 0);
+  hipLaunchKernelGGL(vec_acc_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dst, src, n, accumulate);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}

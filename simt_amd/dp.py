@@ -1,0 +1,99 @@
+"""Single-node data parallelism for the SimT iteration: one process per GPU, RCCL (torch.distributed backend "nccl")
+over xGMI.  The reference has no distributed code at all; semantics chosen: every rank runs
+the reference's iteration on its own micro-batch (BN statistics, anchors, CE means are per rank), gradients of the conv
+stack and of NTM1/NTM2 are AVERAGED, the W inner loop is replica-deterministic and needs no exchange.
+
+`BucketReducer` all-reduces ONE flat fp32 gradient buffer in contiguous buckets.  TrunkPlan lays the gradients out in
+the order backward produces them (heads of layer4, layer4.2 ... stem), so a bucket can be launched on a side HIP stream
+as soon as the launch that completes its last tensor has been enqueued -- the exchange of layer4's 60 MB overlaps the
+backward of layer3.  Buckets are sized for xGMI rings (7 links x ~153 GB/s per GPU, per-link bound): few, large
+messages (default 32 MB) rather than NVSwitch-style small ones.
+"""
+import torch
+import torch.distributed as dist
+
+
+def make_buckets(order, sizes, ready, bucket_elems):
+    """order: tensor names in flat-buffer order; sizes[name] elements; ready[name] = launch index after which the tensor
+    is final.  Returns [(start, end, ready_index)] covering the flat buffer contiguously."""
+    out, start, cur, rdy = [], 0, 0, 0
+    for n in order:
+        cur += sizes[n]
+        rdy = max(rdy, ready.get(n, 0))
+        if cur - start >= bucket_elems:
+            out.append((start, cur, rdy))
+            start = cur
+    if cur > start:
+        out.append((start, cur, rdy))
+    # ready indices must be monotone for the in-order hook
+    fixed, m = [], 0
+    for s, e, r in out:
+        m = max(m, r)
+        fixed.append((s, e, m))
+    return fixed
+
+
+class BucketReducer:
+    def __init__(self, flat, buckets, group=None, extra=()):
+        """flat: 1-D fp32 tensor; buckets from make_buckets; extra: small tensors reduced at finish() (NTM grads)."""
+        self.flat, self.buckets, self.group, self.extra = flat, buckets, group, list(extra)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.cuda = flat.is_cuda
+        self.comm = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        backend = dist.get_backend(group) if dist.is_initialized() else ""
+        self.avg = backend == "nccl"
+        self.handles = []
+        self.next = 0
+
+    def start(self):
+        self.handles, self.next = [], 0
+
+    def _reduce(self, t):
+        if self.world == 1:
+            return
+        if self.avg:
+            self.handles.append(dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+        else:
+            self.handles.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), t))
+
+    def ready_upto(self, launch_index):
+        """Called by the backward replay after `launch_index` launches have been enqueued."""
+        while self.next < len(self.buckets) and self.buckets[self.next][2] <= launch_index:
+            s, e, _ = self.buckets[self.next]
+            self.next += 1
+            if self.world == 1:
+                continue
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                with torch.cuda.stream(self.comm):
+                    self.comm.wait_event(ev)
+                    self._reduce(self.flat[s:e])
+            else:
+                self._reduce(self.flat[s:e])
+
+    def finish(self):
+        """Flush remaining buckets + the extra tensors, then make the compute stream wait for the exchange."""
+        self.ready_upto(1 << 60)
+        if self.world == 1:
+            return
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(ev)
+                for t in self.extra:
+                    self._reduce(t)
+        else:
+            for t in self.extra:
+                self._reduce(t)
+        for h in self.handles:
+            if isinstance(h, tuple):
+                h[0].wait()
+                h[1].div_(self.world)
+            else:
+                h.wait()
+        if self.cuda:
+            done = torch.cuda.Event()
+            done.record(self.comm)
+            torch.cuda.current_stream().wait_event(done)

@@ -405,19 +405,16 @@ class TrunkPlan:
                 bias_parts.append((row, cout, self.p[f"{prefix}.conv2d_list.{i}.bias"]))
             row += cout
         hd.bias, hd.bias_parts = bias, bias_parts
+        for pi, (brow, bcout, bt) in enumerate(bias_parts):
+            # bias of the summed branches = sum of the branch biases (first listing of a row range overwrites)
+            first = all(r != brow for (r, _c, _t) in bias_parts[:pi])
+            self.pack_list.add("simt_vec_acc", bias.data_ptr() + 4 * brow, bt.data_ptr(), bcout, 0 if first else 1)
         logits = self.new(B * h * w, ldp, dtype=torch.float32, zero=True)
         self.out[hd.name] = logits.view(B, h, w, ldp)
         self.ldp[hd.name] = ldp
         hd.feat, hd.h, hd.w, hd.cin, hd.taps = feat, h, w, cin, taps
         self._conv(f, feat, (wp, tile, npad), logits, Bn=B, Hi=h, Wi=w, Cin=cin, Ho=h, Wo=w, Cout=Q, taps=taps, bias=bias,
                    ldy=ldp, Nstore=min(ldp, npad))
-
-    def _refresh_head_bias(self):
-        # bias of the summed branches = sum of the branch biases (tiny; device-side torch adds on raw fp32 params)
-        for hd in self.heads:
-            hd.bias.zero_()
-            for row, cout, b in hd.bias_parts:
-                hd.bias[row:row + cout] += b.detach()
 
     # ------------------------------------------------------------------ gradients
     def grad_param_names(self):
@@ -485,6 +482,7 @@ class TrunkPlan:
         for (pname, co_off, tap_off, cout, rs, cin_dst) in parts:
             lst.add("simt_wgrad_reduce", slab.data_ptr(), self.grads[pname].data_ptr(), nsplit, Cd, Ktot, cin_dst, co_off,
                     tap_off, cout, rs, 0)
+            self.grad_ready[pname] = len(lst)
 
     def _bn_bwd(self, lst, *, dz, y, bname, dy, M, Cn, mask_mode, z=None, y2=None, bname2=None, dy2=None, gout=None):
         s = self.bn[bname]
@@ -533,6 +531,7 @@ class TrunkPlan:
             heads_by_layer.setdefault(hd.feat_layer, []).append(hd)
 
         n_blocks = len(self.block_io)
+        self.grad_ready = {}  # param name -> number of backward launches after which its gradient is final
         self.bwd_marks = {}   # block name -> (first launch, end launch, dz buffer, dx buffer): debugging / DP buckets
         dz = None  # gradient w.r.t. the current block's output z
         for bi in range(n_blocks - 1, -1, -1):
@@ -628,10 +627,15 @@ class TrunkPlan:
             row += cout
         self._wgrad(b, dl, hd.feat, None, Bn=B, Hi=hd.h, Wi=hd.w, Cin=hd.cin, Ho=hd.h, Wo=hd.w, Cd=cd, ldd=hd.ck,
                     taps=hd.taps, stride=1, parts=parts)
-        # bias gradients: column sums of dlogits; both branches of a group share them
-        bsum = self.new(64, dtype=torch.float32, zero=True)
-        b.add("simt_colsum", dl.data_ptr(), bsum.data_ptr(), Mh, hd.ck, hd.Q, 0, ops.dt_code(self.dtype))
-        hd.bsum = bsum
+        # bias gradients: column sums of dlogits, written straight into every live branch's bias gradient
+        row = 0
+        for prefix, cout in hd.groups:
+            for i in range(nd):
+                gname = f"{prefix}.conv2d_list.{i}.bias"
+                b.add("simt_colsum", dl.data_ptr() + row * self.esz, self.grads[gname].data_ptr(), Mh, hd.ck, cout, 0,
+                      ops.dt_code(self.dtype))
+                self.grad_ready[gname] = len(b)
+            row += cout
         # dgrad: operand [Cin][ntaps*ck] assembled from every branch / group
         tile = ops.pick_tile_n(hd.cin)
         npad = ops.round_up(hd.cin, tile)
@@ -653,17 +657,23 @@ class TrunkPlan:
         """x: [B,3,H,W] fp32 CUDA (BGR, mean-subtracted).  Returns {head name: logits [B,h,w,ldp] fp32 (NHWC)}."""
         if x_nchw is not None:
             self.x_in.copy_(x_nchw)
-        self._refresh_head_bias()
         self.fwd_list.run()
         return self.out
 
-    def backward(self):
-        """Consumes self.dlogits[*] (conv dtype, K-padded); fills self.grads."""
-        self.bwd_list.run()
-        for hd in self.heads:
-            row = 0
-            for prefix, cout in hd.groups:
-                for i in range(len(hd.dilations)):
-                    self.grads[f"{prefix}.conv2d_list.{i}.bias"].copy_(hd.bsum[row:row + cout])
-                row += cout
+    def backward(self, hook=None):
+        """Consumes self.dlogits[*] (conv dtype, K-padded); fills self.grads.  hook(n): called with the number of launches
+        enqueued so far at every point where another gradient tensor became final (DP bucket reducer)."""
+        if hook is None:
+            self.bwd_list.run()
+            return self.grads
+        cuts = sorted(set(self.grad_ready.values()))
+        items, i0 = self.bwd_list.items, 0
+        seg = LaunchList()
+        for c in cuts:
+            seg.items = items[i0:c]
+            seg.run()
+            hook(c)
+            i0 = c
+        seg.items = items[i0:]
+        seg.run()
         return self.grads

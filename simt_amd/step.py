@@ -60,6 +60,9 @@ def optim_listing(names, layers_root=("layer3", "layer4"), head_prefixes=("layer
 class SimTTrainer:
     def __init__(self, state, fixed_state, ntm1, ntm2, hp, class_dist, B, H, W, *, dtype=torch.bfloat16, device="cuda:0",
                  openset=True, process_group=None, w_init=None, layers=None):
+        if hp.iter_size != 1:
+            raise NotImplementedError("--iter-size > 1 (gradient accumulation, trainV2_simt.py:341) is not implemented; "
+                                      "every shipped configuration of the reference uses 1")
         self.hp, self.B, self.H, self.W, self.dtype = hp, B, H, W, dtype
         dev = self.dev = torch.device(device)
         self.pg = process_group
@@ -77,7 +80,8 @@ class SimTTrainer:
         Q = self.Q
         # ---- NTM / W state (model/deeplab_multi.py:244-286)
         self.ntm = [ntm1.detach().to(dev, f32).clone(), ntm2.detach().to(dev, f32).clone()]
-        self.ntm_grad = [torch.zeros(Q, Cn, device=dev) for _ in range(2)]
+        self._ntm_grad_flat = torch.zeros(2, Q, Cn, device=dev)
+        self.ntm_grad = [self._ntm_grad_flat[0], self._ntm_grad_flat[1]]
         self.ntm_m = [torch.zeros(Q, Cn, device=dev) for _ in range(2)]
         self.ntm_v = [torch.zeros(Q, Cn, device=dev) for _ in range(2)]
         wi = w_init if w_init is not None else torch.full((Q, Q), 1.0 / (Q - 1.0))
@@ -131,6 +135,13 @@ class SimTTrainer:
         # ---- SGD segments (duplicate listings replayed in registers)
         self._build_sgd()
         self.it_done = 0
+        # ---- data parallel: bucketed mean all-reduce overlapped with backward
+        self.reducer = None
+        if self.pg is not None:
+            from .dp import BucketReducer, make_buckets
+            sizes = {n: k for n, (_o, k) in self.plan.grad_offsets.items()}
+            buckets = make_buckets(self.plan.grad_order, sizes, self.plan.grad_ready, bucket_elems=8 << 20)
+            self.reducer = BucketReducer(self.plan.flat_grad, buckets, group=self.pg, extra=[self._ntm_grad_flat])
 
     # ------------------------------------------------------------------ optimiser plumbing
     def _build_sgd(self):
@@ -170,8 +181,7 @@ class SimTTrainer:
         self.plan.x_in.copy_(image, non_blocking=True)
         self.label.copy_(label, non_blocking=True)
         # 1. inner W loop (NTM grads start from zero each iteration: optimizer_t*.zero_grad(), :314-318)
-        for g in self.ntm_grad:
-            g.zero_()
+        self._ntm_grad_flat.zero_()
         ni = self.inner_desc
         ni.step0, ni.lr = self.inner_steps * self.it_done, lr_T
         L.call("simt_ntm_inner_loop", C.byref(ni), st)
@@ -185,11 +195,13 @@ class SimTTrainer:
         L.call("simt_head_loss", C.byref(self.head_desc), st)
         L.call("simt_ntm_post", C.byref(self.post_desc), st)
         L.call("simt_head_grad", C.byref(self.head_desc), st)
-        # 5. trunk backward
-        self.plan.backward()
-        # 6. data-parallel mean of the gradients (one flat buffer + the two tiny NTM gradients)
-        if self.pg is not None:
-            self._allreduce()
+        # 5. trunk backward (+ 6. data-parallel mean of the gradients, bucket by bucket, on a side stream)
+        if self.reducer is not None:
+            self.reducer.start()
+            self.plan.backward(hook=self.reducer.ready_upto)
+            self.reducer.finish()
+        else:
+            self.plan.backward()
         # 7. optimisers
         d = self.sgd_desc
         d.lr[0], d.lr[1] = lr, lr * 10.0
@@ -201,18 +213,6 @@ class SimTTrainer:
         self.plan.repack()
         self.it_done += 1
         return self.lout
-
-    def _allreduce(self):
-        import torch.distributed as dist
-        ws = dist.get_world_size(self.pg)
-        if ws == 1:
-            return
-        flat = self.plan.flat_grad
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
-        flat.mul_(1.0 / ws)
-        for g in self.ntm_grad:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
-            g.mul_(1.0 / ws)
 
     def losses(self):
         """Host copy of the scalars of the last step (synchronises)."""

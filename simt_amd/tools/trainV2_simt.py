@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""SimT training stage on MI355X: the reference's tools/trainV2_simt.py with the same command-line flags
+(tools/trainV2_simt.py:72-157) driving `SimTTrainer` (simt_amd/step.py) -- the whole iteration body of the reference
+(:308-436) runs as HIP kernels; this script is only the outer loop: flags, checkpoint restore by key filter (:248-255),
+data, LR schedule, printing every 100 iterations (:438-441), snapshots (:447-450).
+
+    python -m simt_amd.tools.trainV2_simt --open-classes 15 --learning-rate 6e-4 --learning-rate-T 6e-3 ...
+    torchrun --standalone --local-addr 127.0.0.1 --nproc-per-node 8 -m simt_amd.tools.trainV2_simt ...   (data parallel)
+
+Data: `--synthetic` (default when --data-dir-target does not exist) feeds Cityscapes-shaped synthetic batches
+(SURVEY 8d); a real `cityscapesPseudo`-style loader is the "next" row 3 of SURVEY 8f and plugs in at `batches()`.
+Additions over the reference (all optional): --synthetic, --compute-dtype, --print-every.
+"""
+import argparse
+import os
+import os.path as osp
+import time
+
+import torch
+
+from simt_amd import model_spec as ms
+from simt_amd.step import Hyper, SimTTrainer, lr_poly
+
+
+def get_arguments(argv=None):
+    p = argparse.ArgumentParser(description="SimT (DeepLab-ResNet) on MI355X")
+    p.add_argument("--model", type=str, default="DeepLab")
+    p.add_argument("--target", type=str, default="cityscapes")
+    p.add_argument("--batch-size", type=int, default=1)
+    p.add_argument("--iter-size", type=int, default=1)
+    p.add_argument("--num-workers", type=int, default=4)
+    p.add_argument("--data-dir", type=str, default="")
+    p.add_argument("--data-list", type=str, default="../dataset/gta5_list/train.txt")
+    p.add_argument("--ignore-label", type=int, default=255)
+    p.add_argument("--input-size", type=str, default="1024,512")
+    p.add_argument("--data-dir-target", type=str, default="")
+    p.add_argument("--data-list-target", type=str, default="../dataset/cityscapes_list/pseudo_bapa.lst")
+    p.add_argument("--input-size-target", type=str, default="1024,512")
+    p.add_argument("--is-training", action="store_true")
+    p.add_argument("--learning-rate", type=float, default=2.5e-4)
+    p.add_argument("--learning-rate-T", type=float, default=2.5e-4)
+    p.add_argument("--lambda-seg", type=float, default=0.1)
+    p.add_argument("--Threshold-high", type=float, default=0.8)
+    p.add_argument("--Threshold-low", type=float, default=0.2)
+    p.add_argument("--lambda-Place", type=float, default=0.1)
+    p.add_argument("--lambda-Convex", type=float, default=0.5)
+    p.add_argument("--lambda-Volume", type=float, default=0.1)
+    p.add_argument("--lambda-Anchor", type=float, default=0.5)
+    p.add_argument("--momentum", type=float, default=0.9)
+    p.add_argument("--not-restore-last", action="store_true")
+    p.add_argument("--num-classes", type=int, default=19)
+    p.add_argument("--open-classes", type=int, default=15)
+    p.add_argument("--num-steps", type=int, default=250000)
+    p.add_argument("--num-steps-stop", type=int, default=40000)
+    p.add_argument("--power", type=float, default=0.9)
+    p.add_argument("--random-mirror", action="store_true")
+    p.add_argument("--random-scale", action="store_true")
+    p.add_argument("--random-seed", type=int, default=1234)
+    p.add_argument("--restore-from", type=str, default="../snapshots/resnet_pretrain.pth")
+    p.add_argument("--save-pred-every", type=int, default=1000)
+    p.add_argument("--snapshot-dir", type=str, default="../snapshots/SimT/")
+    p.add_argument("--weight-decay", type=float, default=0.0005)
+    p.add_argument("--gpu", type=int, default=0)
+    p.add_argument("--set", type=str, default="train")
+    p.add_argument("--log-dir", type=str, default="./log/")
+    # additions
+    p.add_argument("--synthetic", action="store_true", help="synthetic Cityscapes-shaped batches")
+    p.add_argument("--compute-dtype", choices=["bf16", "f32"], default="bf16")
+    p.add_argument("--print-every", type=int, default=100)
+    return p.parse_args(argv)
+
+
+def restore(state, path, not_restore_last=False):
+    """Filter-by-key load of an AdaptSegNet-style checkpoint into a fresh state (trainV2_simt.py:248-255)."""
+    if not path or not osp.exists(path):
+        return 0
+    saved = torch.load(path, map_location="cpu")
+    n = 0
+    for k, v in saved.items():
+        if k in state and (not not_restore_last or not k.startswith(("layer5", "layer6"))) and state[k].shape == v.shape:
+            state[k] = v.clone()
+            n += 1
+    return n
+
+
+def batches(args, B, H, W, cd, rank, dev):
+    it = 0
+    while True:
+        yield ms.synthetic_batch(B, H, W, cd, seed=args.random_seed + 1000 * rank + it, device=dev)
+        it += 1
+
+
+def main(argv=None):
+    args = get_arguments(argv)
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(args.gpu)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("trainV2_simt needs a GPU: the SimT hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+    w, h = map(int, args.input_size_target.split(","))
+    C, K = args.num_classes, args.open_classes
+    state = ms.reference_init(ms.state_shapes(C, K, True), seed=args.random_seed)
+    fixed = ms.reference_init(ms.state_shapes(C, 0, False), seed=args.random_seed)
+    n1 = restore(state, args.restore_from, args.not_restore_last)
+    n2 = restore(fixed, args.restore_from)
+    cd = ms.load_class_dist("bapa")
+    hp = Hyper(num_classes=C, open_classes=K, th_high=args.Threshold_high, th_low=args.Threshold_low,
+               lambda_seg=args.lambda_seg, lambda_place=args.lambda_Place, lambda_convex=args.lambda_Convex,
+               lambda_volume=args.lambda_Volume, lambda_anchor=args.lambda_Anchor, iter_size=args.iter_size,
+               lr=args.learning_rate, lr_T=args.learning_rate_T, momentum=args.momentum,
+               weight_decay=args.weight_decay, power=args.power, num_steps=args.num_steps)
+    dtype = torch.bfloat16 if args.compute_dtype == "bf16" else torch.float32
+    tr = SimTTrainer(state, fixed, ms.ntm_init(C, K, args.random_seed + 1), ms.ntm_init(C, K, args.random_seed + 2), hp, cd,
+                     args.batch_size, h, w, dtype=dtype, device=dev, process_group=pg)
+    if rank == 0:
+        print(f"restored {n1}/{n2} tensors from {args.restore_from}; {world} GPU(s), batch {args.batch_size}/GPU, "
+              f"{h}x{w}, {args.compute_dtype}, K={K}")
+        os.makedirs(args.snapshot_dir, exist_ok=True)
+    data = batches(args, args.batch_size, h, w, cd, rank, dev)
+    t0 = time.time()
+    for i_iter in range(args.num_steps):
+        img, lab = next(data)
+        tr.step(img, lab, i_iter)
+        if i_iter % args.print_every == 0 and rank == 0:
+            l = tr.losses()
+            print("iter = {0:8d}/{1:8d}, loss_seg_p = {2:.3f} loss_seg_y = {3:.3f} Convex = {4:.3f} Volume = {5:.3f} "
+                  "Anchor = {6:.3f} Place = {7:.3f}  lr = {8:.2e}  ({9:.1f} img/s)".format(
+                      i_iter, args.num_steps, l["loss_p2"], l["loss_y2"], l["convex"], l["volume"], l["anchor"], l["place"],
+                      lr_poly(args.learning_rate, i_iter, args.num_steps, args.power),
+                      args.batch_size * world * (i_iter + 1) / max(time.time() - t0, 1e-9)))
+        if i_iter >= args.num_steps_stop - 1 or (i_iter % args.save_pred_every == 0 and i_iter != 0):
+            if rank == 0:
+                sd = {k: v.detach().cpu() for k, v in tr.params.items()}
+                torch.save(sd, osp.join(args.snapshot_dir, f"SimT_{i_iter}.pth"))
+            if i_iter >= args.num_steps_stop - 1:
+                break
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -114,3 +114,36 @@ def test_iteration_vs_oracle_batch2_bf16_sanity(dev):
         rg = stg[name].grad
         err = (g.double() - rg.double()).abs().max().item() / max(rg.abs().max().item(), 1e-30)
         assert err < 0.1, f"{name}: {err}"      # ill-conditioned quantities: see tests/test_gpu_trunk.py for the f64-anchored bound
+
+
+def test_dp_hooked_backward_world1_equals_plain(dev):
+    """The data-parallel code path (bucket hook + side stream + RCCL group of size 1) leaves the same parameters as the
+    plain path: the bucketed replay of the backward launch list is the same launches in the same order."""
+    import torch.distributed as dist
+    layers, K = (1, 1, 2, 1), 3
+    st = so.recipe_state(so.state_shapes(19, K, True, layers=layers), seed=11, head_scale=8.0)
+    fst = so.recipe_state(so.state_shapes(19, 0, False, layers=layers), seed=12, head_scale=8.0)
+    hp = Hyper(open_classes=K, lr=6e-4, lr_T=6e-3)
+    img, lab = so.synthetic_batch(2, 97, 97, CD.numpy(), seed=5, block=8)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        outs = []
+        for pg in (None, dist.group.WORLD):
+            tr = SimTTrainer(st, fst, so.ntm_init(19, K, 1), so.ntm_init(19, K, 2), hp, CD.numpy(), 2, 97, 97,
+                             dtype=torch.float32, device=dev, layers=layers, process_group=pg)
+            if pg is not None:
+                assert len(tr.reducer.buckets) >= 1 and tr.reducer.buckets[-1][1] == tr.plan.flat_grad.numel()
+            for it in range(2):
+                tr.step(img.to(dev), lab.to(dev), it)
+            torch.cuda.synchronize()
+            outs.append(({k: v.clone() for k, v in tr.params.items() if v.dtype != torch.long}, tr.lout.clone()))
+        for k in outs[0][0]:
+            assert torch.equal(outs[0][0][k], outs[1][0][k]), k
+        assert torch.equal(outs[0][1], outs[1][1])
+    finally:
+        if created:
+            dist.destroy_process_group()
