@@ -44,7 +44,7 @@ typedef struct {
   int32_t Npad;        /* rows of w, multiple of tile_n */
   int32_t Nstore;      /* columns written, multiple of 8, <= ldy */
   int32_t ldy, ldr, stride, ntaps, relu;
-  int32_t dtype_in, dtype_out, tile_n; /* tile_n in {128,64,32} */
+  int32_t dtype_in, dtype_out, tile_n; /* tile_n in {128,64,32}; bf16 -> bf16 also 256 */
   int16_t dy[SIMT_MAX_TAPS], dx[SIMT_MAX_TAPS];
 } simt_conv_desc;
 int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);

@@ -263,16 +263,20 @@ static int launch_conv(const ConvKArgs& k, hipStream_t st) {
   return SIMT_OK;
 }
 
+int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream);  // conv_igemm2.hip
+
 extern "C" int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream) {
   SIMT_CHECK(d && d->x && d->w && d->y);
   SIMT_CHECK(d->ntaps >= 1 && d->ntaps <= SIMT_MAX_TAPS);
   const int esz = d->dtype_in == SIMT_BF16 ? 2 : 4;
   SIMT_CHECK((d->Cin * esz) % 128 == 0);          // K-stage = 128 B of one tap
-  SIMT_CHECK(d->tile_n == 128 || d->tile_n == 64 || d->tile_n == 32);
+  const bool v2 = d->dtype_in == SIMT_BF16 && d->dtype_out == SIMT_BF16 && d->tile_n >= 64;
+  SIMT_CHECK(d->tile_n == 128 || d->tile_n == 64 || d->tile_n == 32 || (v2 && d->tile_n == 256));
   SIMT_CHECK(d->Npad % d->tile_n == 0 && d->Npad >= d->Cout);
   SIMT_CHECK(d->Nstore % 8 == 0 && d->Nstore <= d->Npad && d->Nstore <= d->ldy);
   SIMT_CHECK(d->ldy % 8 == 0 && (!d->res || d->ldr % 8 == 0));
   SIMT_CHECK(!(d->dtype_in == SIMT_F32 && d->dtype_out == SIMT_BF16));
+  if (v2) return simt_conv_fprop_bf16_v2(d, stream);
   ConvKArgs k;
   k.x = (const char*)d->x; k.w = (const char*)d->w; k.y = d->y; k.bias = d->bias; k.res = d->res;
   k.stats = d->stats; k.zero = (const char*)simt_zero_page();

@@ -1,0 +1,391 @@
+// Implicit-GEMM convolution, bf16 throughput kernel (fprop and dgrad) for gfx950 -- second generation.
+//
+// Same contract as conv_igemm.hip (simt_conv_desc; reference model/deeplab_multi.py:62,68,73,110,156 and their
+// dgrads), built around what the per-shape profile of round 1 showed: the 128x128 / 2-buffer kernel kept only 64 KB in
+// flight per CU and was latency-bound at ~6 TB/s of L2->LDS fill.  Here:
+//   * tile 128 pixels x BN couts (BN = 256 / 128 / 64), K-stage = 128 B (64 bf16) of one tap, 8 waves (512 threads),
+//     one workgroup per CU, a 3-deep global_load_lds ring (2 stages = up to 96 KB in flight while the third is
+//     multiplied), counted s_waitcnt vmcnt(N) + raw s_barrier: ONE barrier per K-stage, loads never drained in the loop;
+//   * A-gather addressing hoisted: per-row 32-bit pixel offset + a 64-bit tap-validity mask computed once, per stage
+//     only a bit test, an add and a select per 16-B chunk (the old kernel re-derived iy/ix and divided per stage);
+//   * MFMA operands swapped (weights = A operand, pixels = B operand) so every accumulator register quad is 4 consecutive
+//     output channels of one pixel: the epilogue converts to bf16 in registers, writes 8 B per quad into a padded LDS
+//     tile and streams it out as whole 512-B rows with bias / residual / ReLU applied on the way;
+//   * BatchNorm batch statistics from the fp32 accumulators by in-register + DPP (16-lane) reduction, one
+//     deterministic slot per (pixel tile, channel).
+//   * flexible pixel tile: a workgroup owns `rows` <= BM consecutive pixels (BM = 128 or 160 allocated), rows chosen on
+//     the host so that the grid is a whole number of 256-CU rounds (M = 37636: 255 tiles of 148 rows instead of 295
+//     of 128 -> one round instead of two);
+//   * the two waves of a SIMD run the K-stage in opposite order: waves 0-3 load-then-multiply, waves 4-7 multiply the
+//     fragments they fetched in the previous stage first and load afterwards, so one wave's MFMA burst covers the other
+//     wave's global_load_lds issue + ds_read latency (MI355X_MICROARCH "two waves per SIMD", item 9).
+// LDS rows are 128 B; the 16-B chunk index is XOR-swizzled with (row>>1)&7 on the global SOURCE address and on the
+// ds_read_b128 side (conflict-free 16-lane groups), the LDS image itself stays lane-linear as global_load_lds needs.
+#include "common.h"
+
+struct Conv2KArgs {
+  const char* x;
+  const char* w;
+  bf16_t* y;
+  const float* bias;
+  const bf16_t* res;
+  float* stats;
+  const char* zero;
+  int H, W, Ho, Wo, Cout, Nstore, ldy, ldr, stride, ntaps, relu, M;
+  int kc_per_tap, pix_bytes, wrow_bytes;
+  int ntiles_n, ntiles_m;
+  int rows;        // pixels per tile (<= BM)
+  int nblk128;     // stats slots allocated by the caller: ceil(M/128) >= ntiles_m
+  int toff[SIMT_MAX_TAPS];   // (dy*W + dx) * pix_bytes: 32-bit so that the uniform per-stage lookup is an s_load_dword
+                             // (a 16-bit table compiles to global_load_sshort, whose vmcnt(0) drains the glds ring)
+  short dy[SIMT_MAX_TAPS], dx[SIMT_MAX_TAPS];
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 8, "unsupported vmcnt");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+__device__ __forceinline__ float row16_sum(float v) {
+  // sum over the 16 lanes that share lane>>4 (DPP row operations)
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// MODE 0 = product.  MODE 1 (loads only) and MODE 2 (MFMA only) are timing-ablation builds selected by the environment
+// variable SIMT_CONV2_MODE; their outputs are meaningless.
+template <int BN, int TMP, int MODE>
+__global__ __launch_bounds__(512, 2) void conv_igemm2_kernel(Conv2KArgs a) {
+  constexpr int NT = 512, NST = 3;
+  constexpr int WM = (BN == 64) ? 4 : 2;          // waves along pixels
+  constexpr int WN = 8 / WM;                       // waves along couts
+  constexpr int TM = TMP, TN = BN / WN / 16;
+  constexpr int BM = WM * TM * 16;                 // allocated pixel rows (128 or 160)
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_IT = (BM * 8 + NT - 1) / NT, B_IT = BN * 8 / NT;   // 16-B chunks per thread per stage
+  constexpr bool A_TAIL = (BM * 8) % NT != 0;      // BM = 160: the third A pass is only issued by waves 0-3
+  constexpr int CP = BN * 2 + 8;                   // epilogue tile pitch in bytes (bf16 row + 8 B pad)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int nwg = a.ntiles_m * a.ntiles_n;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int mt = tile / a.ntiles_n, nt = tile - mt * a.ntiles_n;
+  const int m0 = mt * a.rows, n0 = nt * BN;
+  const int m_end = min(a.M, m0 + a.rows);
+
+  // ---- hoisted A-gather metadata: chunk q = i*NT + tid -> row = q>>3, position q&7
+  const int c_pos = tid & 7;
+  const int a_cg = c_pos ^ (((tid >> 3) >> 1) & 7);          // (row>>1)&7 only depends on tid>>3 because NT/8 = 64 is even
+  unsigned a_off[A_IT];
+  unsigned long long a_ok[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int row = i * (NT / 8) + (tid >> 3);
+    const int m = m0 + row;
+    a_ok[i] = 0ull;
+    a_off[i] = 0u;
+    if (m < m_end) {
+      const int hw = a.Ho * a.Wo;
+      const int b = m / hw;
+      const int r = m - b * hw;
+      const int oy = r / a.Wo;
+      const int ox = r - oy * a.Wo;
+      const int iy = oy * a.stride, ix = ox * a.stride;
+      a_off[i] = (unsigned)(((b * a.H + iy) * a.W + ix)) * (unsigned)a.pix_bytes + (unsigned)(a_cg * 16);
+      unsigned long long msk = 0ull;
+      for (int t = 0; t < a.ntaps; ++t) {
+        const int yy = iy + a.dy[t], xx = ix + a.dx[t];
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) msk |= (1ull << t);
+      }
+      a_ok[i] = msk;
+    }
+  }
+  unsigned b_off[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int row = i * (NT / 8) + (tid >> 3);
+    b_off[i] = (unsigned)(n0 + row) * (unsigned)a.wrow_bytes + (unsigned)(a_cg * 16);
+  }
+  const char* zsrc = a.zero + a_cg * 16;
+  const bool a_tail_wave = !A_TAIL || wave < (BM * 8 - (A_IT - 1) * NT) / 64;
+
+  int ld_tap = 0, ld_kc = 0, ld_kt = 0;          // position of the NEXT stage to be issued
+  auto issue = [&](int buf) {
+    const int toff = a.toff[ld_tap] + ld_kc * 128;
+    char* sbase = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      if (i == A_IT - 1 && !a_tail_wave) break;
+      const bool ok = (a_ok[i] >> ld_tap) & 1ull;
+      const char* src = ok ? a.x + (unsigned)(a_off[i] + (unsigned)toff) : zsrc;
+      __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sbase + (i * NT + wave * 64) * 16), 16, 0, 0);
+    }
+    const unsigned wk = (unsigned)ld_kt * 128u;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i)
+      __builtin_amdgcn_global_load_lds(GPTR(a.w + (b_off[i] + wk)), LPTR(sbase + A_BYTES + (i * NT + wave * 64) * 16), 16, 0, 0);
+    ++ld_kt;
+    if (++ld_kc == a.kc_per_tap) { ld_kc = 0; ++ld_tap; }
+  };
+  // outstanding vector-memory ops of ONE stage for this wave (the counted wait leaves exactly one stage in flight)
+  auto wait_stage = [&](bool more) {
+    if (!more) { wait_vmcnt<0>(); return; }
+    if constexpr (A_TAIL) {
+      if (!a_tail_wave) { wait_vmcnt<A_IT - 1 + B_IT>(); return; }
+    }
+    wait_vmcnt<A_IT + B_IT>();
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.ntaps * a.kc_per_tap;
+  const int sw = (lane >> 1) & 7;
+  const int frag_row_off = (lane & 15) * 128;
+  const int kq = lane >> 4;
+  const int xbase = (wm * TM * 16) * 128 + frag_row_off;
+  const int wbase = A_BYTES + (wn * TN * 16) * 128 + frag_row_off;
+
+  bf16x8 xf[2][TM], wf[2][TN];
+  auto load_frags = [&](int buf) {
+    const char* px = smem + buf * STAGE + xbase;
+    const char* pw = smem + buf * STAGE + wbase;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int coff = ((4 * s + kq) ^ sw) << 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xf[s][i] = *(const bf16x8*)(px + i * 16 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[s][j] = *(const bf16x8*)(pw + j * 16 * 128 + coff);
+    }
+  };
+  auto mma = [&]() {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][j], xf[s][i], acc[j][i], 0, 0, 0);
+  };
+
+  if (MODE != 2) {
+    issue(0);
+    if (nk > 1) issue(1);
+  }
+  int buf = 0;
+  if (wave < 4) {
+    // ---- early half: [barrier] issue(kt+2) -> fragments(kt) -> MFMA(kt)
+    for (int kt = 0; kt < nk; ++kt) {
+      if (MODE != 2) wait_stage(kt + 1 < nk);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (MODE != 2 && kt + 2 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);     // (kt+2)%3 == (buf+2)%3
+      if (MODE != 1) {
+        load_frags(buf);
+        mma();
+      }
+      buf = (buf + 1 == NST) ? 0 : buf + 1;
+    }
+  } else {
+    // ---- late half: [barrier] MFMA(kt-1) from registers -> issue(kt+2) -> fragments(kt) (kept for the next stage)
+    for (int kt = 0; kt < nk; ++kt) {
+      if (MODE != 2) wait_stage(kt + 1 < nk);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my fragment reads of stage kt-1 are done before anyone refills
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (MODE != 1 && kt > 0) mma();
+      if (MODE != 2 && kt + 2 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
+      if (MODE != 1) load_frags(buf);
+      buf = (buf + 1 == NST) ? 0 : buf + 1;
+    }
+    if (MODE != 1) mma();
+  }
+
+  // ---------------- epilogue ----------------
+  // acc[j][i][e]: cout = n0 + wn*TN*16 + j*16 + (lane>>4)*4 + e ; pixel row = wm*TM*16 + i*16 + (lane&15)
+  __syncthreads();
+  char* sC = smem;                                   // [BM][CP] bytes, bf16
+  float* sS = (float*)(smem + BM * CP);              // [WM][2][BN]
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float v = acc[j][i][e];
+          s1 += v;
+          s2 += v * v;
+        }
+        s1 = row16_sum(s1);
+        s2 = row16_sum(s2);
+        if ((lane & 15) == 0) {
+          const int c = wn * TN * 16 + j * 16 + (lane >> 4) * 4 + e;
+          sS[(wm * 2 + 0) * BN + c] = s1;
+          sS[(wm * 2 + 1) * BN + c] = s2;
+        }
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int r = wm * TM * 16 + i * 16 + (lane & 15);
+      const int c = wn * TN * 16 + j * 16 + (lane >> 4) * 4;
+      uint2 pk;
+      pk.x = (uint32_t)f2bf(acc[j][i][0]) | ((uint32_t)f2bf(acc[j][i][1]) << 16);
+      pk.y = (uint32_t)f2bf(acc[j][i][2]) | ((uint32_t)f2bf(acc[j][i][3]) << 16);
+      *(uint2*)(sC + r * CP + c * 2) = pk;
+    }
+  __syncthreads();
+  if (a.stats && tid < BN) {
+    const int n = n0 + tid;
+    if (n < a.Cout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < WM; ++q) {
+        t1 += sS[(q * 2 + 0) * BN + tid];
+        t2 += sS[(q * 2 + 1) * BN + tid];
+      }
+      a.stats[((long)mt * 2 + 0) * a.Cout + n] = t1;
+      a.stats[((long)mt * 2 + 1) * a.Cout + n] = t2;
+      if (mt == 0)   // the caller sums ceil(M/128) slots; tiles of more than 128 rows leave the tail unused: zero it
+        for (int sl = a.ntiles_m; sl < a.nblk128; ++sl) {
+          a.stats[((long)sl * 2 + 0) * a.Cout + n] = 0.f;
+          a.stats[((long)sl * 2 + 1) * a.Cout + n] = 0.f;
+        }
+    }
+  }
+  constexpr int VPR = BN / 8;        // 16-B vectors per row
+  constexpr int RPP = NT / VPR;      // rows per pass
+  const int vcol = (tid % VPR) * 8;
+  const int n = n0 + vcol;
+  if (n < a.Nstore) {
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = (a.bias && (n + e) < a.Cout) ? a.bias[n + e] : 0.f;
+    const bool plain = !a.bias && !a.res && !a.relu;
+    for (int r = tid / VPR; r < BM; r += RPP) {
+      const int m = m0 + r;
+      if (m >= m_end) break;
+      const uint2 lo = *(const uint2*)(sC + r * CP + vcol * 2);
+      const uint2 hi = *(const uint2*)(sC + r * CP + vcol * 2 + 8);
+      uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      if (!plain) {
+        float v[8];
+        v[0] = __uint_as_float(o.x << 16); v[1] = __uint_as_float(o.x & 0xffff0000u);
+        v[2] = __uint_as_float(o.y << 16); v[3] = __uint_as_float(o.y & 0xffff0000u);
+        v[4] = __uint_as_float(o.z << 16); v[5] = __uint_as_float(o.z & 0xffff0000u);
+        v[6] = __uint_as_float(o.w << 16); v[7] = __uint_as_float(o.w & 0xffff0000u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+        if (a.res) {
+          float rv[8];
+          load8(a.res + (long)m * a.ldr + n, rv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        store8(a.y + (long)m * a.ldy + n, v);
+      } else {
+        *(uint4*)(a.y + (long)m * a.ldy + n) = o;
+      }
+    }
+  }
+}
+
+template <int BN, int TM, int MODE>
+static int launch_conv2m(const Conv2KArgs& k, hipStream_t st) {
+  constexpr int WM = (BN == 64) ? 4 : 2;
+  constexpr int BM = WM * TM * 16;
+  const size_t ring = 3 * (size_t)(BM * 128 + BN * 128);
+  const size_t epi = (size_t)BM * (BN * 2 + 8) + (size_t)4 * 2 * BN * 4;
+  const size_t lds = ring > epi ? ring : epi;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm2_kernel<BN, TM, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm2_kernel<BN, TM, MODE>), dim3(k.ntiles_m * k.ntiles_n), dim3(512), lds, st, k);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+#include <stdlib.h>
+template <int BN, int TM>
+static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("SIMT_CONV2_MODE");
+    mode = e ? atoi(e) : 0;
+  }
+  if (mode == 1) return launch_conv2m<BN, TM, 1>(k, st);
+  if (mode == 2) return launch_conv2m<BN, TM, 2>(k, st);
+  return launch_conv2m<BN, TM, 0>(k, st);
+}
+
+// Pixel rows per tile: 128 (TM = 4) or, for the 2x4 wave layouts, up to 160 (TM = 5) when that saves a whole round of
+// the 256 CUs.  Cost model: rounds * allocated rows.
+static void pick_rows(int M, int ntn, bool allow160, int* rows, int* tm) {
+  const int CUS = 256;
+  long best = -1;
+  *rows = 128; *tm = 4;
+  for (int r = 128; r <= (allow160 ? 160 : 128); r += 4) {
+    const int tiles = (M + r - 1) / r;
+    const long rounds = ((long)tiles * ntn + CUS - 1) / CUS;
+    const long cost = rounds * (r <= 128 ? 128 : 160);
+    if (best < 0 || cost < best) { best = cost; *rows = r; *tm = r <= 128 ? 4 : 5; }
+  }
+}
+
+// Called by simt_conv_fprop (conv_igemm.hip) for bf16 -> bf16 problems with tile_n in {64, 128, 256}.
+int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
+  Conv2KArgs k;
+  k.x = (const char*)d->x; k.w = (const char*)d->w; k.y = (bf16_t*)d->y; k.bias = d->bias; k.res = (const bf16_t*)d->res;
+  k.stats = d->stats; k.zero = (const char*)simt_zero_page();
+  k.H = d->H; k.W = d->W; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout; k.Nstore = d->Nstore; k.ldy = d->ldy; k.ldr = d->ldr;
+  k.stride = d->stride; k.ntaps = d->ntaps; k.relu = d->relu; k.M = d->B * d->Ho * d->Wo;
+  k.kc_per_tap = d->Cin * 2 / 128;
+  k.pix_bytes = d->Cin * 2;
+  k.wrow_bytes = d->ntaps * d->Cin * 2;
+  k.ntiles_n = d->Npad / d->tile_n;
+  int tm = 4;
+  pick_rows(k.M, k.ntiles_n, d->tile_n != 64, &k.rows, &tm);
+  k.ntiles_m = (k.M + k.rows - 1) / k.rows;
+  k.nblk128 = (k.M + 127) / 128;
+  SIMT_CHECK((long)d->B * d->H * d->W * d->Cin * 2 < (1l << 32));      // 32-bit byte offsets
+  SIMT_CHECK((long)d->Npad * k.wrow_bytes < (1l << 32));
+  for (int i = 0; i < SIMT_MAX_TAPS; ++i) {
+    k.dy[i] = d->dy[i];
+    k.dx[i] = d->dx[i];
+    k.toff[i] = (d->dy[i] * d->W + d->dx[i]) * k.pix_bytes;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (d->tile_n == 256) return tm == 5 ? launch_conv2<256, 5>(k, st) : launch_conv2<256, 4>(k, st);
+  if (d->tile_n == 128) return tm == 5 ? launch_conv2<128, 5>(k, st) : launch_conv2<128, 4>(k, st);
+  return launch_conv2<64, 2>(k, st);
+}

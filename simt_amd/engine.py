@@ -186,7 +186,7 @@ class TrunkPlan:
     # ------------------------------------------------------------------ weight packing
     def _plan_pack(self, cname, cout, cin, k, *, scale_bn=None, K_cin=None):
         """fprop operand [Npad][ntaps*Cin_k]; with scale_bn (eval) the BN scale is folded per output channel."""
-        tile = ops.pick_tile_n(cout)
+        tile = ops.pick_tile_n(cout, self.dtype)
         npad = ops.round_up(cout, tile)
         cin_k = K_cin or cin
         wp = self.new(npad, cin_k if cname == "conv1" else k * k * cin_k, zero=True)
@@ -205,7 +205,7 @@ class TrunkPlan:
     def _plan_pack_t(self, cname, cout, cin, k):
         """dgrad operand [Cin_pad][ntaps*Ck], Ck = cout rounded to the K quantum."""
         ck = ops.round_up(cout, self.kq)
-        tile = ops.pick_tile_n(cin)
+        tile = ops.pick_tile_n(cin, self.dtype)
         npad = ops.round_up(cin, tile)
         wt = self.new(npad, k * k * ck, zero=True)
         self.packed_t[cname] = (wt, tile, npad, ck)
@@ -637,7 +637,7 @@ class TrunkPlan:
                 self.grad_ready[gname] = len(b)
             row += cout
         # dgrad: operand [Cin][ntaps*ck] assembled from every branch / group
-        tile = ops.pick_tile_n(hd.cin)
+        tile = ops.pick_tile_n(hd.cin, self.dtype)
         npad = ops.round_up(hd.cin, tile)
         wt = self.new(npad, len(hd.taps) * hd.ck, zero=True)
         row = 0

@@ -44,27 +44,30 @@ def _fill_taps(arr_dy, arr_dx, taps):
         arr_dx[i] = b
 
 
-def pick_tile_n(cout):
+def pick_tile_n(cout, dtype=None):
+    """Output-channel tile of the implicit GEMM; 256 exists only in the bf16 throughput kernel (conv_igemm2.hip)."""
     if cout <= 32:
         return 32
     if cout <= 64:
         return 64
-    return 128
+    if cout <= 128 or dtype != torch.bfloat16:
+        return 128
+    return 256
 
 
 def round_up(a, b):
     return (a + b - 1) // b * b
 
 
-def packed_rows(cout, tile_n=None):
-    tile_n = tile_n or pick_tile_n(cout)
+def packed_rows(cout, tile_n=None, dtype=None):
+    tile_n = tile_n or pick_tile_n(cout, dtype)
     return round_up(cout, tile_n)
 
 
 def make_conv_desc(x, w, y, *, B, H, W, Cin, Ho, Wo, Cout, taps, stride=1, bias=None, res=None, stats=None, relu=False,
                    Npad=None, Nstore=None, ldy=None, ldr=None, tile_n=None):
     d = L.ConvDesc()
-    tile_n = tile_n or pick_tile_n(Cout)
+    tile_n = tile_n or pick_tile_n(Cout, x.dtype if x.dtype == y.dtype else None)
     d.x, d.w, d.y = _p(x), _p(w), _p(y)
     d.bias, d.res, d.stats = _p(bias), _p(res), _p(stats)
     d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, Cin, Ho, Wo, Cout

@@ -47,7 +47,7 @@ def test_conv_fprop_dgrad_wgrad(dev, dtype, case):
     taps = ops.conv_taps(k, k, dil, pad)
 
     x_d = x.permute(0, 2, 3, 1).contiguous().to(dev, dtype)
-    tile = ops.pick_tile_n(Cout)
+    tile = ops.pick_tile_n(Cout, dtype)
     Npad = ops.round_up(Cout, tile)
     wp = torch.zeros(Npad, len(taps) * Cin, device=dev, dtype=dtype)
     ops.pack_weight(w.to(dev).contiguous(), wp, Cout=Cout, Cin=Cin, RS=k * k, ldk=len(taps) * Cin, mode=0)
@@ -90,7 +90,7 @@ def test_conv_fprop_dgrad_wgrad(dev, dtype, case):
     # ---- dgrad (stride 1 only; the stride-2 1x1 goes through scatter_stride)
     esz = 2 if dtype == torch.bfloat16 else 4
     Ck = ops.round_up(Cout, 128 // esz)
-    tile_b = ops.pick_tile_n(Cin)
+    tile_b = ops.pick_tile_n(Cin, dtype)
     wb = torch.zeros(ops.round_up(Cin, tile_b), len(taps) * Ck, device=dev, dtype=dtype)
     ops.pack_weight(w.to(dev).contiguous(), wb, Cout=Cout, Cin=Cin, RS=k * k, ldk=len(taps) * Ck, Ck=Ck, mode=1)
     dyk = torch.zeros(B, Ho, Wo, Ck, device=dev, dtype=dtype)
