@@ -279,7 +279,7 @@ __global__ void bn_bwd_apply_kernel(const T* dz, const T* z, const T* y, const f
 
 static inline int bn_bwd_rows_per_block(long M, int C) {
   int rpar = 256 / (C / 8);
-  long target_blocks = 2048;
+  long target_blocks = 512;   // partials are [nblk][3][C] floats re-read by the finalize pass: keep them small
   long rpb = (M + target_blocks - 1) / target_blocks;
   rpb = ((rpb + rpar - 1) / rpar) * rpar;
   if (rpb < rpar * 4) rpb = rpar * 4;

@@ -11,8 +11,8 @@
 //   * MFMA operands swapped (weights = A operand, pixels = B operand) so every accumulator register quad is 4 consecutive
 //     output channels of one pixel: the epilogue converts to bf16 in registers, writes 8 B per quad into a padded LDS
 //     tile and streams it out as whole 512-B rows with bias / residual / ReLU applied on the way;
-//   * BatchNorm batch statistics from the fp32 accumulators by in-register + DPP (16-lane) reduction, one
-//     deterministic slot per (pixel tile, channel).
+//   * BatchNorm batch statistics (sum, sum of squares of the values as stored) accumulated by the same row-streaming pass,
+//     row groups combined in fixed order through LDS: one deterministic slot per (pixel tile, channel).
 //   * flexible pixel tile: a workgroup owns `rows` <= BM consecutive pixels (BM = 128 or 160 allocated), rows chosen on
 //     the host so that the grid is a whole number of 256-CU rounds (M = 37636: 255 tiles of 148 rows instead of 295
 //     of 128 -> one round instead of two);
@@ -52,15 +52,6 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-}
-
-__device__ __forceinline__ float row16_sum(float v) {
-  // sum over the 16 lanes that share lane>>4 (DPP row operations)
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
-  return v;
 }
 
 // MODE 0 = product.  MODE 1 (loads only) and MODE 2 (MFMA only) are timing-ablation builds selected by the environment
@@ -225,28 +216,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm2_kernel(Conv2KArgs a) {
   // acc[j][i][e]: cout = n0 + wn*TN*16 + j*16 + (lane>>4)*4 + e ; pixel row = wm*TM*16 + i*16 + (lane&15)
   __syncthreads();
   char* sC = smem;                                   // [BM][CP] bytes, bf16
-  float* sS = (float*)(smem + BM * CP);              // [WM][2][BN]
-  if (a.stats) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const float v = acc[j][i][e];
-          s1 += v;
-          s2 += v * v;
-        }
-        s1 = row16_sum(s1);
-        s2 = row16_sum(s2);
-        if ((lane & 15) == 0) {
-          const int c = wn * TN * 16 + j * 16 + (lane >> 4) * 4 + e;
-          sS[(wm * 2 + 0) * BN + c] = s1;
-          sS[(wm * 2 + 1) * BN + c] = s2;
-        }
-      }
-  }
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -259,60 +228,82 @@ __global__ __launch_bounds__(512, 2) void conv_igemm2_kernel(Conv2KArgs a) {
       *(uint2*)(sC + r * CP + c * 2) = pk;
     }
   __syncthreads();
-  if (a.stats && tid < BN) {
-    const int n = n0 + tid;
-    if (n < a.Cout) {
-      float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-      for (int q = 0; q < WM; ++q) {
-        t1 += sS[(q * 2 + 0) * BN + tid];
-        t2 += sS[(q * 2 + 1) * BN + tid];
-      }
-      a.stats[((long)mt * 2 + 0) * a.Cout + n] = t1;
-      a.stats[((long)mt * 2 + 1) * a.Cout + n] = t2;
-      if (mt == 0)   // the caller sums ceil(M/128) slots; tiles of more than 128 rows leave the tail unused: zero it
-        for (int sl = a.ntiles_m; sl < a.nblk128; ++sl) {
-          a.stats[((long)sl * 2 + 0) * a.Cout + n] = 0.f;
-          a.stats[((long)sl * 2 + 1) * a.Cout + n] = 0.f;
-        }
-    }
-  }
+  // Stream the tile out as whole rows (16 B per lane, 512-B rows) with bias / residual / ReLU applied on the way, and
+  // accumulate the BatchNorm statistics (sum, sum of squares of the STORED bf16 values of the valid rows) per lane.
   constexpr int VPR = BN / 8;        // 16-B vectors per row
-  constexpr int RPP = NT / VPR;      // rows per pass
+  constexpr int RPP = NT / VPR;      // rows per pass (= number of row groups)
   const int vcol = (tid % VPR) * 8;
+  const int rg = tid / VPR;
   const int n = n0 + vcol;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
   if (n < a.Nstore) {
     float bias8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = (a.bias && (n + e) < a.Cout) ? a.bias[n + e] : 0.f;
     const bool plain = !a.bias && !a.res && !a.relu;
-    for (int r = tid / VPR; r < BM; r += RPP) {
+    for (int r = rg; r < BM; r += RPP) {
       const int m = m0 + r;
       if (m >= m_end) break;
       const uint2 lo = *(const uint2*)(sC + r * CP + vcol * 2);
       const uint2 hi = *(const uint2*)(sC + r * CP + vcol * 2 + 8);
       uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      if (!plain) {
+      if (!plain || a.stats) {
         float v[8];
         v[0] = __uint_as_float(o.x << 16); v[1] = __uint_as_float(o.x & 0xffff0000u);
         v[2] = __uint_as_float(o.y << 16); v[3] = __uint_as_float(o.y & 0xffff0000u);
         v[4] = __uint_as_float(o.z << 16); v[5] = __uint_as_float(o.z & 0xffff0000u);
         v[6] = __uint_as_float(o.w << 16); v[7] = __uint_as_float(o.w & 0xffff0000u);
+        if (a.stats) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bias8[e];
-        if (a.res) {
-          float rv[8];
-          load8(a.res + (long)m * a.ldr + n, rv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
         }
-        if (a.relu) {
+        if (!plain) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+          if (a.res) {
+            float rv[8];
+            load8(a.res + (long)m * a.ldr + n, rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          }
+          if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          store8(a.y + (long)m * a.ldy + n, v);
+          continue;
         }
-        store8(a.y + (long)m * a.ldy + n, v);
-      } else {
-        *(uint4*)(a.y + (long)m * a.ldy + n) = o;
+      }
+      *(uint4*)(a.y + (long)m * a.ldy + n) = o;
+    }
+  }
+  if (a.stats) {
+    // combine the RPP row groups in fixed order: sR[rg][2][BN] floats behind the tile
+    float* sR = (float*)(smem + BM * CP);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sR[(rg * 2 + 0) * BN + vcol + e] = s1[e];
+      sR[(rg * 2 + 1) * BN + vcol + e] = s2[e];
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int nn = n0 + tid;
+      if (nn < a.Cout) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < RPP; ++q) {
+          t1 += sR[(q * 2 + 0) * BN + tid];
+          t2 += sR[(q * 2 + 1) * BN + tid];
+        }
+        a.stats[((long)mt * 2 + 0) * a.Cout + nn] = t1;
+        a.stats[((long)mt * 2 + 1) * a.Cout + nn] = t2;
+        if (mt == 0)   // the caller sums ceil(M/128) slots; tiles of more than 128 rows leave the tail unused: zero it
+          for (int sl = a.ntiles_m; sl < a.nblk128; ++sl) {
+            a.stats[((long)sl * 2 + 0) * a.Cout + nn] = 0.f;
+            a.stats[((long)sl * 2 + 1) * a.Cout + nn] = 0.f;
+          }
       }
     }
   }
@@ -323,7 +314,7 @@ static int launch_conv2m(const Conv2KArgs& k, hipStream_t st) {
   constexpr int WM = (BN == 64) ? 4 : 2;
   constexpr int BM = WM * TM * 16;
   const size_t ring = 3 * (size_t)(BM * 128 + BN * 128);
-  const size_t epi = (size_t)BM * (BN * 2 + 8) + (size_t)4 * 2 * BN * 4;
+  const size_t epi = (size_t)BM * (BN * 2 + 8) + (size_t)(512 / (BN / 8)) * 2 * BN * 4;
   const size_t lds = ring > epi ? ring : epi;
   static bool attr_set = false;
   if (!attr_set) {

@@ -350,18 +350,35 @@ __global__ __launch_bounds__(256) void head_pass1_kernel(HeadArgs a) {
 //   [16+2QC+2QMAX  .. +QMAX)      anchor pixel index1 (as float bits of int), then index2 [QMAX]
 //   [16+2QC+4QMAX  .. +QC)        dTy1 = d(loss_y1)/dT1 (mean-normalised, unweighted), then dTy2
 // --------------------------------------------------------------------------------------------------------
+// Column sums of the block partials, 32 columns x 8 row lanes per block (fixed combination order, double precision):
+// replaces a single block walking 2048 rows serially (2.5 ms at 4x768x768).
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float* part, int nblk, int stride, int ncols, double* sums) {
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s = 0.0;
+  if (c < ncols)
+    for (int b = r; b < nblk; b += 8) s += (double)part[(long)b * stride + c];
+  red[r][cl] = s;
+  __syncthreads();
+  if (r == 0 && c < ncols) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][cl];
+    sums[c] = t;
+  }
+}
+
+__device__ __forceinline__ double* head_sums(float* hout, int Q, int C) {
+  // 8-byte aligned region behind the documented float layout of hout
+  return (double*)(hout + ((16 + 4 * Q * C + 4 * QMAX + 1) & ~1));
+}
+
 __global__ __launch_bounds__(256) void head_finalize_kernel(HeadArgs a, int nblk) {
   const HeadGeom g = a.g;
   const int Q = g.Q, C = g.C, QC = Q * C;
   const int tid = threadIdx.x;
-  __shared__ double sc[NSCAL];
-  const int stride = NSCAL + 2 * QC;
-  if (tid < NSCAL) {
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)a.part[(long)b * stride + tid];
-    sc[tid] = s;
-  }
-  __syncthreads();
+  const double* sc = head_sums(a.hout, Q, C);
   float* o = a.hout;
   const double Np = sc[8], Nk1 = sc[9], Nk2 = sc[10], Ny = sc[11];
   if (tid == 0) {
@@ -374,11 +391,7 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(HeadArgs a, int nblk
   }
   // dTy: -(1/Ny) * sum_p [label=c] q_j / r
   float* dTy = o + 16 + 2 * QC + 4 * QMAX;
-  for (int i = tid; i < 2 * QC; i += 256) {
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)a.part[(long)b * stride + NSCAL + i];
-    dTy[i] = (float)(-s / Ny);
-  }
+  for (int i = tid; i < 2 * QC; i += 256) dTy[i] = (float)(-sc[NSCAL + i] / Ny);
   // anchors
   float* ex = o + 16 + 2 * QC;
   float* ai = ex + 2 * QMAX;
@@ -606,7 +619,9 @@ extern "C" int simt_head_nblk(int B, int H, int W) {
   return (int)n;
 }
 extern "C" int simt_head_part_floats(int Q, int C) { return NSCAL + 2 * Q * C; }
-extern "C" int simt_head_hout_floats(int Q, int C) { return 16 + 4 * Q * C + 4 * QMAX; }
+extern "C" int simt_head_hout_floats(int Q, int C) {
+  return ((16 + 4 * Q * C + 4 * QMAX + 1) & ~1) + 2 * (NSCAL + 2 * Q * C);   // + the double-precision column sums
+}
 extern "C" int simt_head_keys_count(void) { return 2 * QMAX + 2; }
 
 // losses (pass 1 + finalize).  keys must be zeroed by this call: done here with a memset node on the stream.
@@ -620,6 +635,12 @@ extern "C" int simt_head_loss(const simt_head_desc* d, simt_stream_t stream) {
   size_t lds1 = pass1_lds(d->Q, d->C);
   hipLaunchKernelGGL(head_pass1_kernel, dim3(nblk), dim3(256), lds1, st, a);
   SIMT_LAUNCH_CHECK();
+  {
+    const int ncols = NSCAL + 2 * d->Q * d->C;
+    double* sums = (double*)(d->hout + ((16 + 4 * d->Q * d->C + 4 * QMAX + 1) & ~1));
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((ncols + 31) / 32), dim3(256), 0, st, d->part, nblk, ncols, ncols, sums);
+    SIMT_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, st, a, nblk);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
