@@ -198,6 +198,8 @@ __global__ void wgrad_reduce_kernel(const float* slab, float* dst, int nsplit, i
   dst[d] = accumulate ? dst[d] + s : s;
 }
 
+int simt_conv_wgrad_bf16_v2(const simt_wgrad_desc* d, simt_stream_t stream);  // conv_wgrad2.hip
+
 extern "C" int simt_conv_wgrad(const simt_wgrad_desc* d, simt_stream_t stream) {
   SIMT_CHECK(d && d->dy && d->x && d->slab);
   SIMT_CHECK(d->ntaps >= 1 && d->ntaps <= SIMT_MAX_TAPS);
@@ -205,6 +207,8 @@ extern "C" int simt_conv_wgrad(const simt_wgrad_desc* d, simt_stream_t stream) {
   const int epc = 16 / esz;
   SIMT_CHECK(d->Cin % epc == 0 && d->Cd % epc == 0 && d->ldd % epc == 0 && d->Cd <= d->ldd);
   SIMT_CHECK(d->nsplit >= 1);
+  if (d->dtype == SIMT_BF16 && d->Cd >= 128 && d->ntaps * d->Cin >= 256 && (d->stride != 1 || (d->H == d->Ho && d->W == d->Wo)))
+    return simt_conv_wgrad_bf16_v2(d, stream);
   WgradKArgs k;
   k.dy = (const char*)d->dy; k.x = (const char*)d->x; k.slab = d->slab; k.zero = (const char*)simt_zero_page();
   k.B = d->B; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Ho = d->Ho; k.Wo = d->Wo; k.Cd = d->Cd; k.ldd = d->ldd;

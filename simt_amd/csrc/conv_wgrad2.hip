@@ -1,0 +1,230 @@
+// Weight-gradient implicit GEMM, bf16 throughput kernel -- second generation (same contract as conv_wgrad.hip:
+// simt_wgrad_desc -> fp32 slabs [split][Cd][Ktot] summed in fixed order by simt_wgrad_reduce; reference
+// tools/trainV2_simt.py:428 through model/deeplab_multi.py:62,68,73,156).
+//
+// Same skeleton as conv_igemm2.hip: 8 waves, one workgroup per CU, 3-deep global_load_lds ring with counted vmcnt and
+// one raw barrier per stage, the two waves of a SIMD staggered (load-then-multiply vs multiply-then-load).
+// Output tile 128 (dY channels) x 256 (tap*cin columns), reduction over 64 pixels per stage.  Both MFMA operands are
+// pixel-major in memory, so each stage holds three [64 px][128 ch] images (dY, X columns 0-127, X columns 128-255) that
+// are read back transposed with ds_read_b64_tr_b16; the 16-B chunk index is XOR-swizzled by h(pixel)<<1 on the global
+// source address so the 8 pixel rows a 32-lane half touches land in distinct 32-B slots.
+// Stride-1 convolutions need no per-stage division for the tap-shifted source pixel: input pixel = m + dy*W + dx.
+#include "common.h"
+
+struct Wgrad2KArgs {
+  const char* dy;
+  const char* x;
+  float* slab;
+  const char* zero;
+  int H, W, Cin, Ho, Wo, Cd, ldd, stride, ntaps, M, Ktot;
+  int nsplit, pix_per_split, cotiles, ktiles;
+  float rcpWo, rcpHoWo;
+  short tdy[SIMT_MAX_TAPS], tdx[SIMT_MAX_TAPS];
+};
+
+template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
+  constexpr int NT = 512, NST = 3, BP = 64;
+  constexpr int ROWB = 256;                  // bytes per LDS row (128 channels)
+  constexpr int SUB = BP * ROWB;             // 16 KB image
+  constexpr int STAGE = 3 * SUB;             // dY | X[0:128) | X[128:256)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;   // 2 x 4 waves, 64 x 64 outputs each
+
+  int bid = blockIdx.x;
+  const int split = bid % a.nsplit;
+  bid /= a.nsplit;
+  const int kt_ = bid % a.ktiles, ct = bid / a.ktiles;
+  const int co0 = ct * 128, k0 = kt_ * 256;
+
+  // chunk q = i*NT + tid of an image: row = q>>4 = i*32 + (tid>>4), position q&15
+  const int c_pos = tid & 15;
+  const int row_in_iter = tid >> 4;
+  const int h = ((row_in_iter & 3) | (((row_in_iter >> 3) & 1) << 2)) << 1;
+  const int cg = c_pos ^ h;
+  const int dch = co0 + cg * 8;
+  const bool d_ok = dch < a.Cd;
+  int xoff[2], tdy[2], tdx[2];
+  bool k_ok[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int kk = k0 + s * 128 + cg * 8;
+    k_ok[s] = kk < a.Ktot;
+    int tap = 0, ci = 0;
+    if (k_ok[s]) { tap = kk / a.Cin; ci = kk - tap * a.Cin; }
+    tdy[s] = a.tdy[tap];
+    tdx[s] = a.tdx[tap];
+    xoff[s] = ((tdy[s] * a.W + tdx[s]) * a.Cin + ci) * 2;       // byte shift of the source for stride-1 convs
+  }
+  const int pix_bytes = a.Cin * 2;
+  const int ldd_bytes = a.ldd * 2;
+  const int HoWo = a.Ho * a.Wo;
+  const bool s1 = a.stride == 1;
+  const bool center[2] = {tdy[0] == 0 && tdx[0] == 0, tdy[1] == 0 && tdx[1] == 0};
+
+  const int m_begin = split * a.pix_per_split;
+  int m_end = m_begin + a.pix_per_split;
+  if (m_end > a.M) m_end = a.M;
+  const int nk = (m_end > m_begin) ? (m_end - m_begin + BP - 1) / BP : 0;
+  const char* zsrc = a.zero + c_pos * 16;
+
+  int ld_m = m_begin;
+  auto issue = [&](int buf) {
+    char* sbase = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = ld_m + i * 32 + row_in_iter;
+      const bool mok = m < m_end;
+      const char* srcd = (mok && d_ok) ? a.dy + ((unsigned)m * (unsigned)ldd_bytes + (unsigned)(dch * 2)) : zsrc;
+      int oy = 0, ox = 0, b = 0;
+      if (!(s1 && center[0] && center[1])) {
+        int r;
+        fast_divmod(m, HoWo, a.rcpHoWo, b, r);
+        fast_divmod(r, a.Wo, a.rcpWo, oy, ox);
+      }
+      const char* srcx[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        srcx[s] = zsrc;
+        if (mok && k_ok[s]) {
+          if (s1) {
+            const int iy = oy + tdy[s], ix = ox + tdx[s];
+            if (center[s] || (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W))
+              srcx[s] = a.x + (unsigned)((unsigned)m * (unsigned)pix_bytes + (unsigned)xoff[s]);
+          } else {
+            const int iy = oy * a.stride + tdy[s], ix = ox * a.stride + tdx[s];
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+              srcx[s] = a.x + ((unsigned)((b * a.H + iy) * a.W + ix) * (unsigned)pix_bytes + (unsigned)(xoff[s] - (tdy[s] * a.W + tdx[s]) * pix_bytes));
+          }
+        }
+      }
+      const int ldsoff = (i * NT + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds(GPTR(srcd), LPTR(sbase + ldsoff), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GPTR(srcx[0]), LPTR(sbase + SUB + ldsoff), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GPTR(srcx[1]), LPTR(sbase + 2 * SUB + ldsoff), 16, 0, 0);
+    }
+    ld_m += BP;
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // transposed fragment addressing: lane l: g = l>>4 (k group), q = (l&15)>>2 (row in 4-row block), pp = l&3
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int hh = (q | ((g & 1) << 2)) << 1;
+  int offa[4], offb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int cba = wm * 64 + t * 16, cbb = (wn & 1) * 64 + t * 16;
+    offa[t] = (8 * g + q) * ROWB + ((((cba >> 3) + (pp >> 1)) ^ hh) << 4) + (pp & 1) * 8;
+    offb[t] = (1 + (wn >> 1)) * SUB + (8 * g + q) * ROWB + ((((cbb >> 3) + (pp >> 1)) ^ hh) << 4) + (pp & 1) * 8;
+  }
+  bf16x8 af[2][4], bfr[2][4];
+  auto load_frags = [&](int buf) {
+    const char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const char* pa = base + ks * 32 * ROWB + offa[t];
+        const char* pb = base + ks * 32 * ROWB + offb[t];
+        bf4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)(pa));
+        bf4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)(pa + 4 * ROWB));
+        bf4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)(pb));
+        bf4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)(pb + 4 * ROWB));
+        bf16x4 a0s = __builtin_bit_cast(bf16x4, a0), a1s = __builtin_bit_cast(bf16x4, a1);
+        bf16x4 b0s = __builtin_bit_cast(bf16x4, b0), b1s = __builtin_bit_cast(bf16x4, b1);
+        af[ks][t] = (bf16x8){a0s[0], a0s[1], a0s[2], a0s[3], a1s[0], a1s[1], a1s[2], a1s[3]};
+        bfr[ks][t] = (bf16x8){b0s[0], b0s[1], b0s[2], b0s[3], b1s[0], b1s[1], b1s[2], b1s[3]};
+      }
+  };
+  auto mma = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+  };
+
+  if (nk > 0) issue(0);
+  if (nk > 1) issue(1);
+  int buf = 0;
+  if (wave < 4) {
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) wg_wait_vmcnt<6>(); else wg_wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 2 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
+      load_frags(buf);
+      mma();
+      buf = (buf + 1 == NST) ? 0 : buf + 1;
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) wg_wait_vmcnt<6>(); else wg_wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt > 0) mma();
+      if (kt + 2 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
+      load_frags(buf);
+      buf = (buf + 1 == NST) ? 0 : buf + 1;
+    }
+    if (nk > 0) mma();
+  }
+
+  // slab[split][co][k]: lane&15 -> 16 consecutive k (64-B segments), 4 rows per accumulator
+  float* out = a.slab + (long)split * a.Cd * a.Ktot;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = co0 + wm * 64 + i * 16 + (lane >> 4) * 4 + e;
+        const int k = k0 + wn * 64 + j * 16 + (lane & 15);
+        if (co < a.Cd && k < a.Ktot) out[(long)co * a.Ktot + k] = acc[i][j][e];
+      }
+}
+
+// Called by simt_conv_wgrad (conv_wgrad.hip) for bf16 problems with Cd >= 128.
+int simt_conv_wgrad_bf16_v2(const simt_wgrad_desc* d, simt_stream_t stream) {
+  Wgrad2KArgs k;
+  k.dy = (const char*)d->dy; k.x = (const char*)d->x; k.slab = d->slab; k.zero = (const char*)simt_zero_page();
+  k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Ho = d->Ho; k.Wo = d->Wo; k.Cd = d->Cd; k.ldd = d->ldd;
+  k.stride = d->stride; k.ntaps = d->ntaps; k.M = d->B * d->Ho * d->Wo; k.Ktot = d->ntaps * d->Cin;
+  SIMT_CHECK(k.M < (1 << 24));
+  SIMT_CHECK((long)k.M * d->ldd * 2 < (1l << 32) && (long)d->B * d->H * d->W * d->Cin * 2 < (1l << 32));
+  SIMT_CHECK(d->stride == 1 ? (d->H == d->Ho && d->W == d->Wo) : true);
+  k.nsplit = d->nsplit;
+  const int pps = (k.M + k.nsplit - 1) / k.nsplit;
+  k.pix_per_split = ((pps + 63) / 64) * 64;
+  k.cotiles = (d->Cd + 127) / 128;
+  k.ktiles = (k.Ktot + 255) / 256;
+  k.rcpWo = 1.0f / (float)d->Wo;
+  k.rcpHoWo = 1.0f / (float)(d->Ho * d->Wo);
+  for (int i = 0; i < SIMT_MAX_TAPS; ++i) { k.tdy[i] = d->dy_[i]; k.tdx[i] = d->dx_[i]; }
+  static bool attr_set = false;
+  const int lds = 3 * 3 * 64 * 256;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int grid = k.cotiles * k.ktiles * k.nsplit;
+  hipLaunchKernelGGL(conv_wgrad2_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, k);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}

@@ -100,6 +100,19 @@ def conv_wgrad_desc(d):
 
 
 def wgrad_nsplit(M, Cd, Ktot, dtype, target_wg=768):
+    """Split factor over the pixel dimension.  bf16 / Cd >= 128 / Ktot >= 256 runs the 128x256-tile kernel with one
+    workgroup per CU: aim at a whole number of 256-CU rounds; otherwise the 128x128 kernel at ~3 workgroups per CU."""
+    if dtype == torch.bfloat16 and Cd >= 128 and Ktot >= 256:
+        tiles = ((Cd + 127) // 128) * ((Ktot + 255) // 256)
+        max_split = max(1, M // (64 * 8))
+        best, best_cost = 1, None
+        for ns in range(1, min(max_split, 64) + 1):
+            rounds = -(-tiles * ns // 256)
+            stages = -(-M // (ns * 64))
+            cost = rounds * (stages + 6)            # + epilogue/prologue per workgroup
+            if best_cost is None or cost < best_cost:
+                best, best_cost = ns, cost
+        return best
     tiles = ((Cd + 127) // 128) * ((Ktot + 127) // 128)
     bp = 64 if dtype == torch.bfloat16 else 32
     max_split = max(1, M // (bp * 4))
