@@ -64,6 +64,24 @@ int simt_conv_wgrad(const simt_wgrad_desc* d, simt_stream_t stream);
 int simt_wgrad_reduce(const float* slab, float* dst, int nsplit, int Cd, int Ktot, int Cin, int co_off, int tap_off,
                       int Cout, int RS, int accumulate, simt_stream_t stream);
 
+/* ---- tap-expanded ASPP classifier (bf16 throughput path; model/deeplab_multi.py:104-119) -------------------------
+ * The N = Q = 22 dilated conv is re-associated into a plain GEMM with one output column per (tap, class) plus a
+ * tap gather-sum (forward) / tap scatter (backward); see csrc/head_expand.hip.
+ *   simt_tap_gather_sum: dst[m][n] = bias[n] + sum_t src[m + (dy,dx)[t]][t*QP + n]       (fp32 -> fp32)
+ *   simt_tap_scatter   : dst[m][t*QP + n] = src[m - (dy,dx)[t]][n], 0 outside the image   (bf16 -> bf16)
+ *   simt_wgrad_reduce_exp: slab[split][(tap_off+t)*QP + row_off + co][ci] -> OIHW fp32 gradient */
+typedef struct {
+  const void* src;
+  const float* bias;   /* [Q] or NULL (gather_sum only) */
+  void* dst;
+  int32_t B, H, W, Q, QP, lds, ldd, ntaps;   /* lds / ldd: row pitch of src / dst in elements */
+  int16_t dy[SIMT_MAX_TAPS], dx[SIMT_MAX_TAPS];
+} simt_tap_desc;
+int simt_tap_gather_sum(const simt_tap_desc* d, simt_stream_t stream);
+int simt_tap_scatter(const simt_tap_desc* d, simt_stream_t stream);
+int simt_wgrad_reduce_exp(const float* slab, float* dst, int nsplit, int Cd, int Cin, int QP, int row_off, int tap_off,
+                          int Cout, int RS, simt_stream_t stream);
+
 /* ---- weight packing / BN folding ------------------------------------------------------------------------ */
 int simt_pack_weight(const float* w, void* dst, int Cout, int Cin, int RS, int row_off, int tap_off, long ldk, int Ck,
                      int mode, const float* cscale, int dtype, simt_stream_t stream);

@@ -63,6 +63,12 @@ class NtmPostDesc(C.Structure):
                 ("gscale", f32)]
 
 
+class TapDesc(C.Structure):
+    _fields_ = [("src", c_p), ("bias", c_p), ("dst", c_p),
+                ("B", i32), ("H", i32), ("W", i32), ("Q", i32), ("QP", i32), ("lds", i32), ("ldd", i32), ("ntaps", i32),
+                ("dy", C.c_int16 * MAX_TAPS), ("dx", C.c_int16 * MAX_TAPS)]
+
+
 class SgdDesc(C.Structure):
     _fields_ = [("segs", c_p), ("chunks", c_p), ("nchunks", i32), ("chunk", i32), ("lr", f32 * 4), ("wd", f32 * 4),
                 ("momentum", f32), ("dampening", f32), ("first_step", i32)]
@@ -102,6 +108,9 @@ SIGNATURES = {
     "simt_adam_step": (_I, [c_p, c_p, c_p, c_p, _L, f32, f32, f32, f32, _I, c_p]),
     "simt_sgd_multi": (_I, [C.POINTER(SgdDesc), c_p]),
     "simt_vec_acc": (_I, [c_p, c_p, _I, _I, c_p]),
+    "simt_tap_gather_sum": (_I, [C.POINTER(TapDesc), c_p]),
+    "simt_tap_scatter": (_I, [C.POINTER(TapDesc), c_p]),
+    "simt_wgrad_reduce_exp": (_I, [c_p, c_p, _I, _I, _I, _I, _I, _I, _I, _I, c_p]),
     "simt_loss_ws_bytes": (_I, []),
     "simt_ce2d_fwd": (_I, [c_p, c_p, c_p, _I, _I, _I, _I, _I, _I, c_p, c_p, c_p]),
     "simt_ce2d_bwd": (_I, [c_p, c_p, c_p, _I, _I, _I, _I, _I, _I, c_p, c_p, c_p, c_p]),

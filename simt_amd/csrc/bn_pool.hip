@@ -494,6 +494,7 @@ extern "C" int simt_maxpool_bwd(const void* dp, const unsigned char* idx, void* 
 // Weight packing: OIHW fp32 master -> K-contiguous GEMM operand in the compute dtype.
 //   mode 0 (fprop): dst[(row_off+co)*ldk + (tap_off+t)*Cin + ci] = w[co][ci][t] * (cscale ? cscale[co] : 1)
 //   mode 1 (dgrad): dst[ci*ldk + (tap_off+t)*Ck + row_off + co]  = w[co][ci][t]
+//   mode 2 (tap-expanded fprop, one output column per (tap, cout)): dst[((tap_off+t)*Ck + row_off + co)*ldk + ci] = w[co][ci][t]
 // Padding entries are never written (the buffer is zeroed once at allocation).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -507,7 +508,8 @@ __global__ void pack_weight_kernel(const float* w, T* dst, int Cout, int Cin, in
     float v = w[i];
     if (cscale) v *= cscale[co];
     long o = mode == 0 ? (long)(row_off + co) * ldk + (long)(tap_off + t) * Cin + ci
-                       : (long)ci * ldk + (long)(tap_off + t) * Ck + row_off + co;
+           : mode == 1 ? (long)ci * ldk + (long)(tap_off + t) * Ck + row_off + co
+                       : ((long)(tap_off + t) * Ck + row_off + co) * ldk + ci;
     Elem<T>::st(dst + o, v);
   }
 }

@@ -270,7 +270,8 @@ extern "C" int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream) {
   SIMT_CHECK(d->ntaps >= 1 && d->ntaps <= SIMT_MAX_TAPS);
   const int esz = d->dtype_in == SIMT_BF16 ? 2 : 4;
   SIMT_CHECK((d->Cin * esz) % 128 == 0);          // K-stage = 128 B of one tap
-  const bool v2 = d->dtype_in == SIMT_BF16 && d->dtype_out == SIMT_BF16 && d->tile_n >= 64;
+  const bool v2 = d->dtype_in == SIMT_BF16 && d->tile_n >= 64 &&
+                  (d->dtype_out == SIMT_BF16 || (!d->bias && !d->res && !d->relu && !d->stats && d->tile_n == 256));
   SIMT_CHECK(d->tile_n == 128 || d->tile_n == 64 || d->tile_n == 32 || (v2 && d->tile_n == 256));
   SIMT_CHECK(d->Npad % d->tile_n == 0 && d->Npad >= d->Cout);
   SIMT_CHECK(d->Nstore % 8 == 0 && d->Nstore <= d->Npad && d->Nstore <= d->ldy);

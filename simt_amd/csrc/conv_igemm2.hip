@@ -34,6 +34,7 @@ struct Conv2KArgs {
   int H, W, Ho, Wo, Cout, Nstore, ldy, ldr, stride, ntaps, relu, M;
   int kc_per_tap, pix_bytes, wrow_bytes;
   int ntiles_n, ntiles_m;
+  int out_f32;     // 1: y is fp32 and is stored straight from the accumulators (no bias/residual/ReLU/stats)
   int rows;        // pixels per tile (<= BM)
   int nblk128;     // stats slots allocated by the caller: ceil(M/128) >= ntiles_m
   int toff[SIMT_MAX_TAPS];   // (dy*W + dx) * pix_bytes: 32-bit so that the uniform per-stage lookup is an s_load_dword
@@ -214,6 +215,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm2_kernel(Conv2KArgs a) {
 
   // ---------------- epilogue ----------------
   // acc[j][i][e]: cout = n0 + wn*TN*16 + j*16 + (lane>>4)*4 + e ; pixel row = wm*TM*16 + i*16 + (lane&15)
+  if (a.out_f32) {
+    // fp32 result (tap-expanded ASPP GEMM): every accumulator quad is 16 contiguous bytes of one pixel's row; four lanes
+    // cover a 64-B segment -> stored directly, no LDS round trip
+    float* yf = (float*)a.y;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * TM * 16 + i * 16 + (lane & 15);
+        const int c = n0 + wn * TN * 16 + j * 16 + (lane >> 4) * 4;
+        if (m < m_end && c < a.Nstore) *(f32x4*)(yf + (long)m * a.ldy + c) = acc[j][i];
+      }
+    return;
+  }
   __syncthreads();
   char* sC = smem;                                   // [BM][CP] bytes, bf16
 #pragma unroll
@@ -358,6 +373,8 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
   Conv2KArgs k;
   k.x = (const char*)d->x; k.w = (const char*)d->w; k.y = (bf16_t*)d->y; k.bias = d->bias; k.res = (const bf16_t*)d->res;
   k.stats = d->stats; k.zero = (const char*)simt_zero_page();
+  k.out_f32 = d->dtype_out == SIMT_F32;
+  if (k.out_f32) SIMT_CHECK(!d->bias && !d->res && !d->relu && !d->stats && d->Nstore % 4 == 0 && d->ldy % 4 == 0);
   k.H = d->H; k.W = d->W; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout; k.Nstore = d->Nstore; k.ldy = d->ldy; k.ldr = d->ldr;
   k.stride = d->stride; k.ntaps = d->ntaps; k.relu = d->relu; k.M = d->B * d->Ho * d->Wo;
   k.kc_per_tap = d->Cin * 2 / 128;

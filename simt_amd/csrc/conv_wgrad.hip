@@ -244,3 +244,28 @@ extern "C" int simt_wgrad_reduce(const float* slab, float* dst, int nsplit, int 
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
+
+// Tap-expanded head: slab[split][(tap_off+t)*QP + row_off + co][ci]  ->  dst (OIHW fp32) [co][ci][t]
+__global__ void wgrad_reduce_exp_kernel(const float* slab, float* dst, int nsplit, int Cd, int Cin, int QP, int row_off,
+                                        int tap_off, int Cout, int RS, long total) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int ci = idx % Cin;
+  long r = idx / Cin;
+  int t = r % RS;
+  int co = r / RS;
+  long src = ((long)(tap_off + t) * QP + row_off + co) * Cin + ci;
+  long sstride = (long)Cd * Cin;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += slab[k * sstride + src];
+  dst[((long)co * Cin + ci) * RS + t] = s;
+}
+extern "C" int simt_wgrad_reduce_exp(const float* slab, float* dst, int nsplit, int Cd, int Cin, int QP, int row_off,
+                                     int tap_off, int Cout, int RS, simt_stream_t stream) {
+  SIMT_CHECK(slab && dst && nsplit >= 1);
+  long total = (long)Cout * RS * Cin;
+  hipLaunchKernelGGL(wgrad_reduce_exp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slab,
+                     dst, nsplit, Cd, Cin, QP, row_off, tap_off, Cout, RS, total);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}

@@ -220,7 +220,7 @@ class TrunkPlan:
 
     # ------------------------------------------------------------------ forward construction
     def _conv(self, lst, x, wp_info, y, *, Bn, Hi, Wi, Cin, Ho, Wo, Cout, taps, stride=1, bias=None, res=None, stats=None,
-              relu=False, ldy=None, Nstore=None, alg_k=None):
+              relu=False, ldy=None, Nstore=None, alg_k=None, alg_flops=None):
         """alg_k: algorithmic reduction length per output element (defaults to ntaps*Cin; the K-padded head dgrad and
         the stem pass their true value) -> algorithmic FLOPs = 2 * M * Cout * alg_k."""
         wp, tile, npad = wp_info
@@ -232,7 +232,8 @@ class TrunkPlan:
         tn = {torch.bfloat16: "bf16", torch.float32: "f32"}
         tag = f"conv_igemm<{tn[x.dtype]},{tn[y.dtype]},{tile}>"
         nbytes = (Bn * Hi * Wi * Cin + npad * len(taps) * Cin) * x.element_size() + M * Cout * y.element_size()
-        lst.add_desc("simt_conv_fprop", d, tag=tag, flops=2.0 * M * Cout * k, nbytes=float(nbytes),
+        lst.add_desc("simt_conv_fprop", d, tag=tag, flops=alg_flops if alg_flops is not None else 2.0 * M * Cout * k,
+                     nbytes=float(nbytes),
                      shape=f"M{M} N{Cout} K{len(taps) * Cin} taps{len(taps)} s{stride}")
 
     def _bn_train(self, lst, bname, y, M, Cn):
@@ -392,7 +393,8 @@ class TrunkPlan:
         npad = ops.round_up(Q, tile)
         ldp = ops.round_up(Q, 8) if Q > 32 else 32
         ldp = max(ldp, ops.round_up(Q, 4))
-        wp = self.new(npad, len(taps) * cin, zero=True)
+        expanded = self.dtype == torch.bfloat16
+        wp = None if expanded else self.new(npad, len(taps) * cin, zero=True)
         bias = self.new(npad, dtype=torch.float32, zero=True)
         self.packed["head." + hd.name] = (wp, tile, npad)
         row = 0
@@ -400,8 +402,9 @@ class TrunkPlan:
         for prefix, cout in hd.groups:
             for i in range(nd):
                 wt = self.p[f"{prefix}.conv2d_list.{i}.weight"]
-                self.pack_list.add("simt_pack_weight", wt.data_ptr(), wp.data_ptr(), cout, cin, 9, row, 9 * i,
-                                   len(taps) * cin, 0, 0, None, ops.dt_code(self.dtype))
+                if not expanded:
+                    self.pack_list.add("simt_pack_weight", wt.data_ptr(), wp.data_ptr(), cout, cin, 9, row, 9 * i,
+                                       len(taps) * cin, 0, 0, None, ops.dt_code(self.dtype))
                 bias_parts.append((row, cout, self.p[f"{prefix}.conv2d_list.{i}.bias"]))
             row += cout
         hd.bias, hd.bias_parts = bias, bias_parts
@@ -413,8 +416,33 @@ class TrunkPlan:
         self.out[hd.name] = logits.view(B, h, w, ldp)
         self.ldp[hd.name] = ldp
         hd.feat, hd.h, hd.w, hd.cin, hd.taps = feat, h, w, cin, taps
-        self._conv(f, feat, (wp, tile, npad), logits, Bn=B, Hi=h, Wi=w, Cin=cin, Ho=h, Wo=w, Cout=Q, taps=taps, bias=bias,
-                   ldy=ldp, Nstore=min(ldp, npad))
+        hd.expanded = expanded
+        if not hd.expanded:
+            self._conv(f, feat, (wp, tile, npad), logits, Bn=B, Hi=h, Wi=w, Cin=cin, Ho=h, Wo=w, Cout=Q, taps=taps, bias=bias,
+                       ldy=ldp, Nstore=min(ldp, npad))
+            return
+        # ---- bf16 throughput path: tap-expanded GEMM (csrc/head_expand.hip): P = feat x Wexp^T, then a tap gather-sum
+        Mh, nt = B * h * w, len(taps)
+        QP = ops.round_up(Q, 8)
+        nexp = nt * QP
+        npe = ops.round_up(nexp, 256)
+        wexp = self.new(npe, cin, zero=True)
+        row = 0
+        for prefix, cout in hd.groups:
+            for i in range(nd):
+                wt = self.p[f"{prefix}.conv2d_list.{i}.weight"]
+                self.pack_list.add("simt_pack_weight", wt.data_ptr(), wexp.data_ptr(), cout, cin, 9, row, 9 * i, cin, QP, 2, None,
+                                   ops.dt_code(self.dtype))
+            row += cout
+        P = self.new(Mh, nexp, dtype=torch.float32)
+        hd.QP, hd.nexp = QP, nexp
+        self._conv(f, feat, (wexp, 256, npe), P, Bn=B, Hi=h, Wi=w, Cin=cin, Ho=h, Wo=w, Cout=nexp, taps=[(0, 0)], ldy=nexp,
+                   Nstore=nexp, alg_flops=2.0 * Mh * Q * nt * cin)
+        td = L.TapDesc()
+        td.src, td.bias, td.dst = P.data_ptr(), bias.data_ptr(), logits.data_ptr()
+        td.B, td.H, td.W, td.Q, td.QP, td.lds, td.ldd, td.ntaps = B, h, w, Q, QP, nexp, ldp, nt
+        ops._fill_taps(td.dy, td.dx, taps)
+        f.add_desc("simt_tap_gather_sum", td)
 
     # ------------------------------------------------------------------ gradients
     def grad_param_names(self):
@@ -518,6 +546,8 @@ class TrunkPlan:
             cd = ops.round_up(hd.Q, 8)
             kt = len(hd.taps) * hd.cin
             self._slab_cap = max(self._slab_cap, ops.wgrad_nsplit(Mh, cd, kt, dt) * cd * kt)
+            if getattr(hd, "expanded", False):
+                self._slab_cap = max(self._slab_cap, ops.wgrad_nsplit(Mh, hd.nexp, hd.cin, dt) * hd.nexp * hd.cin)
 
         # upstream gradients of the head logits, in the conv dtype, K-padded for the dgrad GEMM
         self.dlogits = {}
@@ -618,15 +648,6 @@ class TrunkPlan:
         dl = self.dlogits[hd.name]
         Mh = B * hd.h * hd.w
         nd = len(hd.dilations)
-        cd = ops.round_up(hd.Q, 8)
-        parts = []
-        row = 0
-        for prefix, cout in hd.groups:
-            for i in range(nd):
-                parts.append((f"{prefix}.conv2d_list.{i}.weight", row, 9 * i, cout, 9, hd.cin))
-            row += cout
-        self._wgrad(b, dl, hd.feat, None, Bn=B, Hi=hd.h, Wi=hd.w, Cin=hd.cin, Ho=hd.h, Wo=hd.w, Cd=cd, ldd=hd.ck,
-                    taps=hd.taps, stride=1, parts=parts)
         # bias gradients: column sums of dlogits, written straight into every live branch's bias gradient
         row = 0
         for prefix, cout in hd.groups:
@@ -636,20 +657,66 @@ class TrunkPlan:
                       ops.dt_code(self.dtype))
                 self.grad_ready[gname] = len(b)
             row += cout
-        # dgrad: operand [Cin][ntaps*ck] assembled from every branch / group
+        dfeat = self.buf("g.dfeat%d" % hd.feat_layer, Mo, c4)
         tile = ops.pick_tile_n(hd.cin, self.dtype)
         npad = ops.round_up(hd.cin, tile)
-        wt = self.new(npad, len(hd.taps) * hd.ck, zero=True)
+        if not hd.expanded:
+            cd = ops.round_up(hd.Q, 8)
+            parts = []
+            row = 0
+            for prefix, cout in hd.groups:
+                for i in range(nd):
+                    parts.append((f"{prefix}.conv2d_list.{i}.weight", row, 9 * i, cout, 9, hd.cin))
+                row += cout
+            self._wgrad(b, dl, hd.feat, None, Bn=B, Hi=hd.h, Wi=hd.w, Cin=hd.cin, Ho=hd.h, Wo=hd.w, Cd=cd, ldd=hd.ck,
+                        taps=hd.taps, stride=1, parts=parts)
+            # dgrad: operand [Cin][ntaps*ck] assembled from every branch / group
+            wt = self.new(npad, len(hd.taps) * hd.ck, zero=True)
+            row = 0
+            for prefix, cout in hd.groups:
+                for i in range(nd):
+                    w = self.p[f"{prefix}.conv2d_list.{i}.weight"]
+                    self.pack_list.add("simt_pack_weight", w.data_ptr(), wt.data_ptr(), cout, hd.cin, 9, row, 9 * i,
+                                       len(hd.taps) * hd.ck, hd.ck, 1, None, ops.dt_code(self.dtype))
+                row += cout
+            self._conv(b, dl, (wt, tile, npad), dfeat, Bn=B, Hi=hd.h, Wi=hd.w, Cin=hd.ck, Ho=hd.h, Wo=hd.w, Cout=hd.cin,
+                       taps=[(-a, -c) for (a, c) in hd.taps], res=dz_prev, alg_k=len(hd.taps) * hd.Q)
+            return dfeat
+        # ---- tap-expanded backward: G[m'][t*QP+n] = dlogits[m' - d_t][n]; dW = G^T x feat; dfeat = G x Wt (+ dz_prev)
+        nt, QP, nexp = len(hd.taps), hd.QP, hd.nexp
+        kexp = ops.round_up(nexp, self.kq)
+        G = self.new(Mh, kexp, zero=True)
+        td = L.TapDesc()
+        td.src, td.bias, td.dst = dl.data_ptr(), None, G.data_ptr()
+        td.B, td.H, td.W, td.Q, td.QP, td.lds, td.ldd, td.ntaps = B, hd.h, hd.w, hd.Q, QP, hd.ck, kexp, nt
+        ops._fill_taps(td.dy, td.dx, hd.taps)
+        b.add_desc("simt_tap_scatter", td)
+        nsplit = ops.wgrad_nsplit(Mh, nexp, hd.cin, self.dtype)
+        assert nsplit * nexp * hd.cin <= self._slab_cap
+        slab = self.buf("wgrad.slab", self._slab_cap, dtype=torch.float32)
+        wd = ops.make_wgrad_desc(G, hd.feat, slab, B=B, H=hd.h, W=hd.w, Cin=hd.cin, Ho=hd.h, Wo=hd.w, Cd=nexp, taps=[(0, 0)],
+                                 stride=1, nsplit=nsplit, ldd=kexp)
+        b.add_desc("simt_conv_wgrad", wd, tag="conv_wgrad<bf16>", flops=2.0 * Mh * hd.Q * nt * hd.cin,
+                   nbytes=float((Mh * kexp + Mh * hd.cin) * 2 + nsplit * nexp * hd.cin * 4),
+                   shape=f"M{Mh} Cd{nexp} K{hd.cin} taps1 split{nsplit} (tap-expanded head)")
+        row = 0
+        for prefix, cout in hd.groups:
+            for i in range(nd):
+                gname = f"{prefix}.conv2d_list.{i}.weight"
+                b.add("simt_wgrad_reduce_exp", slab.data_ptr(), self.grads[gname].data_ptr(), nsplit, nexp, hd.cin, QP, row,
+                      9 * i, cout, 9)
+                self.grad_ready[gname] = len(b)
+            row += cout
+        wt = self.new(npad, kexp, zero=True)
         row = 0
         for prefix, cout in hd.groups:
             for i in range(nd):
                 w = self.p[f"{prefix}.conv2d_list.{i}.weight"]
-                self.pack_list.add("simt_pack_weight", w.data_ptr(), wt.data_ptr(), cout, hd.cin, 9, row, 9 * i,
-                                   len(hd.taps) * hd.ck, hd.ck, 1, None, ops.dt_code(self.dtype))
+                self.pack_list.add("simt_pack_weight", w.data_ptr(), wt.data_ptr(), cout, hd.cin, 9, row, 9 * i, kexp, QP, 1,
+                                   None, ops.dt_code(self.dtype))
             row += cout
-        dfeat = self.buf("g.dfeat%d" % hd.feat_layer, Mo, c4)
-        self._conv(b, dl, (wt, tile, npad), dfeat, Bn=B, Hi=hd.h, Wi=hd.w, Cin=hd.ck, Ho=hd.h, Wo=hd.w, Cout=hd.cin,
-                   taps=[(-a, -c) for (a, c) in hd.taps], res=dz_prev, alg_k=len(hd.taps) * hd.Q)
+        self._conv(b, G, (wt, tile, npad), dfeat, Bn=B, Hi=hd.h, Wi=hd.w, Cin=kexp, Ho=hd.h, Wo=hd.w, Cout=hd.cin,
+                   taps=[(0, 0)], res=dz_prev, alg_k=nt * hd.Q)
         return dfeat
 
     # ------------------------------------------------------------------ run

@@ -152,3 +152,78 @@ def test_conv_epilogue_bias_res_relu_and_aspp_taps(dev, dtype):
     ops.conv_fprop_desc(d)
     torch.cuda.synchronize()
     assert _rel(z_d.float().cpu().permute(0, 3, 1, 2), ref) < _tol(dtype)
+
+
+def test_tap_expanded_head_kernels(dev):
+    """bf16 throughput form of the ASPP classifier (csrc/head_expand.hip): P = x @ Wexp^T (fp32 out of the bf16 GEMM),
+    tap gather-sum, tap scatter, expanded weight-gradient reduce -- against the dilated convs of torch CPU fp32 evaluated
+    on the bf16-rounded inputs.  1e-2 of max|ref| (bf16 operands, fp32 accumulation)."""
+    import ctypes as C
+    from simt_amd import _lib as L
+    B, H, W, Cin, Q = 2, 15, 17, 128, 22
+    QP, dils = 24, (6, 12)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    ws = [(torch.randn(19, Cin, 3, 3, generator=g) * 0.05), (torch.randn(19, Cin, 3, 3, generator=g) * 0.05),
+          (torch.randn(3, Cin, 3, 3, generator=g) * 0.05), (torch.randn(3, Cin, 3, 3, generator=g) * 0.05)]
+    wq = [w.bfloat16().float() for w in ws]
+    bias = torch.randn(Q, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = [w.clone().requires_grad_(True) for w in wq]
+    y0 = ops_ref.conv2d(xr, wr[0], None, pad=6, dil=6) + ops_ref.conv2d(xr, wr[1], None, pad=12, dil=12)
+    y1 = ops_ref.conv2d(xr, wr[2], None, pad=6, dil=6) + ops_ref.conv2d(xr, wr[3], None, pad=12, dil=12)
+    y_ref = torch.cat([y0, y1], 1) + bias.view(1, -1, 1, 1)
+    dy = torch.randn(y_ref.shape, generator=g).bfloat16().float()
+    y_ref.backward(dy)
+    taps = ops.conv_taps(3, 3, 6, 6) + ops.conv_taps(3, 3, 12, 12)
+    nt, M = len(taps), B * H * W
+    nexp, npe = nt * QP, 512
+    x_d = x.permute(0, 2, 3, 1).contiguous().to(dev, torch.bfloat16)
+    wexp = torch.zeros(npe, Cin, device=dev, dtype=torch.bfloat16)
+    for (w, row, i) in ((ws[0], 0, 0), (ws[1], 0, 1), (ws[2], 19, 0), (ws[3], 19, 1)):
+        ops.pack_weight(w.to(dev).contiguous(), wexp, Cout=w.shape[0], Cin=Cin, RS=9, row_off=row, tap_off=9 * i, ldk=Cin, Ck=QP,
+                        mode=2)
+    P = torch.full((M, nexp), float("nan"), device=dev)
+    d = ops.make_conv_desc(x_d, wexp, P, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=nexp, taps=[(0, 0)], Npad=npe, tile_n=256,
+                           ldy=nexp, Nstore=nexp)
+    ops.conv_fprop_desc(d)
+    logits = torch.zeros(M, 32, device=dev)
+    td = L.TapDesc()
+    bias_d = bias.to(dev)
+    td.src, td.bias, td.dst = P.data_ptr(), bias_d.data_ptr(), logits.data_ptr()
+    td.B, td.H, td.W, td.Q, td.QP, td.lds, td.ldd, td.ntaps = B, H, W, Q, QP, nexp, 32, nt
+    ops._fill_taps(td.dy, td.dx, taps)
+    L.call("simt_tap_gather_sum", C.byref(td), ops.stream_ptr())
+    torch.cuda.synchronize()
+    got = logits[:, :Q].cpu().reshape(B, H, W, Q).permute(0, 3, 1, 2)
+    assert _rel(got, y_ref.detach()) < 1e-2
+    assert torch.all(logits[:, Q:] == 0)
+    # ---- backward: scatter, expanded wgrad + reduce, dgrad as a plain GEMM
+    dl = torch.zeros(M, 64, device=dev, dtype=torch.bfloat16)
+    dl[:, :Q] = dy.permute(0, 2, 3, 1).reshape(M, Q).to(dev, torch.bfloat16)
+    kexp = 448
+    G = torch.zeros(M, kexp, device=dev, dtype=torch.bfloat16)
+    ts = L.TapDesc()
+    ts.src, ts.bias, ts.dst = dl.data_ptr(), None, G.data_ptr()
+    ts.B, ts.H, ts.W, ts.Q, ts.QP, ts.lds, ts.ldd, ts.ntaps = B, H, W, Q, QP, 64, kexp, nt
+    ops._fill_taps(ts.dy, ts.dx, taps)
+    L.call("simt_tap_scatter", C.byref(ts), ops.stream_ptr())
+    for nsplit in (1, 2):
+        slab = torch.full((nsplit, nexp, Cin), float("nan"), device=dev)
+        wd = ops.make_wgrad_desc(G, x_d, slab, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cd=nexp, taps=[(0, 0)], nsplit=nsplit, ldd=kexp)
+        ops.conv_wgrad_desc(wd)
+        for (wi, row, i) in ((0, 0, 0), (1, 0, 1), (2, 19, 0), (3, 19, 1)):
+            dw = torch.full(tuple(ws[wi].shape), float("nan"), device=dev)
+            L.call("simt_wgrad_reduce_exp", slab.data_ptr(), dw.data_ptr(), nsplit, nexp, Cin, QP, row, 9 * i, ws[wi].shape[0], 9,
+                   ops.stream_ptr())
+            torch.cuda.synchronize()
+            assert _rel(dw.cpu(), wr[wi].grad) < 1e-2, (wi, nsplit)
+    wt = torch.zeros(128, kexp, device=dev, dtype=torch.bfloat16)
+    for (w, row, i) in ((ws[0], 0, 0), (ws[1], 0, 1), (ws[2], 19, 0), (ws[3], 19, 1)):
+        ops.pack_weight(w.to(dev).contiguous(), wt, Cout=w.shape[0], Cin=Cin, RS=9, row_off=row, tap_off=9 * i, ldk=kexp, Ck=QP,
+                        mode=1)
+    dx_d = torch.empty(B, H, W, Cin, device=dev, dtype=torch.bfloat16)
+    dd = ops.make_conv_desc(G, wt, dx_d, B=B, H=H, W=W, Cin=kexp, Ho=H, Wo=W, Cout=Cin, taps=[(0, 0)])
+    ops.conv_fprop_desc(dd)
+    torch.cuda.synchronize()
+    assert _rel(dx_d.float().cpu().permute(0, 3, 1, 2), xr.grad) < 1e-2
