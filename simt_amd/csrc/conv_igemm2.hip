@@ -57,9 +57,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 
 // MODE 0 = product.  MODE 1 (loads only) and MODE 2 (MFMA only) are timing-ablation builds selected by the environment
 // variable SIMT_CONV2_MODE; their outputs are meaningless.
-template <int BN, int TMP, int MODE>
-__global__ __launch_bounds__(512, 2) void conv_igemm2_kernel(Conv2KArgs a) {
-  constexpr int NT = 512, NST = 3;
+template <int BN, int TMP, int NSTP, int MODE>
+__global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(Conv2KArgs a) {
+  constexpr int NT = 512, NST = NSTP;   // NST = 3: one workgroup per CU, two stages in flight; NST = 2 (short-K, output-
+                                        // bound shapes): two workgroups per CU so one's epilogue overlaps the other's loads
   constexpr int WM = (BN == 64) ? 4 : 2;          // waves along pixels
   constexpr int WN = 8 / WM;                       // waves along couts
   constexpr int TM = TMP, TN = BN / WN / 16;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm2_kernel(Conv2KArgs a) {
   };
   // outstanding vector-memory ops of ONE stage for this wave (the counted wait leaves exactly one stage in flight)
   auto wait_stage = [&](bool more) {
-    if (!more) { wait_vmcnt<0>(); return; }
+    if (NST == 2 || !more) { wait_vmcnt<0>(); return; }
     if constexpr (A_TAIL) {
       if (!a_tail_wave) { wait_vmcnt<A_IT - 1 + B_IT>(); return; }
     }
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm2_kernel(Conv2KArgs a) {
 
   if (MODE != 2) {
     issue(0);
-    if (nk > 1) issue(1);
+    if (NST == 3 && nk > 1) issue(1);
   }
   int buf = 0;
   if (wave < 4) {
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm2_kernel(Conv2KArgs a) {
       if (MODE != 2) wait_stage(kt + 1 < nk);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (MODE != 2 && kt + 2 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);     // (kt+2)%3 == (buf+2)%3
+      if (MODE != 2 && kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);     // stage kt+NST-1 -> buffer (buf-1) mod NST
       if (MODE != 1) {
         load_frags(buf);
         mma();
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm2_kernel(Conv2KArgs a) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (MODE != 1 && kt > 0) mma();
-      if (MODE != 2 && kt + 2 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
+      if (MODE != 2 && kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
       if (MODE != 1) load_frags(buf);
       buf = (buf + 1 == NST) ? 0 : buf + 1;
     }
@@ -324,34 +325,34 @@ __global__ __launch_bounds__(512, 2) void conv_igemm2_kernel(Conv2KArgs a) {
   }
 }
 
-template <int BN, int TM, int MODE>
+template <int BN, int TM, int NST, int MODE>
 static int launch_conv2m(const Conv2KArgs& k, hipStream_t st) {
   constexpr int WM = (BN == 64) ? 4 : 2;
   constexpr int BM = WM * TM * 16;
-  const size_t ring = 3 * (size_t)(BM * 128 + BN * 128);
+  const size_t ring = NST * (size_t)(BM * 128 + BN * 128);
   const size_t epi = (size_t)BM * (BN * 2 + 8) + (size_t)(512 / (BN / 8)) * 2 * BN * 4;
   const size_t lds = ring > epi ? ring : epi;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm2_kernel<BN, TM, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_igemm2_kernel<BN, TM, NST, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm2_kernel<BN, TM, MODE>), dim3(k.ntiles_m * k.ntiles_n), dim3(512), lds, st, k);
+  hipLaunchKernelGGL((conv_igemm2_kernel<BN, TM, NST, MODE>), dim3(k.ntiles_m * k.ntiles_n), dim3(512), lds, st, k);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
 
 #include <stdlib.h>
-template <int BN, int TM>
+template <int BN, int TM, int NST = 3>
 static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("SIMT_CONV2_MODE");
     mode = e ? atoi(e) : 0;
   }
-  if (mode == 1) return launch_conv2m<BN, TM, 1>(k, st);
-  if (mode == 2) return launch_conv2m<BN, TM, 2>(k, st);
-  return launch_conv2m<BN, TM, 0>(k, st);
+  if (mode == 1) return launch_conv2m<BN, TM, NST, 1>(k, st);
+  if (mode == 2) return launch_conv2m<BN, TM, NST, 2>(k, st);
+  return launch_conv2m<BN, TM, NST, 0>(k, st);
 }
 
 // Pixel rows per tile: 128 (TM = 4) or, for the 2x4 wave layouts, up to 160 (TM = 5) when that saves a whole round of
@@ -380,9 +381,14 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
   k.kc_per_tap = d->Cin * 2 / 128;
   k.pix_bytes = d->Cin * 2;
   k.wrow_bytes = d->ntaps * d->Cin * 2;
-  k.ntiles_n = d->Npad / d->tile_n;
+  // Short reductions with wide outputs (1x1 convs 256 -> 1024 and their dgrads) are bound by the output stream, not by
+  // MFMA: run them as 128-column tiles with a 2-stage ring, two workgroups per CU.
+  int tile_n = d->tile_n;
+  const bool short_k = tile_n == 256 && !k.out_f32 && (long)d->ntaps * d->Cin <= 512 && d->Cout >= 512;
+  if (short_k) tile_n = 128;
+  k.ntiles_n = d->Npad / tile_n;
   int tm = 4;
-  pick_rows(k.M, k.ntiles_n, d->tile_n != 64, &k.rows, &tm);
+  pick_rows(k.M, short_k ? (k.ntiles_n + 1) / 2 : k.ntiles_n, tile_n != 64, &k.rows, &tm);
   k.ntiles_m = (k.M + k.rows - 1) / k.rows;
   k.nblk128 = (k.M + 127) / 128;
   SIMT_CHECK((long)d->B * d->H * d->W * d->Cin * 2 < (1l << 32));      // 32-bit byte offsets
@@ -393,7 +399,8 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
     k.toff[i] = (d->dy[i] * d->W + d->dx[i]) * k.pix_bytes;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (d->tile_n == 256) return tm == 5 ? launch_conv2<256, 5>(k, st) : launch_conv2<256, 4>(k, st);
-  if (d->tile_n == 128) return tm == 5 ? launch_conv2<128, 5>(k, st) : launch_conv2<128, 4>(k, st);
+  if (short_k) return tm == 5 ? launch_conv2<128, 5, 2>(k, st) : launch_conv2<128, 4, 2>(k, st);
+  if (tile_n == 256) return tm == 5 ? launch_conv2<256, 5>(k, st) : launch_conv2<256, 4>(k, st);
+  if (tile_n == 128) return tm == 5 ? launch_conv2<128, 5>(k, st) : launch_conv2<128, 4>(k, st);
   return launch_conv2<64, 2>(k, st);
 }
