@@ -150,7 +150,7 @@ def main():
                 "avg_launch_us": round(ms_k / n * 1e3, 2), "alg_gflop_per_launch": round(fl / n / 1e9, 3),
                 "share_of_step_kernel_time": round(ms_k / tot_ms, 3),
                 "classes": {k: {"ms": round(v[0], 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[1] else None,
-                                "n": v[3]} for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])[:12]}}
+                                "n": v[3]} for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])[:16]}}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(K, a.cpu_size)

@@ -84,6 +84,7 @@ SIGNATURES = {
     "simt_conv_wgrad": (_I, [C.POINTER(WgradDesc), c_p]),
     "simt_wgrad_reduce": (_I, [c_p, c_p, _I, _I, _I, _I, _I, _I, _I, _I, _I, c_p]),
     "simt_pack_weight": (_I, [c_p, c_p, _I, _I, _I, _I, _I, _L, _I, _I, c_p, _I, c_p]),
+    "simt_pack_weight_multi": (_I, [c_p, c_p, _I, _I, c_p]),
     "simt_bn_fold": (_I, [c_p, c_p, c_p, c_p, f32, c_p, c_p, _I, c_p]),
     "simt_bn_finalize": (_I, [c_p, _I, _I, _L, c_p, c_p, c_p, c_p, f32, f32, c_p, c_p, c_p, c_p, c_p]),
     "simt_bn_apply": (_I, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, _L, _I, _I, _I, c_p]),

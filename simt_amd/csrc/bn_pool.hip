@@ -528,6 +528,40 @@ extern "C" int simt_pack_weight(const float* w, void* dst, int Cout, int Cin, in
   return SIMT_OK;
 }
 
+// Batched form: one launch packs every weight of a plan (306 launches of ~4 us each per training step otherwise).
+struct PackJob {
+  const float* w;
+  void* dst;
+  const float* cscale;
+  long long ldk, total;
+  int Cout, Cin, RS, row_off, tap_off, Ck, mode, dtype;
+};
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackJob* jobs, const int* chunks, int chunk) {
+  const PackJob j = jobs[chunks[2 * blockIdx.x]];
+  const long long start = (long long)chunks[2 * blockIdx.x + 1] * chunk;
+  long long end = start + chunk;
+  if (end > j.total) end = j.total;
+  for (long long i = start + threadIdx.x; i < end; i += 256) {
+    int t = (int)(i % j.RS);
+    long long r = i / j.RS;
+    int ci = (int)(r % j.Cin);
+    int co = (int)(r / j.Cin);
+    float v = j.w[i];
+    if (j.cscale) v *= j.cscale[co];
+    long long o = j.mode == 0 ? (long long)(j.row_off + co) * j.ldk + (long long)(j.tap_off + t) * j.Cin + ci
+                : j.mode == 1 ? (long long)ci * j.ldk + (long long)(j.tap_off + t) * j.Ck + j.row_off + co
+                              : ((long long)(j.tap_off + t) * j.Ck + j.row_off + co) * j.ldk + ci;
+    if (j.dtype == SIMT_BF16) ((bf16_t*)j.dst)[o] = f2bf(v); else ((float*)j.dst)[o] = v;
+  }
+}
+extern "C" int simt_pack_weight_multi(const void* jobs, const void* chunks, int nchunks, int chunk, simt_stream_t stream) {
+  SIMT_CHECK(jobs && chunks && nchunks > 0 && chunk > 0);
+  hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs,
+                     (const int*)chunks, chunk);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
 // eval-mode BN folding constants: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                float* scale, float* shift, int C) {

@@ -79,15 +79,16 @@ struct HeadEval {
   float m2, sum2, lse2;  // log-sum-exp of `predict` (arg-max logit replaced by -0.0)
 };
 
+template <int QM>
 __device__ __forceinline__ void eval_head(const float* v, int Q, int C, float th_high, HeadEval& e) {
   float vmax = v[0];
   int arg = 0;
 #pragma unroll
-  for (int j = 1; j < QMAX; ++j)
+  for (int j = 1; j < QM; ++j)
     if (j < Q && v[j] > vmax) { vmax = v[j]; arg = j; }
   float sum = 0.f;
 #pragma unroll
-  for (int j = 0; j < QMAX; ++j)
+  for (int j = 0; j < QM; ++j)
     if (j < Q) sum += expf(v[j] - vmax);
   e.arg = arg; e.vmax = vmax; e.sum = sum; e.lse = vmax + logf(sum);
   float pm = 1.0f / sum;
@@ -97,14 +98,14 @@ __device__ __forceinline__ void eval_head(const float* v, int Q, int C, float th
   int y = 0;
   float m2 = 0.f;  // the replaced entry contributes the value 0
 #pragma unroll
-  for (int j = 0; j < QMAX; ++j)
+  for (int j = 0; j < QM; ++j)
     if (j < Q && j != arg) {
       m2 = fmaxf(m2, v[j]);
       if (j >= C && v[j] > best) { best = v[j]; y = j; }
     }
   float s2 = expf(0.f - m2);
 #pragma unroll
-  for (int j = 0; j < QMAX; ++j)
+  for (int j = 0; j < QM; ++j)
     if (j < Q && j != arg) s2 += expf(v[j] - m2);
   e.yopen = y; e.m2 = m2; e.sum2 = s2; e.lse2 = m2 + logf(s2);
 }
@@ -174,6 +175,7 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
   return v;
 }
 
+template <int QM>
 __global__ __launch_bounds__(256) void head_pass1_kernel(HeadArgs a) {
   const HeadGeom g = a.g;
   const int Q = g.Q, C = g.C, QC = Q * C;
@@ -213,21 +215,21 @@ __global__ __launch_bounds__(256) void head_pass1_kernel(HeadArgs a) {
     float fm = -INFINITY;
     int fa = 0;
     {
-      float buf[QMAX];
-      interp_vec<QMAX>(a.fixp, g.ldf, C, tp, buf);
+      float buf[QM];
+      interp_vec<QM>(a.fixp, g.ldf, C, tp, buf);
 #pragma unroll
-      for (int c = 0; c < QMAX; ++c)
+      for (int c = 0; c < QM; ++c)
         if (c < C && buf[c] > fm) { fm = buf[c]; fa = c; }
     }
     int conf = (fm > a.th_high) ? fa : 255;
     if (fm < a.th_low) conf = C;
 
-    float v2[QMAX], v1[QMAX];
-    interp_vec<QMAX>(a.pred2, g.ldp, Q, tp, v2);
-    interp_vec<QMAX>(a.pred1, g.ldp, Q, tp, v1);
+    float v2[QM], v1[QM];
+    interp_vec<QM>(a.pred2, g.ldp, Q, tp, v2);
+    interp_vec<QM>(a.pred1, g.ldp, Q, tp, v1);
     HeadEval e2, e1;
-    eval_head(v2, Q, C, a.th_high, e2);
-    eval_head(v1, Q, C, a.th_high, e1);
+    eval_head<QM>(v2, Q, C, a.th_high, e2);
+    eval_head<QM>(v1, Q, C, a.th_high, e1);
     if (conf == C) conf = (e2.arg >= C) ? e2.arg : 255;  // reference :387-393
 
     long long lab = live ? a.label[p] : 255;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void head_pass1_kernel(HeadArgs a) {
       if (conf != 255) {
         float l1 = 0.f, l2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < QMAX; ++j)
+        for (int j = 0; j < QM; ++j)
           if (j == conf) { l1 = e1.lse - v1[j]; l2 = e2.lse - v2[j]; }
         acc[0] += l1; acc[1] += l2; acc[8] += 1.f;
       }
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void head_pass1_kernel(HeadArgs a) {
         acc[2] += e1.lse - e1.vmax;
         float vy = 0.f;
 #pragma unroll
-        for (int j = 0; j < QMAX; ++j)
+        for (int j = 0; j < QM; ++j)
           if (j == e1.yopen && j != e1.arg) vy = v1[j];
         acc[4] += e1.lse2 - vy;
         acc[9] += 1.f;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256) void head_pass1_kernel(HeadArgs a) {
         acc[3] += e2.lse - e2.vmax;
         float vy = 0.f;
 #pragma unroll
-        for (int j = 0; j < QMAX; ++j)
+        for (int j = 0; j < QM; ++j)
           if (j == e2.yopen && j != e2.arg) vy = v2[j];
         acc[5] += e2.lse2 - vy;
         acc[10] += 1.f;
@@ -264,12 +266,20 @@ __global__ __launch_bounds__(256) void head_pass1_kernel(HeadArgs a) {
     // ---- noise-posterior loss: q = softmax(v); r = q.T[:,label]  (reference :402-409, utils/loss.py:29-39)
     float r1 = 0.f, r2 = 0.f;
     const float inv1 = 1.0f / e1.sum, inv2 = 1.0f / e2.sum;
+    float q1[QM], q2[QM];      // softmax probabilities, evaluated once and reused by the dT partials below
+    if (__ballot(lab_ok)) {
+#pragma unroll
+      for (int j = 0; j < QM; ++j) {
+        q1[j] = (j < Q) ? expf(v1[j] - e1.vmax) * inv1 : 0.f;
+        q2[j] = (j < Q) ? expf(v2[j] - e2.vmax) * inv2 : 0.f;
+      }
+    }
     if (lab_ok) {
 #pragma unroll
-      for (int j = 0; j < QMAX; ++j)
+      for (int j = 0; j < QM; ++j)
         if (j < Q) {
-          r1 += (expf(v1[j] - e1.vmax) * inv1) * sT[j * C + labi];
-          r2 += (expf(v2[j] - e2.vmax) * inv2) * sT[QC + j * C + labi];
+          r1 += q1[j] * sT[j * C + labi];
+          r2 += q2[j] * sT[QC + j * C + labi];
         }
       acc[6] += -logf(r1);
       acc[7] += -logf(r2);
@@ -278,16 +288,17 @@ __global__ __launch_bounds__(256) void head_pass1_kernel(HeadArgs a) {
     // dL_y/dT partials: per wave, one label value at a time (labels are spatially coherent -> few rounds)
     {
       unsigned long long todo = __ballot(lab_ok);
+      const float ir1 = lab_ok ? 1.0f / r1 : 0.f, ir2 = lab_ok ? 1.0f / r2 : 0.f;
       while (todo) {
         int src = __ffsll((long long)todo) - 1;
         int c = __shfl(labi, src, 64);
         bool mine = lab_ok && labi == c;
         todo &= ~__ballot(mine);
 #pragma unroll
-        for (int j = 0; j < QMAX; ++j)
+        for (int j = 0; j < QM; ++j)
           if (j < Q) {
-            float c1 = mine ? (expf(v1[j] - e1.vmax) * inv1) / r1 : 0.f;
-            float c2 = mine ? (expf(v2[j] - e2.vmax) * inv2) / r2 : 0.f;
+            float c1 = mine ? q1[j] * ir1 : 0.f;
+            float c2 = mine ? q2[j] * ir2 : 0.f;
             c1 = wave_sum(c1);
             c2 = wave_sum(c2);
             if (lane == 0) {
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(256) void head_pass1_kernel(HeadArgs a) {
       ex2 = wave_or_u64(ex2);
       if (lane == 0) { atomicOr(&sEx[0], ex1); atomicOr(&sEx[1], ex2); }
 #pragma unroll
-      for (int j = 0; j < QMAX; ++j)
+      for (int j = 0; j < QM; ++j)
         if (j < Q) {
           float a1 = live ? v1[j] : -INFINITY, a2 = live ? v2[j] : -INFINITY;
           float m1 = wave_max_f(a1), m2 = wave_max_f(a2);
@@ -422,6 +433,7 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(HeadArgs a, int nblk
 // --------------------------------------------------------------------------------------------------------
 // pass 2: gradient w.r.t. the upsampled logits, reduced along x inside the block.  One block per (b, y) row.
 // --------------------------------------------------------------------------------------------------------
+template <int QM>
 __global__ __launch_bounds__(256) void head_pass2_kernel(HeadArgs a) {
   const HeadGeom g = a.g;
   const int Q = g.Q, C = g.C, QC = Q * C, QP = a.QP;
@@ -451,20 +463,20 @@ __global__ __launch_bounds__(256) void head_pass2_kernel(HeadArgs a) {
       float fm = -INFINITY;
       int fa = 0;
       {
-        float buf[QMAX];
-        interp_vec<QMAX>(a.fixp, g.ldf, C, tp, buf);
+        float buf[QM];
+        interp_vec<QM>(a.fixp, g.ldf, C, tp, buf);
 #pragma unroll
-        for (int c = 0; c < QMAX; ++c)
+        for (int c = 0; c < QM; ++c)
           if (c < C && buf[c] > fm) { fm = buf[c]; fa = c; }
       }
       int conf = (fm > a.th_high) ? fa : 255;
       if (fm < a.th_low) conf = C;
-      float v2[QMAX], v1[QMAX];
-      interp_vec<QMAX>(a.pred2, g.ldp, Q, tp, v2);
-      interp_vec<QMAX>(a.pred1, g.ldp, Q, tp, v1);
+      float v2[QM], v1[QM];
+      interp_vec<QM>(a.pred2, g.ldp, Q, tp, v2);
+      interp_vec<QM>(a.pred1, g.ldp, Q, tp, v1);
       HeadEval e2, e1;
-      eval_head(v2, Q, C, a.th_high, e2);
-      eval_head(v1, Q, C, a.th_high, e1);
+      eval_head<QM>(v2, Q, C, a.th_high, e2);
+      eval_head<QM>(v1, Q, C, a.th_high, e1);
       if (conf == C) conf = (e2.arg >= C) ? e2.arg : 255;
       long long lab = live ? a.label[((long)b * g.H + y) * g.W + x] : 255;
       const bool lab_ok = live && lab >= 0 && lab != 255 && lab < C;
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(256) void head_pass2_kernel(HeadArgs a) {
       float r1 = 0.f, r2 = 0.f;
       if (lab_ok) {
 #pragma unroll
-        for (int j = 0; j < QMAX; ++j)
+        for (int j = 0; j < QM; ++j)
           if (j < Q) {
             r1 += (expf(v1[j] - e1.vmax) * inv1) * sT[j * C + labi];
             r2 += (expf(v2[j] - e2.vmax) * inv2) * sT[QC + j * C + labi];
@@ -481,7 +493,7 @@ __global__ __launch_bounds__(256) void head_pass2_kernel(HeadArgs a) {
       }
       const float is1 = 1.0f / e1.sum2, is2 = 1.0f / e2.sum2;
 #pragma unroll
-      for (int j = 0; j < QMAX; ++j)
+      for (int j = 0; j < QM; ++j)
         if (j < Q) {
           float q1 = expf(v1[j] - e1.vmax) * inv1, q2 = expf(v2[j] - e2.vmax) * inv2;
           float G1 = 0.f, G2 = 0.f;
@@ -633,7 +645,10 @@ extern "C" int simt_head_loss(const simt_head_desc* d, simt_stream_t stream) {
   const int nblk = simt_head_nblk(d->B, d->H, d->W);
   (void)hipMemsetAsync(d->keys, 0, (2 * QMAX + 2) * sizeof(unsigned long long), st);
   size_t lds1 = pass1_lds(d->Q, d->C);
-  hipLaunchKernelGGL(head_pass1_kernel, dim3(nblk), dim3(256), lds1, st, a);
+  if (d->Q <= 24)
+    hipLaunchKernelGGL(head_pass1_kernel<24>, dim3(nblk), dim3(256), lds1, st, a);
+  else
+    hipLaunchKernelGGL(head_pass1_kernel<QMAX>, dim3(nblk), dim3(256), lds1, st, a);
   SIMT_LAUNCH_CHECK();
   {
     const int ncols = NSCAL + 2 * d->Q * d->C;
@@ -657,10 +672,14 @@ extern "C" int simt_head_grad(const simt_head_desc* d, simt_stream_t stream) {
   SIMT_CHECK(lds2 <= 160 * 1024);
   static size_t lds2_set = 0;
   if (lds2 > lds2_set) {
-    (void)hipFuncSetAttribute((const void*)head_pass2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    (void)hipFuncSetAttribute((const void*)head_pass2_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    (void)hipFuncSetAttribute((const void*)head_pass2_kernel<QMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     lds2_set = lds2;
   }
-  hipLaunchKernelGGL(head_pass2_kernel, dim3(d->B * d->H), dim3(256), lds2, st, a);
+  if (d->Q <= 24)
+    hipLaunchKernelGGL(head_pass2_kernel<24>, dim3(d->B * d->H), dim3(256), lds2, st, a);
+  else
+    hipLaunchKernelGGL(head_pass2_kernel<QMAX>, dim3(d->B * d->H), dim3(256), lds2, st, a);
   SIMT_LAUNCH_CHECK();
   long total = 2l * d->B * d->h * d->w * d->QP;
   unsigned grid = (unsigned)((total + 255) / 256);

@@ -182,6 +182,9 @@ __global__ __launch_bounds__(256) void ntm_post_kernel(NtmPostArgs a) {
   __shared__ float G[NC * NC], Gi[NC * NC];
   __shared__ float red[256];
   __shared__ float s_convex[2], s_vol[2], s_anchor[2];
+  __shared__ float fcol[NC];
+  __shared__ float s_det;
+  __shared__ int s_piv;
   const int tid = threadIdx.x, Q = a.Q, C = a.C, QC = Q * C;
   if (tid < C) cd[tid] = a.class_dist[tid];
   __syncthreads();
@@ -224,36 +227,53 @@ __global__ __launch_bounds__(256) void ntm_post_kernel(NtmPostArgs a) {
       Gi[i] = (r == c) ? 1.f : 0.f;
     }
     __syncthreads();
-    // Gauss-Jordan with partial pivoting (serial; 19x19): det = prod(pivots)*sign, Gi = G^-1
-    if (tid == 0) {
-      float det = 1.f;
-      for (int p = 0; p < C; ++p) {
+    // Gauss-Jordan with partial pivoting on [G | Gi]: det = prod(pivots)*sign, Gi = G^-1.  Same arithmetic per element
+    // as the textbook serial loop; the row operations of one pivot step run across the block (a single thread walking
+    // 19 x 19 x 38 LDS-latency-bound FMAs took 0.45 ms per matrix).
+    if (tid == 0) s_det = 1.f;
+    __syncthreads();
+    for (int p = 0; p < C; ++p) {
+      if (tid == 0) {
         int piv = p;
         float best = fabsf(G[p * C + p]);
         for (int r = p + 1; r < C; ++r) {
           float v = fabsf(G[r * C + p]);
           if (v > best) { best = v; piv = r; }
         }
-        if (piv != p) {
-          for (int c = 0; c < C; ++c) {
-            float t = G[p * C + c]; G[p * C + c] = G[piv * C + c]; G[piv * C + c] = t;
-            t = Gi[p * C + c]; Gi[p * C + c] = Gi[piv * C + c]; Gi[piv * C + c] = t;
-          }
-          det = -det;
-        }
-        float d = G[p * C + p];
-        det *= d;
-        float inv = 1.f / d;
-        for (int c = 0; c < C; ++c) { G[p * C + c] *= inv; Gi[p * C + c] *= inv; }
-        for (int r = 0; r < C; ++r) {
-          if (r == p) continue;
-          float f = G[r * C + p];
-          if (f != 0.f)
-            for (int c = 0; c < C; ++c) { G[r * C + c] -= f * G[p * C + c]; Gi[r * C + c] -= f * Gi[p * C + c]; }
+        s_piv = piv;
+        if (piv != p) s_det = -s_det;
+      }
+      __syncthreads();
+      const int piv = s_piv;
+      if (piv != p && tid < 2 * C) {
+        float* Mx = tid < C ? G : Gi;
+        const int c = tid < C ? tid : tid - C;
+        float t = Mx[p * C + c]; Mx[p * C + c] = Mx[piv * C + c]; Mx[piv * C + c] = t;
+      }
+      __syncthreads();
+      const float d = G[p * C + p];
+      __syncthreads();
+      if (tid == 0) s_det *= d;
+      if (tid < 2 * C) {
+        float* Mx = tid < C ? G : Gi;
+        const int c = tid < C ? tid : tid - C;
+        Mx[p * C + c] *= 1.f / d;
+      }
+      __syncthreads();
+      if (tid < C) fcol[tid] = G[tid * C + p];
+      __syncthreads();
+      for (int idx = tid; idx < C * 2 * C; idx += 256) {
+        const int r = idx / (2 * C), cc = idx - r * 2 * C;
+        const float f = fcol[r];
+        if (r != p && f != 0.f) {
+          float* Mx = cc < C ? G : Gi;
+          const int c = cc < C ? cc : cc - C;
+          Mx[r * C + c] -= f * Mx[p * C + c];
         }
       }
-      s_vol[k] = logf(sqrtf(fabsf(det)));
+      __syncthreads();
     }
+    if (tid == 0) s_vol[k] = logf(sqrtf(fabsf(s_det)));
     __syncthreads();
     for (int i = tid; i < QC; i += 256) {
       int j = i / C, c = i - j * C;

@@ -124,6 +124,38 @@ class LaunchList:
     def __len__(self):
         return len(self.items)
 
+    def coalesce_packs(self, device):
+        """Replace every simt_pack_weight entry by ONE simt_pack_weight_multi launch (placed where the last of them
+        was: BN-fold launches whose scales the packs read stay in front).  Returns the device tables (kept alive)."""
+        import numpy as np
+        lib = L.load()
+        packs = [it for it in self.items if it.fn is lib.simt_pack_weight]
+        if len(packs) < 2:
+            return None
+        job_dt = np.dtype([("w", "<u8"), ("dst", "<u8"), ("cscale", "<u8"), ("ldk", "<i8"), ("total", "<i8"), ("Cout", "<i4"),
+                           ("Cin", "<i4"), ("RS", "<i4"), ("row_off", "<i4"), ("tap_off", "<i4"), ("Ck", "<i4"), ("mode", "<i4"),
+                           ("dtype", "<i4")])
+        assert job_dt.itemsize == 72
+        recs, chunks, chunk = [], [], 32768
+        for ji, it in enumerate(packs):
+            w, dst, cout, cin, rs, row_off, tap_off, ldk, ck, mode, cscale, dtype = it.args
+            total = cout * cin * rs
+            recs.append((w, dst, cscale or 0, ldk, total, cout, cin, rs, row_off, tap_off, ck, mode, dtype))
+            chunks += [(ji, ci) for ci in range((total + chunk - 1) // chunk)]
+        jobs = torch.from_numpy(np.array(recs, dtype=job_dt).view(np.uint8).copy()).to(device)
+        ch = torch.tensor(chunks, dtype=torch.int32).to(device)
+        last = max(i for i, it in enumerate(self.items) if it.fn is lib.simt_pack_weight)
+        new_items = []
+        for i, it in enumerate(self.items):
+            if it.fn is lib.simt_pack_weight:
+                if i == last:
+                    new_items.append(_Launch(lib.simt_pack_weight_multi, (jobs.data_ptr(), ch.data_ptr(), len(chunks), chunk),
+                                             (jobs, ch), "simt_pack_weight_multi"))
+                continue
+            new_items.append(it)
+        self.items = new_items
+        return jobs, ch
+
 
 class TrunkPlan:
     """Forward (train or eval) and backward of ResNetMulti for one fixed input shape.
@@ -162,6 +194,7 @@ class TrunkPlan:
         if train:
             self._alloc_grads(grad_names)
             self._build_backward()
+        self._pack_tables = self.pack_list.coalesce_packs(self.dev)
         self.repack()
 
     # ------------------------------------------------------------------ buffers
