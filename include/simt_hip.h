@@ -86,7 +86,7 @@ int simt_wgrad_reduce_exp(const float* slab, float* dst, int nsplit, int Cd, int
 int simt_pack_weight(const float* w, void* dst, int Cout, int Cin, int RS, int row_off, int tap_off, long ldk, int Ck,
                      int mode, const float* cscale, int dtype, simt_stream_t stream);
 /* batched form: jobs = device array of {const float* w; void* dst; const float* cscale; int64 ldk, total; int32 Cout, Cin, RS,
- * row_off, tap_off, Ck, mode, dtype} (72 bytes), chunks = device int32 [nchunks][2] (job, chunk index) */
+ * row_off, tap_off, Ck, mode, dtype} (72 bytes), chunks = device int32 [nchunks][2] (job, 32x32 (cout, cin) tile index) */
 int simt_pack_weight_multi(const void* jobs, const void* chunks, int nchunks, int chunk, simt_stream_t stream);
 int simt_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale,
                  float* shift, int C, simt_stream_t stream);

@@ -529,6 +529,7 @@ extern "C" int simt_pack_weight(const float* w, void* dst, int Cout, int Cin, in
 }
 
 // Batched form: one launch packs every weight of a plan (306 launches of ~4 us each per training step otherwise).
+// chunks[i] = (job, tile index); tiles enumerate ceil(Cout/32) x ceil(Cin/32).
 struct PackJob {
   const float* w;
   void* dst;
@@ -536,26 +537,48 @@ struct PackJob {
   long long ldk, total;
   int Cout, Cin, RS, row_off, tap_off, Ck, mode, dtype;
 };
-__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackJob* jobs, const int* chunks, int chunk) {
+// One block = one 32 (cout) x 32 (cin) tile of one job, all RS taps: the OIHW source is read as 32 contiguous runs of
+// 32*RS floats, transposed through LDS, and written with the destination's fastest index across lanes (2-byte scattered
+// stores made the first version of this kernel 10x slower than the bytes it moves).
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackJob* jobs, const int* chunks, int /*chunk*/) {
+  __shared__ float tile[9 * 32 * 33];
   const PackJob j = jobs[chunks[2 * blockIdx.x]];
-  const long long start = (long long)chunks[2 * blockIdx.x + 1] * chunk;
-  long long end = start + chunk;
-  if (end > j.total) end = j.total;
-  for (long long i = start + threadIdx.x; i < end; i += 256) {
-    int t = (int)(i % j.RS);
-    long long r = i / j.RS;
-    int ci = (int)(r % j.Cin);
-    int co = (int)(r / j.Cin);
-    float v = j.w[i];
-    if (j.cscale) v *= j.cscale[co];
-    long long o = j.mode == 0 ? (long long)(j.row_off + co) * j.ldk + (long long)(j.tap_off + t) * j.Cin + ci
-                : j.mode == 1 ? (long long)ci * j.ldk + (long long)(j.tap_off + t) * j.Ck + j.row_off + co
-                              : ((long long)(j.tap_off + t) * j.Ck + j.row_off + co) * j.ldk + ci;
-    if (j.dtype == SIMT_BF16) ((bf16_t*)j.dst)[o] = f2bf(v); else ((float*)j.dst)[o] = v;
+  const int tidx = chunks[2 * blockIdx.x + 1];
+  const int ntc = (j.Cin + 31) >> 5;
+  const int co0 = (tidx / ntc) << 5, ci0 = (tidx % ntc) << 5;
+  const int RS = j.RS;
+  const int nci = min(32, j.Cin - ci0), nco = min(32, j.Cout - co0);
+  for (int tb = 0; tb < RS; tb += 9) {          // RS <= 9 in one pass (3x3); larger kernels in slices of 9 taps
+    const int nt = min(9, RS - tb);
+    __syncthreads();
+    // ---- read: element e -> (co_l, ci_l, t) with (ci_l, t) contiguous in memory
+    const int per_co = nci * RS;
+    for (int e = threadIdx.x; e < nco * per_co; e += 256) {
+      const int co_l = e / per_co, rem = e - co_l * per_co;
+      const int ci_l = rem / RS, t = rem - ci_l * RS;
+      if (t < tb || t >= tb + nt) continue;
+      float v = j.w[((long long)(co0 + co_l) * j.Cin + ci0) * RS + rem];
+      if (j.cscale) v *= j.cscale[co0 + co_l];
+      tile[((t - tb) * 32 + co_l) * 33 + ci_l] = v;
+    }
+    __syncthreads();
+    // ---- write
+    for (int e = threadIdx.x; e < nt * 32 * 32; e += 256) {
+      const int t = e >> 10;
+      int co_l, ci_l;
+      if (j.mode == 1) { co_l = e & 31; ci_l = (e >> 5) & 31; } else { ci_l = e & 31; co_l = (e >> 5) & 31; }
+      if (co_l >= nco || ci_l >= nci) continue;
+      const float v = tile[(t * 32 + co_l) * 33 + ci_l];
+      const int co = co0 + co_l, ci = ci0 + ci_l, tt = j.tap_off + tb + t;
+      const long long o = j.mode == 0 ? (long long)(j.row_off + co) * j.ldk + (long long)tt * j.Cin + ci
+                        : j.mode == 1 ? (long long)ci * j.ldk + (long long)tt * j.Ck + j.row_off + co
+                                      : ((long long)tt * j.Ck + j.row_off + co) * j.ldk + ci;
+      if (j.dtype == SIMT_BF16) ((bf16_t*)j.dst)[o] = f2bf(v); else ((float*)j.dst)[o] = v;
+    }
   }
 }
 extern "C" int simt_pack_weight_multi(const void* jobs, const void* chunks, int nchunks, int chunk, simt_stream_t stream) {
-  SIMT_CHECK(jobs && chunks && nchunks > 0 && chunk > 0);
+  SIMT_CHECK(jobs && chunks && nchunks > 0);
   hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs,
                      (const int*)chunks, chunk);
   SIMT_LAUNCH_CHECK();

@@ -71,6 +71,30 @@ __device__ __forceinline__ void interp_vec(const float* src, int ld, int n, cons
   }
 }
 
+// max / first arg-max over channels [0, n) of the interpolated vector, without materialising it
+template <int NMAX>
+__device__ __forceinline__ void interp_argmax(const float* src, int ld, int n, const Taps& t, float& fm, int& fa) {
+  const float* p00 = src + (long)t.o00 * ld;
+  const float* p01 = src + (long)t.o01 * ld;
+  const float* p10 = src + (long)t.o10 * ld;
+  const float* p11 = src + (long)t.o11 * ld;
+  fm = -INFINITY;
+  fa = 0;
+#pragma unroll
+  for (int j4 = 0; j4 < NMAX / 4; ++j4) {
+    if (j4 * 4 < n) {
+      float4 a = *(const float4*)(p00 + j4 * 4), b = *(const float4*)(p01 + j4 * 4);
+      float4 c = *(const float4*)(p10 + j4 * 4), d = *(const float4*)(p11 + j4 * 4);
+      const float v0 = lerp4(t, a.x, b.x, c.x, d.x), v1 = lerp4(t, a.y, b.y, c.y, d.y);
+      const float v2 = lerp4(t, a.z, b.z, c.z, d.z), v3 = lerp4(t, a.w, b.w, c.w, d.w);
+      if (j4 * 4 + 0 < n && v0 > fm) { fm = v0; fa = j4 * 4 + 0; }
+      if (j4 * 4 + 1 < n && v1 > fm) { fm = v1; fa = j4 * 4 + 1; }
+      if (j4 * 4 + 2 < n && v2 > fm) { fm = v2; fa = j4 * 4 + 2; }
+      if (j4 * 4 + 3 < n && v3 > fm) { fm = v3; fa = j4 * 4 + 3; }
+    }
+  }
+}
+
 struct HeadEval {
   int arg;       // argmax_j v[j], first index
   float vmax, sum, lse;
@@ -164,6 +188,21 @@ struct HeadArgs {
   float gscale;
 };
 
+// Full-wave sum with DPP row operations (no LDS crossbar): result valid in lane 63.
+__device__ __forceinline__ float wave_sum_dpp63(float v) {
+  int x = __float_as_int(v);
+#define DPP_ADD(ctrl, rmask)                                                                                  \
+  x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, true)))
+  DPP_ADD(0xB1, 0xf);    // quad_perm [1,0,3,2]
+  DPP_ADD(0x4E, 0xf);    // quad_perm [2,3,0,1]
+  DPP_ADD(0x141, 0xf);   // row_half_mirror
+  DPP_ADD(0x140, 0xf);   // row_mirror      -> every lane holds its 16-lane row sum
+  DPP_ADD(0x142, 0xa);   // row_bcast:15    -> rows 1 and 3 += previous row
+  DPP_ADD(0x143, 0xc);   // row_bcast:31    -> rows 2 and 3 += row 1 (lane 31)
+#undef DPP_ADD
+  return __int_as_float(x);
+}
+
 __device__ __forceinline__ float wave_max_f(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -176,7 +215,7 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
 }
 
 template <int QM>
-__global__ __launch_bounds__(256) void head_pass1_kernel(HeadArgs a) {
+__global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(HeadArgs a) {
   const HeadGeom g = a.g;
   const int Q = g.Q, C = g.C, QC = Q * C;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -212,15 +251,10 @@ __global__ __launch_bounds__(256) void head_pass1_kernel(HeadArgs a) {
     }
     Taps tp = make_taps(g, b, y, x);
     // ---- fixed-model posterior -> confidence label (reference :354-361)
-    float fm = -INFINITY;
-    int fa = 0;
-    {
-      float buf[QM];
-      interp_vec<QM>(a.fixp, g.ldf, C, tp, buf);
-#pragma unroll
-      for (int c = 0; c < QM; ++c)
-        if (c < C && buf[c] > fm) { fm = buf[c]; fa = c; }
-    }
+    float fm;
+    int fa;
+    interp_argmax<QM>(a.fixp, g.ldf, C, tp, fm, fa);
+    asm volatile("" ::: "memory");   // keep the next gathers from being hoisted above (register pressure)
     int conf = (fm > a.th_high) ? fa : 255;
     if (fm < a.th_low) conf = C;
 
@@ -299,9 +333,9 @@ __global__ __launch_bounds__(256) void head_pass1_kernel(HeadArgs a) {
           if (j < Q) {
             float c1 = mine ? q1[j] * ir1 : 0.f;
             float c2 = mine ? q2[j] * ir2 : 0.f;
-            c1 = wave_sum(c1);
-            c2 = wave_sum(c2);
-            if (lane == 0) {
+            c1 = wave_sum_dpp63(c1);
+            c2 = wave_sum_dpp63(c2);
+            if (lane == 63) {
               sdT[(wave * 2 + 0) * QC + j * C + c] += c1;
               sdT[(wave * 2 + 1) * QC + j * C + c] += c2;
             }
@@ -434,7 +468,7 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(HeadArgs a, int nblk
 // pass 2: gradient w.r.t. the upsampled logits, reduced along x inside the block.  One block per (b, y) row.
 // --------------------------------------------------------------------------------------------------------
 template <int QM>
-__global__ __launch_bounds__(256) void head_pass2_kernel(HeadArgs a) {
+__global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass2_kernel(HeadArgs a) {
   const HeadGeom g = a.g;
   const int Q = g.Q, C = g.C, QC = Q * C, QP = a.QP;
   const int GP = Q + 1;  // LDS pitch of the per-pixel gradient rows
@@ -442,6 +476,8 @@ __global__ __launch_bounds__(256) void head_pass2_kernel(HeadArgs a) {
   float* sT = (float*)smem;          // [2][QC]
   float* sG = sT + 2 * QC;           // [2][256][GP]
   float* sAcc = sG + 2 * 256 * GP;   // [2][w][Q]
+  int* sI0 = (int*)(sAcc + 2 * g.w * Q);     // [256] low-res column of each pixel of the chunk
+  float* sL1 = (float*)(sI0 + 256);          // [256] its right-tap weight
   const int tid = threadIdx.x;
   const int b = blockIdx.x / g.H, y = blockIdx.x % g.H;
   for (int i = tid; i < QC; i += 256) { sT[i] = a.T1[i]; sT[QC + i] = a.T2[i]; }
@@ -460,15 +496,17 @@ __global__ __launch_bounds__(256) void head_pass2_kernel(HeadArgs a) {
     const bool live = x < g.W;
     {
       Taps tp = make_taps(g, b, y, live ? x : 0);
-      float fm = -INFINITY;
-      int fa = 0;
       {
-        float buf[QM];
-        interp_vec<QM>(a.fixp, g.ldf, C, tp, buf);
-#pragma unroll
-        for (int c = 0; c < QM; ++c)
-          if (c < C && buf[c] > fm) { fm = buf[c]; fa = c; }
+        const float fx = g.sx * (float)x;
+        int i0 = (int)fx;
+        if (i0 > g.w - 1) i0 = g.w - 1;
+        sI0[tid] = live ? i0 : -100;
+        sL1[tid] = fx - (float)i0;
       }
+      float fm;
+      int fa;
+      interp_argmax<QM>(a.fixp, g.ldf, C, tp, fm, fa);
+      asm volatile("" ::: "memory");
       int conf = (fm > a.th_high) ? fa : 255;
       if (fm < a.th_low) conf = C;
       float v2[QM], v1[QM];
@@ -521,12 +559,17 @@ __global__ __launch_bounds__(256) void head_pass2_kernel(HeadArgs a) {
         }
     }
     __syncthreads();
-    // x-reduction: out[hd][xl][j] += sum_x wgt(x, xl) * G[hd][x][j]
+    // x-reduction: out[hd][xl][j] += sum_x wgt(x, xl) * G[hd][x][j]  -- only the low-res columns this 256-pixel chunk
+    // can touch; the tap (i0, l1) of every pixel was computed once by its thread above
     const int xend = min(x0 + 256, g.W);
-    for (int idx = tid; idx < 2 * g.w * Q; idx += 256) {
-      int hd = idx / (g.w * Q);
-      int r = idx - hd * g.w * Q;
-      int xl = r / Q, j = r - xl * Q;
+    const int xl_lo = max(0, (int)(g.sx * (float)x0) - 1);
+    const int xl_hi = min(g.w - 1, (int)(g.sx * (float)(xend - 1)) + 2);
+    const int nxl = xl_hi - xl_lo + 1;
+    for (int idx = tid; idx < 2 * nxl * Q; idx += 256) {
+      int hd = idx / (nxl * Q);
+      int r = idx - hd * nxl * Q;
+      int xr = r / Q, j = r - xr * Q;
+      int xl = xl_lo + xr;
       int lo, hi;
       if (g.sx > 0.f) {
         lo = (int)floorf((float)(xl - 1) / g.sx) - 1;
@@ -538,15 +581,13 @@ __global__ __launch_bounds__(256) void head_pass2_kernel(HeadArgs a) {
       hi = min(hi, xend - 1);
       float s = 0.f;
       for (int xx = lo; xx <= hi; ++xx) {
-        float fx = g.sx * (float)xx;
-        int i0 = (int)fx;
-        if (i0 > g.w - 1) i0 = g.w - 1;
-        int i1 = i0 + (i0 < g.w - 1 ? 1 : 0);
-        float l1 = fx - (float)i0, l0 = 1.f - l1;
-        float wgt = (i0 == xl ? l0 : 0.f) + (i1 == xl ? l1 : 0.f);
+        const int i0 = sI0[xx - x0];
+        const float l1 = sL1[xx - x0];
+        const int i1 = i0 + (i0 < g.w - 1 ? 1 : 0);
+        const float wgt = (i0 == xl ? 1.f - l1 : 0.f) + (i1 == xl ? l1 : 0.f);
         if (wgt != 0.f) s += wgt * sG[(hd * 256 + (xx - x0)) * GP + j];
       }
-      sAcc[idx] += s;
+      sAcc[(hd * g.w + xl) * Q + j] += s;
     }
     __syncthreads();
   }
@@ -604,7 +645,7 @@ static size_t pass1_lds(int Q, int C) {
 }
 static size_t pass2_lds(int Q, int C, int w) {
   size_t QC = (size_t)Q * C;
-  return (2 * QC + 2 * 256 * (size_t)(Q + 1) + 2 * (size_t)w * Q) * 4;
+  return (2 * QC + 2 * 256 * (size_t)(Q + 1) + 2 * (size_t)w * Q + 512) * 4;
 }
 
 static int fill_args(const simt_head_desc* d, HeadArgs& a) {

@@ -136,12 +136,12 @@ class LaunchList:
                            ("Cin", "<i4"), ("RS", "<i4"), ("row_off", "<i4"), ("tap_off", "<i4"), ("Ck", "<i4"), ("mode", "<i4"),
                            ("dtype", "<i4")])
         assert job_dt.itemsize == 72
-        recs, chunks, chunk = [], [], 32768
+        recs, chunks, chunk = [], [], 1024
         for ji, it in enumerate(packs):
             w, dst, cout, cin, rs, row_off, tap_off, ldk, ck, mode, cscale, dtype = it.args
             total = cout * cin * rs
             recs.append((w, dst, cscale or 0, ldk, total, cout, cin, rs, row_off, tap_off, ck, mode, dtype))
-            chunks += [(ji, ci) for ci in range((total + chunk - 1) // chunk)]
+            chunks += [(ji, ti) for ti in range(((cout + 31) // 32) * ((cin + 31) // 32))]      # 32x32 (cout, cin) tiles
         jobs = torch.from_numpy(np.array(recs, dtype=job_dt).view(np.uint8).copy()).to(device)
         ch = torch.tensor(chunks, dtype=torch.int32).to(device)
         last = max(i for i, it in enumerate(self.items) if it.fn is lib.simt_pack_weight)
