@@ -139,14 +139,21 @@ def main():
             for (tag, shape), v in sorted(shp.items(), key=lambda kv: -kv[1][0]):
                 print(f"{tag:28s} {shape:44s} n={v[3]:3d} total {v[0]:7.3f} ms  avg {v[0] / v[3] * 1e3:8.1f} us  "
                       f"{v[1] / (v[0] * 1e-3) / 1e12:7.1f} TF/s  {v[2] / (v[0] * 1e-3) / 1e9:7.0f} GB/s(alg)", file=sys.stderr)
-        conv = {k: v for k, v in acc.items() if k.startswith("conv_")}
+        conv = {k: v for k, v in acc.items() if k.startswith("conv_igemm")}
         dom = max(conv, key=lambda k: conv[k][0])
         ms_k, fl, by, n = conv[dom]
         ach = fl / (ms_k * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[a.dtype]
         tot_ms = sum(v[0] for v in acc.values())
+        traffic, tsrc = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):       # HBM bytes per launch from rocprofv3 PMC passes of this same command (see the file)
+            for kname, v in json.load(open(pmc))["kernels"].items():
+                if kname.replace("void ", "").strip() == dom:
+                    traffic, tsrc = v["hbm_bytes_per_launch_corrected"], "profiles/r01_pmc_traffic.json"
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": n,
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+                "alg_bytes_per_launch": int(by / n), "launches_per_step": n,
                 "avg_launch_us": round(ms_k / n * 1e3, 2), "alg_gflop_per_launch": round(fl / n / 1e9, 3),
                 "share_of_step_kernel_time": round(ms_k / tot_ms, 3),
                 "classes": {k: {"ms": round(v[0], 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[1] else None,

@@ -48,6 +48,8 @@ typedef struct {
   int16_t dy[SIMT_MAX_TAPS], dx[SIMT_MAX_TAPS];
 } simt_conv_desc;
 int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);
+/* which kernel instantiation simt_conv_fprop runs for d: returns 0 (conv_igemm_kernel) or 2 (conv_igemm2_kernel<bn,tm,nst>) */
+int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int* nst);
 
 /* ---- convolution: wgrad (split-K over pixels, transposed MFMA operands) -------------------------------
  * slab[split][co][tap*Cin+ci] = sum_{m in split} dy[m][co] * x[pixel(m)*stride + (dy,dx)[tap]][ci]

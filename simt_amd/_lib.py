@@ -81,6 +81,7 @@ SIGNATURES = {
     "simt_last_error": (C.c_char_p, []),
     "simt_abi_version": (_I, []),
     "simt_conv_fprop": (_I, [C.POINTER(ConvDesc), c_p]),
+    "simt_conv_variant": (_I, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "simt_conv_wgrad": (_I, [C.POINTER(WgradDesc), c_p]),
     "simt_wgrad_reduce": (_I, [c_p, c_p, _I, _I, _I, _I, _I, _I, _I, _I, _I, c_p]),
     "simt_pack_weight": (_I, [c_p, c_p, _I, _I, _I, _I, _I, _L, _I, _I, c_p, _I, c_p]),

@@ -369,6 +369,34 @@ static void pick_rows(int M, int ntn, bool allow160, int* rows, int* tm) {
   }
 }
 
+struct Conv2Variant { int tile_n, tm, nst, rows, ntiles_n; };
+static Conv2Variant pick_variant(const simt_conv_desc* d) {
+  Conv2Variant v;
+  const int M = d->B * d->Ho * d->Wo;
+  // Short reductions with wide outputs (1x1 convs 256 -> 1024 and their dgrads) are bound by the output stream, not by
+  // MFMA: run them as 128-column tiles with a 2-stage ring, two workgroups per CU.
+  v.tile_n = d->tile_n;
+  const bool short_k = d->tile_n == 256 && d->dtype_out == SIMT_BF16 && (long)d->ntaps * d->Cin <= 512 && d->Cout >= 512;
+  if (short_k) v.tile_n = 128;
+  v.nst = short_k ? 2 : 3;
+  v.ntiles_n = d->Npad / v.tile_n;
+  v.tm = 4;
+  pick_rows(M, short_k ? (v.ntiles_n + 1) / 2 : v.ntiles_n, v.tile_n != 64, &v.rows, &v.tm);
+  if (v.tile_n == 64) v.tm = 2;
+  return v;
+}
+
+// Which instantiation simt_conv_fprop will run for this descriptor (profiling / reporting): 0 = conv_igemm_kernel (v1),
+// otherwise conv_igemm2_kernel<bn, tm, nst>.
+extern "C" int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int* nst) {
+  const bool v2 = d->dtype_in == SIMT_BF16 && d->tile_n >= 64 &&
+                  (d->dtype_out == SIMT_BF16 || (!d->bias && !d->res && !d->relu && !d->stats && d->tile_n == 256));
+  if (!v2) { *bn = d->tile_n; *tm = 0; *nst = 2; return 0; }
+  const Conv2Variant v = pick_variant(d);
+  *bn = v.tile_n; *tm = v.tm; *nst = v.nst;
+  return 2;
+}
+
 // Called by simt_conv_fprop (conv_igemm.hip) for bf16 -> bf16 problems with tile_n in {64, 128, 256}.
 int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
   Conv2KArgs k;
@@ -381,14 +409,11 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
   k.kc_per_tap = d->Cin * 2 / 128;
   k.pix_bytes = d->Cin * 2;
   k.wrow_bytes = d->ntaps * d->Cin * 2;
-  // Short reductions with wide outputs (1x1 convs 256 -> 1024 and their dgrads) are bound by the output stream, not by
-  // MFMA: run them as 128-column tiles with a 2-stage ring, two workgroups per CU.
-  int tile_n = d->tile_n;
-  const bool short_k = tile_n == 256 && !k.out_f32 && (long)d->ntaps * d->Cin <= 512 && d->Cout >= 512;
-  if (short_k) tile_n = 128;
-  k.ntiles_n = d->Npad / tile_n;
-  int tm = 4;
-  pick_rows(k.M, short_k ? (k.ntiles_n + 1) / 2 : k.ntiles_n, tile_n != 64, &k.rows, &tm);
+  const Conv2Variant v = pick_variant(d);
+  const int tile_n = v.tile_n, tm = v.tm;
+  const bool short_k = v.nst == 2;
+  k.ntiles_n = v.ntiles_n;
+  k.rows = v.rows;
   k.ntiles_m = (k.M + k.rows - 1) / k.rows;
   k.nblk128 = (k.M + 127) / 128;
   SIMT_CHECK((long)d->B * d->H * d->W * d->Cin * 2 < (1l << 32));      // 32-bit byte offsets

@@ -263,7 +263,10 @@ class TrunkPlan:
         M = Bn * Ho * Wo
         k = alg_k if alg_k is not None else len(taps) * Cin
         tn = {torch.bfloat16: "bf16", torch.float32: "f32"}
-        tag = f"conv_igemm<{tn[x.dtype]},{tn[y.dtype]},{tile}>"
+        bn_, tm_, nst_ = C.c_int(), C.c_int(), C.c_int()
+        gen = L.load().simt_conv_variant(C.byref(d), C.byref(bn_), C.byref(tm_), C.byref(nst_))
+        tag = (f"conv_igemm2_kernel<{bn_.value}, {tm_.value}, {nst_.value}, 0>" if gen == 2 else
+               f"conv_igemm_kernel<{tn[x.dtype]}, {tn[y.dtype]}, {tile}>")
         nbytes = (Bn * Hi * Wi * Cin + npad * len(taps) * Cin) * x.element_size() + M * Cout * y.element_size()
         lst.add_desc("simt_conv_fprop", d, tag=tag, flops=alg_flops if alg_flops is not None else 2.0 * M * Cout * k,
                      nbytes=float(nbytes),
