@@ -192,10 +192,20 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
       if (MODE != 2) wait_stage(kt + 1 < nk);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (MODE != 2 && kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);     // stage kt+NST-1 -> buffer (buf-1) mod NST
-      if (MODE != 1) {
+      if constexpr (MODE == 0 || MODE == 11 || MODE == 13) {
         load_frags(buf);
+        if (kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
+        if (MODE == 13) __builtin_amdgcn_s_setprio(1);
         mma();
+        if (MODE == 13) __builtin_amdgcn_s_setprio(0);
+      } else {
+        if (MODE != 2 && kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);     // stage kt+NST-1 -> buffer (buf-1) mod NST
+        if (MODE != 1) {
+          load_frags(buf);
+          if (MODE == 12) __builtin_amdgcn_s_setprio(1);
+          mma();
+          if (MODE == 12) __builtin_amdgcn_s_setprio(0);
+        }
       }
       buf = (buf + 1 == NST) ? 0 : buf + 1;
     }
@@ -206,7 +216,11 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my fragment reads of stage kt-1 are done before anyone refills
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (MODE != 1 && kt > 0) mma();
+      if (MODE != 1 && kt > 0) {
+        if (MODE == 12 || MODE == 13) __builtin_amdgcn_s_setprio(1);
+        mma();
+        if (MODE == 12 || MODE == 13) __builtin_amdgcn_s_setprio(0);
+      }
       if (MODE != 2 && kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
       if (MODE != 1) load_frags(buf);
       buf = (buf + 1 == NST) ? 0 : buf + 1;
@@ -352,6 +366,9 @@ static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
   }
   if (mode == 1) return launch_conv2m<BN, TM, NST, 1>(k, st);
   if (mode == 2) return launch_conv2m<BN, TM, NST, 2>(k, st);
+  if (mode == 11) return launch_conv2m<BN, TM, NST, 11>(k, st);
+  if (mode == 12) return launch_conv2m<BN, TM, NST, 12>(k, st);
+  if (mode == 13) return launch_conv2m<BN, TM, NST, 13>(k, st);
   return launch_conv2m<BN, TM, NST, 0>(k, st);
 }
 
@@ -376,7 +393,8 @@ static Conv2Variant pick_variant(const simt_conv_desc* d) {
   // Short reductions with wide outputs (1x1 convs 256 -> 1024 and their dgrads) are bound by the output stream, not by
   // MFMA: run them as 128-column tiles with a 2-stage ring, two workgroups per CU.
   v.tile_n = d->tile_n;
-  const bool short_k = d->tile_n == 256 && d->dtype_out == SIMT_BF16 && (long)d->ntaps * d->Cin <= 512 && d->Cout >= 512;
+  const long Kt = (long)d->ntaps * d->Cin;
+  const bool short_k = d->tile_n == 256 && d->dtype_out == SIMT_BF16 && ((Kt <= 512 && d->Cout >= 512) || (Kt <= 128 && d->Cout >= 256));
   if (short_k) v.tile_n = 128;
   v.nst = short_k ? 2 : 3;
   v.ntiles_n = d->Npad / v.tile_n;
