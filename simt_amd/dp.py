@@ -56,8 +56,9 @@ class BucketReducer:
         else:
             self.handles.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), t))
 
-    def ready_upto(self, launch_index):
-        """Called by the backward replay after `launch_index` launches have been enqueued."""
+    def ready_upto(self, launch_index, producer_event=None):
+        """Called by the backward replay after `launch_index` launch-list entries have been enqueued.  producer_event:
+        event on the stream that writes the gradients (the plan's side stream) covering those entries."""
         while self.next < len(self.buckets) and self.buckets[self.next][2] <= launch_index:
             s, e, _ = self.buckets[self.next]
             self.next += 1
@@ -68,6 +69,8 @@ class BucketReducer:
                 ev.record(torch.cuda.current_stream())
                 with torch.cuda.stream(self.comm):
                     self.comm.wait_event(ev)
+                    if producer_event is not None:
+                        self.comm.wait_event(producer_event)
                     self._reduce(self.flat[s:e])
             else:
                 self._reduce(self.flat[s:e])

@@ -67,10 +67,24 @@ def single_head(num_classes):
 
 
 class _Launch:
-    __slots__ = ("fn", "args", "keep", "tag", "flops", "bytes", "shape")
+    __slots__ = ("fn", "args", "keep", "tag", "flops", "bytes", "shape", "stream")
 
-    def __init__(self, fn, args, keep, tag=None, flops=0.0, nbytes=0.0, shape=None):
+    def __init__(self, fn, args, keep, tag=None, flops=0.0, nbytes=0.0, shape=None, stream=0):
         self.fn, self.args, self.keep, self.tag, self.flops, self.bytes, self.shape = fn, args, keep, tag, flops, nbytes, shape
+        self.stream = stream          # 0 = the caller's current stream, 1 = the plan's side stream
+
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(device=None):
+    """One extra HIP stream per device: weight-gradient GEMMs (off the critical path of backward) and the frozen
+    model's forward run there, so their MFMA-bound workgroups share the CUs with the HBM-bound BatchNorm passes of the
+    main stream instead of queueing behind them."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev not in _SIDE_STREAMS:
+        _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[dev]
 
 
 class LaunchList:
@@ -79,9 +93,18 @@ class LaunchList:
     def __init__(self):
         self.items = []
 
-    def add(self, name, *args, keep=None, tag=None, flops=0.0, nbytes=0.0, shape=None):
+    def add(self, name, *args, keep=None, tag=None, flops=0.0, nbytes=0.0, shape=None, stream=0):
         fn = getattr(L.load(), name)
-        self.items.append(_Launch(fn, args, keep, tag or name, flops, nbytes, shape))
+        self.items.append(_Launch(fn, args, keep, tag or name, flops, nbytes, shape, stream))
+
+    def record(self, stream):
+        """Event recorded on `stream` at this point of the replay; returns it (pass to wait())."""
+        ev = torch.cuda.Event()
+        self.items.append(_Launch(None, (ev,), None, "record", stream=stream))
+        return ev
+
+    def wait(self, ev, stream):
+        self.items.append(_Launch(None, (ev,), None, "wait", stream=stream))
 
     def add_desc(self, name, desc, **kw):
         self.add(name, C.byref(desc), keep=desc, **kw)
@@ -93,6 +116,8 @@ class LaunchList:
         st = stream.cuda_stream
         evs = []
         for it in self.items:
+            if it.fn is None:       # measured serially on one stream: stream assignments and events are not needed
+                continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             rc = it.fn(*it.args, st)
@@ -114,10 +139,27 @@ class LaunchList:
                 b[2] += it.bytes
                 b[3] += 1
 
-    def run(self):
-        st = torch.cuda.current_stream().cuda_stream
+    def run(self, single_stream=False):
+        main = torch.cuda.current_stream()
+        if single_stream or not any(it.stream for it in self.items):
+            st = main.cuda_stream
+            for it in self.items:
+                if it.fn is None:
+                    continue
+                rc = it.fn(*it.args, st)
+                if rc != 0:
+                    L.check(rc)
+            return
+        streams = (main, side_stream(main.device))
+        handles = (main.cuda_stream, streams[1].cuda_stream)
         for it in self.items:
-            rc = it.fn(*it.args, st)
+            if it.fn is None:
+                if it.tag == "record":
+                    it.args[0].record(streams[it.stream])
+                else:
+                    streams[it.stream].wait_event(it.args[0])
+                continue
+            rc = it.fn(*it.args, handles[it.stream])
             if rc != 0:
                 L.check(rc)
 
@@ -529,7 +571,7 @@ class TrunkPlan:
             off += k
 
     # ------------------------------------------------------------------ backward construction
-    def _wgrad(self, lst, dy, x, gname, *, Bn, Hi, Wi, Cin, Ho, Wo, Cd, ldd, taps, stride, parts):
+    def _wgrad(self, lst, dy, x, gname, *, Bn, Hi, Wi, Cin, Ho, Wo, Cd, ldd, taps, stride, parts, stream=1):
         """parts: [(param name, co_off, tap_off, Cout, RS, Cin_dst)] slices of the slab reduced into OIHW gradients."""
         M = Bn * Ho * Wo
         Ktot = len(taps) * Cin
@@ -542,10 +584,10 @@ class TrunkPlan:
         lst.add_desc("simt_conv_wgrad", d, tag=f"conv_wgrad<{'bf16' if self.dtype == torch.bfloat16 else 'f32'}>",
                      flops=2.0 * M * alg_cd * (147 if parts[0][0] == "conv1.weight" else Ktot),
                      nbytes=float((M * ldd + Bn * Hi * Wi * Cin) * self.esz + nsplit * Cd * Ktot * 4),
-                     shape=f"M{M} Cd{Cd} K{Ktot} taps{len(taps)} split{nsplit}")
+                     shape=f"M{M} Cd{Cd} K{Ktot} taps{len(taps)} split{nsplit}", stream=stream)
         for (pname, co_off, tap_off, cout, rs, cin_dst) in parts:
             lst.add("simt_wgrad_reduce", slab.data_ptr(), self.grads[pname].data_ptr(), nsplit, Cd, Ktot, cin_dst, co_off,
-                    tap_off, cout, rs, 0)
+                    tap_off, cout, rs, 0, stream=stream)
             self.grad_ready[pname] = len(lst)
 
     def _bn_bwd(self, lst, *, dz, y, bname, dy, M, Cn, mask_mode, z=None, y2=None, bname2=None, dy2=None, gout=None):
@@ -600,6 +642,13 @@ class TrunkPlan:
         self.grad_ready = {}  # param name -> number of backward launches after which its gradient is final
         self.bwd_marks = {}   # block name -> (first launch, end launch, dz buffer, dx buffer): debugging / DP buckets
         dz = None  # gradient w.r.t. the current block's output z
+        # Two-stream schedule: the dgrad / BN-backward chain is the critical path (stream 0); every weight-gradient GEMM
+        # (+ slab reduce, bias column sums) runs on the side stream (1) behind an event recorded after the kernel that
+        # produced its dY.  dY buffers are double-buffered by block parity; stream 0 waits for the side stream's work of
+        # the block two steps back before it overwrites them.
+        e0 = b.record(0)
+        b.wait(e0, 1)
+        last_side = {0: None, 1: None}
         for bi in range(n_blocks - 1, -1, -1):
             rec = self.block_io[bi]
             name, Mo, Mi, p, inpl = rec["name"], rec["Mo"], rec["Mi"], rec["planes"], rec["inpl"]
@@ -612,22 +661,27 @@ class TrunkPlan:
                     dz = self._build_head_bwd(hd, dz, Mo, c4, bi)
             assert dz is not None, "no gradient reaches the last block (a head must sit on the last layer)"
             blk_start = len(b)
+            par = bi & 1
+            if last_side[par] is not None:
+                b.wait(last_side[par], 0)
             # ---- z = relu(bn3(y3) + shortcut)
-            dy3 = self.buf("g.dy3", Mo, c4)
+            dy3 = self.buf("g.dy3.%d" % par, Mo, c4)
             g = self.buf("g.g", Mo, c4)
-            dyd = self.buf("g.dyd", Mo, c4) if down else None
+            dyd = self.buf("g.dyd.%d" % par, Mo, c4) if down else None
             self._bn_bwd(b, dz=dz, z=rec["z"], y=rec["y3"], bname=f"{name}.bn3", dy=dy3, M=Mo, Cn=c4, mask_mode=1,
                          y2=rec.get("yd"), bname2=f"{name}.downsample.1" if down else None, dy2=dyd,
                          gout=None if down else g)
             # conv3
+            b.wait(b.record(0), 1)
             self._wgrad(b, dy3, rec["a2"], None, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4, taps=[(0, 0)],
                         stride=1, parts=[(f"{name}.conv3.weight", 0, 0, c4, 1, p)])
             wt3 = self._plan_pack_t(f"{name}.conv3", c4, p, 1)
             da2 = self.buf("g.da", Mo, p)
             self._conv(b, dy3, wt3[:3], da2, Bn=B, Hi=Ho, Wi=Wo, Cin=wt3[3], Ho=Ho, Wo=Wo, Cout=p, taps=[(0, 0)])
-            dy2 = self.buf("g.dyp", Mo, p)
+            dy2 = self.buf("g.dy2.%d" % par, Mo, p)
             self._bn_bwd(b, dz=da2, y=rec["y2"], bname=f"{name}.bn2", dy=dy2, M=Mo, Cn=p, mask_mode=2)
             # conv2 (3x3 dilated)
+            b.wait(b.record(0), 1)
             t3 = ops.conv_taps(3, 3, dil, dil)
             self._wgrad(b, dy2, rec["a1"], None, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cd=p, ldd=p, taps=t3, stride=1,
                         parts=[(f"{name}.conv2.weight", 0, 0, p, 9, p)])
@@ -637,14 +691,16 @@ class TrunkPlan:
             assert wt2[3] == p and wt3[3] == c4
             self._conv(b, dy2, wt2[:3], da1, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cout=p,
                        taps=[(-a, -c) for (a, c) in t3])
-            dy1 = self.buf("g.dyp", Mo, p)
+            dy1 = self.buf("g.dy1.%d" % par, Mo, p)
             self._bn_bwd(b, dz=da1, y=rec["y1"], bname=f"{name}.bn1", dy=dy1, M=Mo, Cn=p, mask_mode=2)
             # conv1 (+ downsample) wgrads
+            b.wait(b.record(0), 1)
             self._wgrad(b, dy1, rec["x"], None, Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Ho, Wo=Wo, Cd=p, ldd=p, taps=[(0, 0)],
                         stride=stride, parts=[(f"{name}.conv1.weight", 0, 0, p, 1, inpl)])
             if down:
                 self._wgrad(b, dyd, rec["x"], None, Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4,
                             taps=[(0, 0)], stride=stride, parts=[(f"{name}.downsample.0.weight", 0, 0, c4, 1, inpl)])
+            last_side[par] = b.record(1)
             # input gradient
             wt1 = self._plan_pack_t(f"{name}.conv1", p, inpl, 1)
             assert wt1[3] == p
@@ -675,8 +731,10 @@ class TrunkPlan:
               ops.dt_code(dt))
         dy0 = self.buf("g.dy0", M0, 64)
         self._bn_bwd(b, dz=da0, y=self.saved["stem.y"], bname="bn1", dy=dy0, M=M0, Cn=64, mask_mode=2)
+        b.wait(b.record(0), 1)
         self._wgrad(b, dy0, self.saved["stem.A"], None, Bn=1, Hi=1, Wi=M0, Cin=192, Ho=1, Wo=M0, Cd=64, ldd=64,
                     taps=[(0, 0)], stride=1, parts=[("conv1.weight", 0, 0, 64, 1, 147)])
+        b.wait(b.record(1), 0)        # join: the optimiser (stream 0) sees every gradient
 
     def _build_head_bwd(self, hd, dz_prev, Mo, c4, bi):
         """wgrad/bias grads of the fused ASPP GEMM and its dgrad into the feature gradient (added to dz_prev)."""
@@ -690,7 +748,7 @@ class TrunkPlan:
             for i in range(nd):
                 gname = f"{prefix}.conv2d_list.{i}.bias"
                 b.add("simt_colsum", dl.data_ptr() + row * self.esz, self.grads[gname].data_ptr(), Mh, hd.ck, cout, 0,
-                      ops.dt_code(self.dtype))
+                      ops.dt_code(self.dtype), stream=1)
                 self.grad_ready[gname] = len(b)
             row += cout
         dfeat = self.buf("g.dfeat%d" % hd.feat_layer, Mo, c4)
@@ -727,6 +785,7 @@ class TrunkPlan:
         td.B, td.H, td.W, td.Q, td.QP, td.lds, td.ldd, td.ntaps = B, hd.h, hd.w, hd.Q, QP, hd.ck, kexp, nt
         ops._fill_taps(td.dy, td.dx, hd.taps)
         b.add_desc("simt_tap_scatter", td)
+        b.wait(b.record(0), 1)
         nsplit = ops.wgrad_nsplit(Mh, nexp, hd.cin, self.dtype)
         assert nsplit * nexp * hd.cin <= self._slab_cap
         slab = self.buf("wgrad.slab", self._slab_cap, dtype=torch.float32)
@@ -734,13 +793,13 @@ class TrunkPlan:
                                  stride=1, nsplit=nsplit, ldd=kexp)
         b.add_desc("simt_conv_wgrad", wd, tag="conv_wgrad<bf16>", flops=2.0 * Mh * hd.Q * nt * hd.cin,
                    nbytes=float((Mh * kexp + Mh * hd.cin) * 2 + nsplit * nexp * hd.cin * 4),
-                   shape=f"M{Mh} Cd{nexp} K{hd.cin} taps1 split{nsplit} (tap-expanded head)")
+                   shape=f"M{Mh} Cd{nexp} K{hd.cin} taps1 split{nsplit} (tap-expanded head)", stream=1)
         row = 0
         for prefix, cout in hd.groups:
             for i in range(nd):
                 gname = f"{prefix}.conv2d_list.{i}.weight"
                 b.add("simt_wgrad_reduce_exp", slab.data_ptr(), self.grads[gname].data_ptr(), nsplit, nexp, hd.cin, QP, row,
-                      9 * i, cout, 9)
+                      9 * i, cout, 9, stream=1)
                 self.grad_ready[gname] = len(b)
             row += cout
         wt = self.new(npad, kexp, zero=True)
@@ -764,18 +823,22 @@ class TrunkPlan:
         return self.out
 
     def backward(self, hook=None):
-        """Consumes self.dlogits[*] (conv dtype, K-padded); fills self.grads.  hook(n): called with the number of launches
-        enqueued so far at every point where another gradient tensor became final (DP bucket reducer)."""
+        """Consumes self.dlogits[*] (conv dtype, K-padded); fills self.grads.  hook(n, event): called with the number of
+        launch-list entries replayed so far at every point where another gradient tensor became final, and an event
+        recorded on the side stream (where the weight gradients are produced) -- used by the DP bucket reducer."""
         if hook is None:
             self.bwd_list.run()
             return self.grads
         cuts = sorted(set(self.grad_ready.values()))
         items, i0 = self.bwd_list.items, 0
         seg = LaunchList()
+        side = side_stream(self.dev)
         for c in cuts:
             seg.items = items[i0:c]
             seg.run()
-            hook(c)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            hook(c, ev)
             i0 = c
         seg.items = items[i0:]
         seg.run()
