@@ -22,7 +22,7 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .engine import LaunchList, TrunkPlan, multi_heads
+from .engine import LaunchList, TrunkPlan, multi_heads, side_stream
 
 
 class Hyper:
@@ -185,12 +185,22 @@ class SimTTrainer:
         ni = self.inner_desc
         ni.step0, ni.lr = self.inner_steps * self.it_done, lr_T
         L.call("simt_ntm_inner_loop", C.byref(ni), st)
-        # 2. frozen model -> low-res posterior
-        self.fixed.forward(self.plan.x_in)
-        fl = self.fixed.out["x2"]
-        ops.softmax_rows(fl, self.ldf, self.fixp, self.ldf, self.B * self.h * self.w, self.C)
+        # 2. frozen model -> low-res posterior, on the side stream: its eval-mode convs share the CUs with the HBM-bound
+        #    BatchNorm passes of the trainable forward (3.) instead of running before it
+        main = torch.cuda.current_stream()
+        side = side_stream(self.dev)
+        ev_in = torch.cuda.Event()
+        ev_in.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev_in)
+            self.fixed.x_in.copy_(self.plan.x_in, non_blocking=True)
+            self.fixed.forward()
+            ops.softmax_rows(self.fixed.out["x2"], self.ldf, self.fixp, self.ldf, self.B * self.h * self.w, self.C)
+            ev_fix = torch.cuda.Event()
+            ev_fix.record(side)
         # 3. trainable forward
         self.plan.forward()
+        main.wait_event(ev_fix)
         # 4. fused head + NTM regularisers + gradients of the low-res logits
         L.call("simt_head_loss", C.byref(self.head_desc), st)
         L.call("simt_ntm_post", C.byref(self.post_desc), st)
