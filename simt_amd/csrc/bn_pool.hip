@@ -13,30 +13,30 @@
 //   part [nblk][2][C] (sum, sum of squares)  ->  mean, rstd, scale = gamma*rstd, shift = beta - mean*scale
 //   running_mean/var updated like PyTorch (momentum 0.1, unbiased var), if running != null.
 // ---------------------------------------------------------------------------------------------
-// One block = 32 channels x 8 row lanes: lane r sums partial rows r, r+8, ... (128-B coalesced rows), then the 8 lanes are
-// combined in fixed order through LDS -> bitwise reproducible, and nblk = 4608 (stem) costs 576 loads per thread
-// instead of 9216 dependent ones.
+// One block = 8 channels x 32 row lanes: lane r sums partial rows r, r+32, ... , then the 32 lanes are combined in fixed
+// order through LDS -> bitwise reproducible.  These kernels sit on the critical path between a conv and the pass that
+// consumes its statistics, so they are shaped for latency: C/8 blocks, at most nblk/32 dependent loads per thread.
 template <int NJ>
-__device__ __forceinline__ void part_colsum32(const float* part, int nblk, int C, int c0, double* out /*[NJ]*/, double (*red)[32][NJ]) {
-  const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
+__device__ __forceinline__ void part_colsum8(const float* part, int nblk, int C, int c0, double* out /*[NJ]*/, double (*red)[8][NJ]) {
+  const int cl = threadIdx.x & 7, r = threadIdx.x >> 3;
   const int c = c0 + cl;
   double s[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) s[j] = 0.0;
   if (c < C) {
     int b = r;
-    for (; b + 24 < nblk; b += 32) {
+    for (; b + 96 < nblk; b += 128) {
       float v[4][NJ];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) v[u][j] = part[((long)(b + 8 * u) * NJ + j) * C + c];
+        for (int j = 0; j < NJ; ++j) v[u][j] = part[((long)(b + 32 * u) * NJ + j) * C + c];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) s[j] += (double)v[u][j];
     }
-    for (; b < nblk; b += 8)
+    for (; b < nblk; b += 32)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) s[j] += (double)part[((long)b * NJ + j) * C + c];
   }
@@ -47,8 +47,7 @@ __device__ __forceinline__ void part_colsum32(const float* part, int nblk, int C
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       double t = 0.0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) t += red[q][cl][j];
+      for (int q = 0; q < 32; ++q) t += red[q][cl][j];
       out[j] = t;
     }
   }
@@ -58,11 +57,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* part, int
                                                          const float* beta, float* running_mean, float* running_var,
                                                          float momentum, float eps, float* mean_out, float* rstd_out,
                                                          float* scale_out, float* shift_out) {
-  __shared__ double red[8][32][2];
+  __shared__ double red[32][8][2];
   double s[2];
-  part_colsum32<2>(part, nblk, C, blockIdx.x * 32, s, red);
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-  if ((threadIdx.x >> 5) != 0 || c >= C) return;
+  part_colsum8<2>(part, nblk, C, blockIdx.x * 8, s, red);
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  if ((threadIdx.x >> 3) != 0 || c >= C) return;
   double mean = s[0] / (double)count;
   double var = s[1] / (double)count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -84,7 +83,7 @@ extern "C" int simt_bn_finalize(const float* part, int nblk, int C, long count, 
                                 float* running_mean, float* running_var, float momentum, float eps, float* mean,
                                 float* rstd, float* scale, float* shift, simt_stream_t stream) {
   SIMT_CHECK(part && mean && rstd && scale && shift && C > 0 && nblk > 0);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, nblk, C, count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, part, nblk, C, count,
                      gamma, beta, running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
@@ -222,11 +221,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dz, const T
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, long count, float* coef) {
-  __shared__ double red[8][32][3];
+  __shared__ double red[32][8][3];
   double s[3];
-  part_colsum32<3>(part, nblk, C, blockIdx.x * 32, s, red);
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-  if ((threadIdx.x >> 5) != 0 || c >= C) return;
+  part_colsum8<3>(part, nblk, C, blockIdx.x * 8, s, red);
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  if ((threadIdx.x >> 3) != 0 || c >= C) return;
 #pragma unroll
   for (int j = 0; j < 3; ++j) coef[j * C + c] = (float)(s[j] / (double)count);
 }
@@ -311,7 +310,7 @@ extern "C" int simt_bn_bwd(const simt_bn_bwd_desc* d, simt_stream_t stream) {
                        (const float*)d->y2, d->mean2, d->rstd2, d->part, d->M, d->C, rpb, d->mask_mode);
   }
   SIMT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 31) / 32), dim3(256), 0, st, d->part, nblk, d->C, d->M, d->coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 7) / 8), dim3(256), 0, st, d->part, nblk, d->C, d->M, d->coef);
   SIMT_LAUNCH_CHECK();
   if (d->dtype == SIMT_BF16) {
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)d->dz,
