@@ -213,6 +213,13 @@ int simt_ce2d_bwd(const float* pred, const int64_t* target, const float* weight,
 int simt_entropy2d(const float* x, int n, int c, int h, int w, void* ws, float* out, const float* grad_out, float* dx,
                    simt_stream_t stream);
 
+/* ---- evaluation (tools/evaluate_cityscapes.py:96-162 evaluate_simt; :81-83 fast_hist) --------------------------------
+ * pred[b][y][x] = argmax_c ( up(la)[c] + up(lb)[c] ), bilinear align_corners=True to (H, W), first index on ties;
+ * lb may be NULL (single scale).  hist[n*gt + pred] += 1 for 0 <= gt < n (int64, accumulates across calls). */
+int simt_upsample_sum_argmax(const float* la, int ha, int wa, int lda, const float* lb, int hb, int wb, int ldb, int B, int H,
+                             int W, int C, int32_t* pred, simt_stream_t stream);
+int simt_confusion_hist(const int64_t* gt, const int32_t* pred, long P, int n, int64_t* hist, simt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,6 +113,8 @@ SIGNATURES = {
     "simt_tap_gather_sum": (_I, [C.POINTER(TapDesc), c_p]),
     "simt_tap_scatter": (_I, [C.POINTER(TapDesc), c_p]),
     "simt_wgrad_reduce_exp": (_I, [c_p, c_p, _I, _I, _I, _I, _I, _I, _I, _I, c_p]),
+    "simt_upsample_sum_argmax": (_I, [c_p, _I, _I, _I, c_p, _I, _I, _I, _I, _I, _I, _I, c_p, c_p]),
+    "simt_confusion_hist": (_I, [c_p, c_p, _L, _I, c_p, c_p]),
     "simt_loss_ws_bytes": (_I, []),
     "simt_ce2d_fwd": (_I, [c_p, c_p, c_p, _I, _I, _I, _I, _I, _I, c_p, c_p, c_p]),
     "simt_ce2d_bwd": (_I, [c_p, c_p, c_p, _I, _I, _I, _I, _I, _I, c_p, c_p, c_p, c_p]),

@@ -1,0 +1,106 @@
+// Evaluation path of the reference (tools/evaluate_cityscapes.py:96-162, evaluate_simt): logits of the main head at two
+// input scales are bilinearly upsampled (align_corners=True) to the label resolution, SUMMED, arg-maxed, and scored with
+// a confusion histogram (fast_hist :81-83) -> per-class IoU / mIoU (:86-87).  The reference does the sum / argmax /
+// bincount on the CPU in numpy per image; here one fused kernel gathers the 4 taps of both low-res maps (L2-resident),
+// and the histogram is integer atomics (exact, order-independent).
+#include "common.h"
+
+struct EvalArgs {
+  const float* la;     // [B][ha][wa][lda] logits, scale A (first C channels used)
+  const float* lb;     // [B][hb][wb][ldb] logits, scale B, or NULL
+  int* pred;           // [B][H][W] arg-max class
+  int B, ha, wa, lda, hb, wb, ldb, H, W, C;
+  float sya, sxa, syb, sxb;
+};
+
+__device__ __forceinline__ void bil_taps(int y, int x, int h, int w, float sy, float sx, int& o00, int& o01, int& o10, int& o11,
+                                         float& wy0, float& wy1, float& wx0, float& wx1) {
+  // ATen upsample_bilinear2d, align_corners=True: src = scale * dst, scale = (in-1)/(out-1)
+  const float fy = sy * (float)y, fx = sx * (float)x;
+  int iy0 = (int)fy, ix0 = (int)fx;
+  if (iy0 > h - 1) iy0 = h - 1;
+  if (ix0 > w - 1) ix0 = w - 1;
+  const int iy1 = iy0 + (iy0 < h - 1 ? 1 : 0), ix1 = ix0 + (ix0 < w - 1 ? 1 : 0);
+  wy1 = fy - (float)iy0; wy0 = 1.f - wy1;
+  wx1 = fx - (float)ix0; wx0 = 1.f - wx1;
+  o00 = iy0 * w + ix0; o01 = iy0 * w + ix1; o10 = iy1 * w + ix0; o11 = iy1 * w + ix1;
+}
+
+__global__ __launch_bounds__(256) void upsample_sum_argmax_kernel(EvalArgs a) {
+  const long P = (long)a.B * a.H * a.W;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(p % a.W);
+    const long t = p / a.W;
+    const int y = (int)(t % a.H);
+    const int b = (int)(t / a.H);
+    int a00, a01, a10, a11, b00 = 0, b01 = 0, b10 = 0, b11 = 0;
+    float ay0, ay1, ax0, ax1, by0 = 0, by1 = 0, bx0 = 0, bx1 = 0;
+    bil_taps(y, x, a.ha, a.wa, a.sya, a.sxa, a00, a01, a10, a11, ay0, ay1, ax0, ax1);
+    const float* pa = a.la + (long)b * a.ha * a.wa * a.lda;
+    const float* pb = nullptr;
+    if (a.lb) {
+      bil_taps(y, x, a.hb, a.wb, a.syb, a.sxb, b00, b01, b10, b11, by0, by1, bx0, bx1);
+      pb = a.lb + (long)b * a.hb * a.wb * a.ldb;
+    }
+    float best = -INFINITY;
+    int arg = 0;
+    for (int c = 0; c < a.C; ++c) {
+      // same association as ATen: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11); then numpy's a + b
+      float v = ay0 * (ax0 * pa[(long)a00 * a.lda + c] + ax1 * pa[(long)a01 * a.lda + c]) +
+                ay1 * (ax0 * pa[(long)a10 * a.lda + c] + ax1 * pa[(long)a11 * a.lda + c]);
+      if (pb) {
+        const float u = by0 * (bx0 * pb[(long)b00 * a.ldb + c] + bx1 * pb[(long)b01 * a.ldb + c]) +
+                        by1 * (bx0 * pb[(long)b10 * a.ldb + c] + bx1 * pb[(long)b11 * a.ldb + c]);
+        v = v + u;
+      }
+      if (v > best) { best = v; arg = c; }     // first index on ties, like np.argmax
+    }
+    a.pred[p] = arg;
+  }
+}
+
+extern "C" int simt_upsample_sum_argmax(const float* la, int ha, int wa, int lda, const float* lb, int hb, int wb, int ldb,
+                                        int B, int H, int W, int C, int32_t* pred, simt_stream_t stream) {
+  SIMT_CHECK(la && pred && B > 0 && C > 0 && C <= lda && (!lb || C <= ldb));
+  EvalArgs a;
+  a.la = la; a.lb = lb; a.pred = pred; a.B = B; a.ha = ha; a.wa = wa; a.lda = lda; a.hb = hb; a.wb = wb; a.ldb = ldb;
+  a.H = H; a.W = W; a.C = C;
+  a.sya = H > 1 ? (float)(ha - 1) / (float)(H - 1) : 0.f;
+  a.sxa = W > 1 ? (float)(wa - 1) / (float)(W - 1) : 0.f;
+  a.syb = (lb && H > 1) ? (float)(hb - 1) / (float)(H - 1) : 0.f;
+  a.sxb = (lb && W > 1) ? (float)(wb - 1) / (float)(W - 1) : 0.f;
+  long P = (long)B * H * W;
+  long grid = (P + 255) / 256;
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(upsample_sum_argmax_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+// hist[n*gt + pred] += 1 for 0 <= gt < n   (fast_hist: labels outside [0, n) -- the 255 "ignore" id -- are skipped)
+__global__ __launch_bounds__(256) void confusion_hist_kernel(const int64_t* gt, const int32_t* pred, long P, int n,
+                                                             unsigned long long* hist) {
+  __shared__ unsigned int sh[32 * 32];
+  const int nn = n * n;
+  for (int i = threadIdx.x; i < nn; i += 256) sh[i] = 0u;
+  __syncthreads();
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+    const long long g = gt[p];
+    const int q = pred[p];
+    if (g >= 0 && g < n && q >= 0 && q < n) atomicAdd(&sh[(int)g * n + q], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nn; i += 256)
+    if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
+}
+
+extern "C" int simt_confusion_hist(const int64_t* gt, const int32_t* pred, long P, int n, int64_t* hist,
+                                   simt_stream_t stream) {
+  SIMT_CHECK(gt && pred && hist && n > 0 && n <= 32);
+  long grid = (P + 255) / 256;
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(confusion_hist_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, gt, pred, P, n,
+                     (unsigned long long*)hist);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}

@@ -1,0 +1,88 @@
+"""GPU parity of the evaluation path (reference tools/evaluate_cityscapes.py:81-162): two-scale upsample +
+sum + arg-max, confusion histogram, mIoU -- against the reference's definition evaluated on the CPU (torch
+F.interpolate align_corners=True + numpy argmax / bincount, i.e. the oracle's fast_hist / per_class_iu pinned by golden
+g9).  Histogram and mIoU given identical predictions: bit-exact.  Arg-max from fp32 logits: exact except where the top
+two summed logits are within 1e-5 of each other (the CPU may or may not contract a*b+c into an FMA)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import simt_oracle as so
+from simt_amd import _lib as L
+from simt_amd import ops
+from simt_amd.tools.evaluate_cityscapes import Evaluator, fast_hist, per_class_iu
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_upsample_sum_argmax_and_histogram(dev):
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W = 2, 19, 96, 160
+    la = torch.randn(B, C, 13, 21, generator=g) * 3
+    lb = torch.randn(B, C, 17, 26, generator=g) * 3
+    ref_sum = (F.interpolate(la, size=(H, W), mode="bilinear", align_corners=True).numpy() +
+               F.interpolate(lb, size=(H, W), mode="bilinear", align_corners=True).numpy())
+    ref = np.argmax(ref_sum.transpose(0, 2, 3, 1), axis=3)
+
+    def nhwc(t, ld=32):
+        o = torch.zeros(t.shape[0], t.shape[2], t.shape[3], ld)
+        o[..., :t.shape[1]] = t.permute(0, 2, 3, 1)
+        return o.to(dev)
+    a_d, b_d = nhwc(la), nhwc(lb)
+    pred = torch.full((B, H, W), -1, device=dev, dtype=torch.int32)
+    L.call("simt_upsample_sum_argmax", ops._p(a_d), 13, 21, 32, ops._p(b_d), 17, 26, 32, B, H, W, C, ops._p(pred), ops.stream_ptr())
+    got = pred.cpu().numpy()
+    srt = np.sort(ref_sum, axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    diff = got != ref
+    assert diff.sum() <= 2 and np.all(margin[diff] < 1e-5), f"{diff.sum()} mismatches, margins {margin[diff]}"
+    # single scale
+    L.call("simt_upsample_sum_argmax", ops._p(a_d), 13, 21, 32, None, 0, 0, 0, B, H, W, C, ops._p(pred), ops.stream_ptr())
+    ref1 = F.interpolate(la, size=(H, W), mode="bilinear", align_corners=True).argmax(1).numpy()
+    assert (pred.cpu().numpy() != ref1).sum() <= 2
+    # confusion histogram: exact, ignores labels outside [0, n), accumulates across calls
+    gt = torch.randint(0, C, (B, H, W), generator=g)
+    gt[torch.rand(B, H, W, generator=g) < 0.1] = 255
+    hist = torch.zeros(C * C, device=dev, dtype=torch.int64)
+    for _ in range(2):
+        L.call("simt_confusion_hist", ops._p(gt.to(dev)), ops._p(pred), gt.numel(), C, ops._p(hist), ops.stream_ptr())
+    exp = 2 * fast_hist(gt.numpy().flatten(), pred.cpu().numpy().flatten().astype(np.int64), C)
+    assert np.array_equal(hist.cpu().numpy().reshape(C, C), exp)
+
+
+def test_metric_helpers_match_reference_golden():
+    d = np.load(os.path.join(G, "g9_metric.npz"))
+    h = fast_hist(d["gt"], d["pred"], 19)
+    assert np.array_equal(h, d["hist"])
+    np.testing.assert_array_equal(per_class_iu(h), d["iu"])
+    assert round(float(np.nanmean(per_class_iu(h))) * 100, 2) == float(d["miou"])
+
+
+def test_evaluator_end_to_end_small(dev):
+    """Two eval plans (two input scales) + fused predict + histogram vs the oracle on the CPU, fp32, small trunk."""
+    layers = (1, 1, 2, 1)
+    st = so.recipe_state(so.state_shapes(19, 3, True, layers=layers), seed=31, head_scale=8.0)
+    g = torch.Generator().manual_seed(9)
+    B, (H, W) = 1, (64, 96)
+    s1, s2 = (33, 49), (41, 61)
+    img1 = torch.randn(B, 3, *s1, generator=g) * 50
+    img2 = F.interpolate(img1, size=s2, mode="bilinear", align_corners=True)
+    gt = torch.randint(0, 19, (B, H, W), generator=g)
+    ev = Evaluator(st, num_classes=19, open_classes=3, batch=B, label_hw=(H, W), scales=(s1, s2), dtype=torch.float32,
+                   device=dev, layers=layers)
+    ev.add(img1, img2, gt)
+    miou, ius = ev.result()
+    _, o1 = so.deeplab_multi_forward(st, img1, False, True, layers=layers)
+    _, o2 = so.deeplab_multi_forward(st, img2, False, True, layers=layers)
+    out = (F.interpolate(o1[:, :19], size=(H, W), mode="bilinear", align_corners=True).numpy() +
+           F.interpolate(o2[:, :19], size=(H, W), mode="bilinear", align_corners=True).numpy())
+    pred = np.argmax(out.transpose(0, 2, 3, 1), axis=3)
+    got = ev.pred.cpu().numpy()
+    assert (got != pred).mean() < 2e-3          # logits carry 1e-5-level conv noise: near-ties may flip
+    h = fast_hist(gt.numpy().flatten(), got.flatten().astype(np.int64), 19)
+    assert np.array_equal(ev.hist.cpu().numpy().reshape(19, 19), h)
+    assert miou == round(float(np.nanmean(per_class_iu(h))) * 100, 2)
