@@ -149,6 +149,8 @@ typedef struct {
   void* dpred2_t;
   int32_t B, h, w, H, W, C, Q, ldp, ldf, QP, ld_f32, ld_t, grad_dtype;
   float th_high, th_low, lambda_seg, lambda_place, gscale;
+  int32_t mode;         /* 0: SimT loss block.  1: warm-up stage (tools/trainV1_warmup.py:217-224): CE of both heads against
+                         * `label` (ignore 255); fixp/T1/T2 unused (may be NULL); hout[0],[1] = loss_seg1/2, hout[14] = total */
 } simt_head_desc;
 int simt_head_nblk(int B, int H, int W);
 int simt_head_part_floats(int Q, int C);

@@ -485,3 +485,58 @@ class OracleTrainer:
                 s["step"] += 1
                 adam_step_(self.ntm[k], self.ntm[k].grad, s["m"], s["v"], s["step"], lr_T)
         return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# warm-up stage (tools/trainV1_warmup.py:156-256): DeeplabMulti(num_classes) without open-set heads, plain CE
+# ------------------------------------------------------------------------------------------------------------
+def warmup_losses(pred_lr1, pred_lr2, label, lambda_seg, size):
+    """loss = CE(up(pred2), label) + lambda_seg * CE(up(pred1), label), ignore_index 255 (:213-224)."""
+    p1, p2 = upsample(pred_lr1, size), upsample(pred_lr2, size)
+    l1 = F.cross_entropy(p1, label, ignore_index=255)
+    l2 = F.cross_entropy(p2, label, ignore_index=255)
+    return l2 + lambda_seg * l1, l1, l2
+
+
+class OracleWarmupTrainer:
+    """One warm-up iteration: forward (train-mode BN), CE on both heads, backward, SGD over conv1..layer4 (duplicate
+    listings, `optim_parameters(args, warmup=True)`) + heads at 10x lr (:192-193, :205-232)."""
+
+    def __init__(self, st, hp, layers=LAYERS, dtype=torch.float32):
+        self.hp, self.layers, self.dtype = hp, layers, dtype
+        st = {k: (v.to(dtype) if v.dtype != torch.long else v) for k, v in st.items()}
+        self.st = {k: (v.clone().requires_grad_(True) if v.dtype != torch.long and not
+                       (k.endswith("running_mean") or k.endswith("running_var")) else v.clone()) for k, v in st.items()}
+        for k, v in self.st.items():
+            if (".bn" in k or k.startswith("bn1") or "downsample.1" in k) and v.dtype != torch.long and v.requires_grad:
+                v.requires_grad_(False)
+        shapes = {k: tuple(v.shape) for k, v in st.items()}
+        g0, g1 = optim_param_names(shapes, warmup=True, openset=False)
+        self.groups = []
+        for names, lr_mult in ((g0, 1.0), (g1, 10.0)):
+            uniq = list(dict.fromkeys(names))
+            self.groups.append({"names": uniq, "mult": [names.count(n) for n in uniq], "lr_mult": lr_mult})
+        self.bufs, self.first = {}, True
+
+    def step(self, image, label, it):
+        hp = self.hp
+        lr = lr_poly(hp.lr, it, hp.num_steps, hp.power)
+        for v in self.st.values():
+            if v.dtype != torch.long:
+                v.grad = None
+        x1, x2 = deeplab_multi_forward(self.st, image.to(self.dtype), True, False, layers=self.layers)
+        total, l1, l2 = warmup_losses(x1, x2, label, hp.lambda_seg, tuple(label.shape[1:]))
+        total.backward()
+        with torch.no_grad():
+            for g in self.groups:
+                ps, gs, bs, ms = [], [], [], []
+                for n, m in zip(g["names"], g["mult"]):
+                    p = self.st[n]
+                    if p.grad is None:
+                        continue
+                    if n not in self.bufs:
+                        self.bufs[n] = torch.zeros_like(p)
+                    ps.append(p); gs.append(p.grad); bs.append(self.bufs[n]); ms.append(m)
+                sgd_step_(ps, gs, bs, ms, lr * g["lr_mult"], hp.weight_decay, hp.momentum, self.first)
+            self.first = False
+        return {"total": total.detach(), "loss_seg1": l1.detach(), "loss_seg2": l2.detach()}

@@ -186,6 +186,7 @@ struct HeadArgs {
   float* g1;                   // [2][B][H][w][QP] x-reduced gradients
   int QP;
   float gscale;
+  int mode;                    // 0 = SimT loss block; 1 = warm-up stage: plain CE of both heads against `label`
 };
 
 // Full-wave sum with DPP row operations (no LDS crossbar): result valid in lane 63.
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
   float* sRed = (float*)(sEx + 2);                                 // [4][NSCAL]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < QC; i += 256) { sT[i] = a.T1[i]; sT[QC + i] = a.T2[i]; }
+  for (int i = tid; i < QC; i += 256) { sT[i] = a.mode == 0 ? a.T1[i] : 0.f; sT[QC + i] = a.mode == 0 ? a.T2[i] : 0.f; }
   for (int i = tid; i < 8 * QC; i += 256) sdT[i] = 0.f;
   if (tid < 2 * QMAX) sKey[tid] = 0ull;
   if (tid < 2) sEx[tid] = 0ull;
@@ -251,9 +252,9 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
     }
     Taps tp = make_taps(g, b, y, x);
     // ---- fixed-model posterior -> confidence label (reference :354-361)
-    float fm;
-    int fa;
-    interp_argmax<QM>(a.fixp, g.ldf, C, tp, fm, fa);
+    float fm = 0.f;
+    int fa = 0;
+    if (a.mode == 0) interp_argmax<QM>(a.fixp, g.ldf, C, tp, fm, fa);
     asm volatile("" ::: "memory");   // keep the next gathers from being hoisted above (register pressure)
     int conf = (fm > a.th_high) ? fa : 255;
     if (fm < a.th_low) conf = C;
@@ -267,8 +268,16 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
     if (conf == C) conf = (e2.arg >= C) ? e2.arg : 255;  // reference :387-393
 
     long long lab = live ? a.label[p] : 255;
-    const bool lab_ok = live && lab >= 0 && lab != 255 && lab < C;
+    bool lab_ok = live && lab >= 0 && lab != 255 && lab < C;
     const int labi = lab_ok ? (int)lab : 0;
+    if (a.mode == 1) {
+      // warm-up stage (tools/trainV1_warmup.py:217-224): CrossEntropyLoss(ignore_index=255) of both heads against the
+      // label itself; no placeholder, noise-posterior or anchor terms
+      conf = lab_ok ? labi : 255;
+      e1.pseudo1 = 255;
+      e2.pseudo1 = 255;
+      lab_ok = false;
+    }
 
     if (live) {
       if (conf != 255) {
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
       }
     }
     // ---- anchors: arg-max over all pixels of each channel's upsampled logit (first index), Exist masks (:375-384)
-    {
+    if (a.mode == 0) {
       unsigned long long ex1 = live ? (1ull << e1.arg) : 0ull, ex2 = live ? (1ull << e2.arg) : 0ull;
       ex1 = wave_or_u64(ex1);
       ex2 = wave_or_u64(ex2);
@@ -432,7 +441,9 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(HeadArgs a, int nblk
     o[2] = k1 + a.lambda_place * u1; o[3] = k2 + a.lambda_place * u2;
     o[4] = (float)(sc[6] / Ny); o[5] = (float)(sc[7] / Ny);
     o[6] = (float)Np; o[7] = (float)Nk1; o[8] = (float)Nk2; o[9] = (float)Ny;
-    o[10] = k1; o[11] = k2; o[12] = u1; o[13] = u2; o[14] = 0.f; o[15] = 0.f;
+    o[10] = k1; o[11] = k2; o[12] = u1; o[13] = u2;
+    o[14] = o[1] + a.lambda_seg * o[0];      // warm-up total: loss_seg2 + lambda_seg * loss_seg1 (trainV1_warmup.py:224)
+    o[15] = 0.f;
   }
   // dTy: -(1/Ny) * sum_p [label=c] q_j / r
   float* dTy = o + 16 + 2 * QC + 4 * QMAX;
@@ -449,6 +460,7 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(HeadArgs a, int nblk
     ai[tid] = __int_as_float(pidx);
   }
   for (int i = tid; i < 2 * QC; i += 256) {
+    if (a.mode != 0) { o[16 + i] = 0.f; continue; }
     int hd = i / QC, r = i % QC, j = r / C, c = r % C;
     unsigned long long key = a.keys[hd * QMAX + j];
     long p = (long)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
@@ -480,7 +492,7 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass2_kernel(Hea
   float* sL1 = (float*)(sI0 + 256);          // [256] its right-tap weight
   const int tid = threadIdx.x;
   const int b = blockIdx.x / g.H, y = blockIdx.x % g.H;
-  for (int i = tid; i < QC; i += 256) { sT[i] = a.T1[i]; sT[QC + i] = a.T2[i]; }
+  for (int i = tid; i < QC; i += 256) { sT[i] = a.mode == 0 ? a.T1[i] : 0.f; sT[QC + i] = a.mode == 0 ? a.T2[i] : 0.f; }
   for (int i = tid; i < 2 * g.w * Q; i += 256) sAcc[i] = 0.f;
   const float* o = a.hout;
   const float Np = o[6], Nk1 = o[7], Nk2 = o[8], Ny = o[9];
@@ -503,9 +515,9 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass2_kernel(Hea
         sI0[tid] = live ? i0 : -100;
         sL1[tid] = fx - (float)i0;
       }
-      float fm;
-      int fa;
-      interp_argmax<QM>(a.fixp, g.ldf, C, tp, fm, fa);
+      float fm = 0.f;
+      int fa = 0;
+      if (a.mode == 0) interp_argmax<QM>(a.fixp, g.ldf, C, tp, fm, fa);
       asm volatile("" ::: "memory");
       int conf = (fm > a.th_high) ? fa : 255;
       if (fm < a.th_low) conf = C;
@@ -517,8 +529,14 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass2_kernel(Hea
       eval_head<QM>(v1, Q, C, a.th_high, e1);
       if (conf == C) conf = (e2.arg >= C) ? e2.arg : 255;
       long long lab = live ? a.label[((long)b * g.H + y) * g.W + x] : 255;
-      const bool lab_ok = live && lab >= 0 && lab != 255 && lab < C;
+      bool lab_ok = live && lab >= 0 && lab != 255 && lab < C;
       const int labi = lab_ok ? (int)lab : 0;
+      if (a.mode == 1) {
+        conf = lab_ok ? labi : 255;
+        e1.pseudo1 = 255;
+        e2.pseudo1 = 255;
+        lab_ok = false;
+      }
       const float inv1 = 1.0f / e1.sum, inv2 = 1.0f / e2.sum;
       float r1 = 0.f, r2 = 0.f;
       if (lab_ok) {
@@ -649,7 +667,8 @@ static size_t pass2_lds(int Q, int C, int w) {
 }
 
 static int fill_args(const simt_head_desc* d, HeadArgs& a) {
-  SIMT_CHECK(d && d->pred1 && d->pred2 && d->fixp && d->label && d->T1 && d->T2 && d->part && d->keys && d->hout);
+  SIMT_CHECK(d && d->pred1 && d->pred2 && d->label && d->part && d->keys && d->hout);
+  SIMT_CHECK(d->mode == 1 || (d->fixp && d->T1 && d->T2));
   SIMT_CHECK(d->Q <= QMAX && d->C < d->Q + 1 && d->C >= 1 && d->Q <= 64);
   SIMT_CHECK(d->ldp % 4 == 0 && d->ldf % 4 == 0 && d->ldp >= ((d->Q + 3) / 4) * 4 && d->ldf >= ((d->C + 3) / 4) * 4);
   SIMT_CHECK((long)d->B * d->H * d->W < 0xFFFFFFFFl);
@@ -662,6 +681,8 @@ static int fill_args(const simt_head_desc* d, HeadArgs& a) {
   a.th_high = d->th_high; a.th_low = d->th_low; a.lambda_seg = d->lambda_seg; a.lambda_place = d->lambda_place;
   a.part = d->part; a.keys = (unsigned long long*)d->keys; a.hout = d->hout; a.g1 = d->g1; a.QP = d->QP;
   a.gscale = d->gscale;
+  a.mode = d->mode;
+  SIMT_CHECK(d->mode == 0 || d->mode == 1);
   return SIMT_OK;
 }
 

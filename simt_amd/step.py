@@ -144,8 +144,8 @@ class SimTTrainer:
             self.reducer = BucketReducer(self.plan.flat_grad, buckets, group=self.pg, extra=[self._ntm_grad_flat])
 
     # ------------------------------------------------------------------ optimiser plumbing
-    def _build_sgd(self):
-        g0, g1 = optim_listing(self.plan.grads.keys())
+    def _build_sgd(self, roots=("layer3", "layer4")):
+        g0, g1 = optim_listing(self.plan.grads.keys(), layers_root=roots)
         recs = []
         self.mom = {}
         for group, listing in ((0, g0), (1, g1)):
@@ -229,3 +229,77 @@ class SimTTrainer:
         v = self.lout.cpu().tolist()
         keys = ["total", "loss_p1", "loss_p2", "loss_y1", "loss_y2", "place", "convex", "volume", "anchor", "vol_ok"]
         return dict(zip(keys, v))
+
+
+class WarmupTrainer:
+    """The warm-up stage of the reference (tools/trainV1_warmup.py:156-256) on gfx950: DeeplabMulti(num_classes) without
+    open-set heads, loss = CE(up(pred2), label) + lambda_seg * CE(up(pred1), label) with ignore_index 255 (:217-224), SGD over
+    conv1 ... layer4 with the duplicate listings of `optim_parameters(args, warmup=True)` + heads at 10x lr (:192-193).
+    Same engine as SimTTrainer: TrunkPlan forward/backward, the fused head kernels in mode 1, simt_sgd_multi."""
+
+    def __init__(self, state, hp, B, H, W, *, dtype=torch.bfloat16, device="cuda:0", process_group=None, layers=None):
+        self.hp, self.B, self.H, self.W, self.dtype = hp, B, H, W, dtype
+        dev = self.dev = torch.device(device)
+        self.pg = process_group
+        Cn = self.C = hp.num_classes
+        f32 = torch.float32
+        self.params = {k: v.detach().to(dev, f32 if v.dtype != torch.long else torch.long).clone() for k, v in state.items()}
+        kw = {"layers": layers} if layers is not None else {}
+        self.plan = TrunkPlan(self.params, B, H, W, multi_heads(Cn, 0, False), dtype=dtype, train=True, **kw)
+        h, w = self.plan.heads[1].h, self.plan.heads[1].w
+        lib = L.load()
+        self.part = torch.zeros(lib.simt_head_nblk(B, H, W), lib.simt_head_part_floats(Cn, Cn), device=dev)
+        self.keys = torch.zeros(lib.simt_head_keys_count(), device=dev, dtype=torch.int64)
+        self.hout = torch.zeros(lib.simt_head_hout_floats(Cn, Cn), device=dev)
+        self.QP = ops.round_up(Cn, 8)
+        self.g1 = torch.zeros(2, B, H, w, self.QP, device=dev)
+        self.label = torch.zeros(B, H, W, device=dev, dtype=torch.int64)
+        hd = L.HeadDesc()
+        d1, d2 = self.plan.dlogits["x1"], self.plan.dlogits["x2"]
+        hd.pred1, hd.pred2, hd.fixp, hd.label = self.plan.out["x1"].data_ptr(), self.plan.out["x2"].data_ptr(), None, self.label.data_ptr()
+        hd.T1, hd.T2 = None, None
+        hd.part, hd.keys, hd.hout, hd.g1 = self.part.data_ptr(), self.keys.data_ptr(), self.hout.data_ptr(), self.g1.data_ptr()
+        hd.dpred1_f32, hd.dpred2_f32, hd.dpred1_t, hd.dpred2_t = None, None, d1.data_ptr(), d2.data_ptr()
+        hd.B, hd.h, hd.w, hd.H, hd.W, hd.C, hd.Q = B, h, w, H, W, Cn, Cn
+        hd.ldp, hd.ldf, hd.QP, hd.ld_f32, hd.ld_t = self.plan.ldp["x1"], self.plan.ldp["x1"], self.QP, 0, d1.shape[1]
+        hd.grad_dtype = ops.dt_code(dtype)
+        hd.th_high, hd.th_low, hd.lambda_seg, hd.lambda_place, hd.gscale = 2.0, -1.0, hp.lambda_seg, 0.0, 1.0
+        hd.mode = 1
+        self.head_desc = hd
+        SimTTrainer._build_sgd(self, roots=("conv1", "layer1", "layer2", "layer3", "layer4"))
+        self.it_done = 0
+        self.reducer = None
+        if self.pg is not None:
+            from .dp import BucketReducer, make_buckets
+            sizes = {n: k for n, (_o, k) in self.plan.grad_offsets.items()}
+            buckets = make_buckets(self.plan.grad_order, sizes, self.plan.grad_ready, bucket_elems=8 << 20)
+            self.reducer = BucketReducer(self.plan.flat_grad, buckets, group=self.pg)
+
+    def step(self, image, label, it=None):
+        hp = self.hp
+        it = self.it_done if it is None else it
+        lr = lr_poly(hp.lr, it, hp.num_steps, hp.power)
+        st = ops.stream_ptr()
+        self.plan.x_in.copy_(image, non_blocking=True)
+        self.label.copy_(label, non_blocking=True)
+        self.plan.forward()
+        L.call("simt_head_loss", C.byref(self.head_desc), st)
+        L.call("simt_head_grad", C.byref(self.head_desc), st)
+        if self.reducer is not None:
+            self.reducer.start()
+            self.plan.backward(hook=self.reducer.ready_upto)
+            self.reducer.finish()
+        else:
+            self.plan.backward()
+        d = self.sgd_desc
+        d.lr[0], d.lr[1] = lr, lr * 10.0
+        d.wd[0], d.wd[1] = hp.weight_decay, hp.weight_decay
+        d.first_step = 1 if self.it_done == 0 else 0
+        L.call("simt_sgd_multi", C.byref(d), st)
+        self.plan.repack()
+        self.it_done += 1
+        return self.hout
+
+    def losses(self):
+        v = self.hout[:16].cpu().tolist()
+        return {"total": v[14], "loss_seg1": v[0], "loss_seg2": v[1]}

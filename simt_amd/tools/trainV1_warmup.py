@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Warm-up stage on MI355X: the reference's tools/trainV1_warmup.py (plain CE on both heads, SGD over the whole net)
+driven by `WarmupTrainer` (simt_amd/step.py).  Same flag names as the reference for everything that matters
+(trainV1_warmup.py:60-150); data: synthetic Cityscapes-shaped batches unless a loader is plugged into `batches()`.
+
+    python -m simt_amd.tools.trainV1_warmup --learning-rate 2.5e-4 --input-size-target 1024,512 --num-steps-stop 40000
+"""
+import argparse
+import os
+import os.path as osp
+import time
+
+import torch
+
+from simt_amd import model_spec as ms
+from simt_amd.step import Hyper, WarmupTrainer, lr_poly
+from simt_amd.tools.trainV2_simt import restore
+
+
+def get_arguments(argv=None):
+    p = argparse.ArgumentParser(description="DeepLab-ResNet warm-up on MI355X")
+    p.add_argument("--batch-size", type=int, default=1)
+    p.add_argument("--iter-size", type=int, default=1)
+    p.add_argument("--input-size-target", type=str, default="1024,512")
+    p.add_argument("--learning-rate", type=float, default=2.5e-4)
+    p.add_argument("--lambda-seg", type=float, default=0.1)
+    p.add_argument("--momentum", type=float, default=0.9)
+    p.add_argument("--num-classes", type=int, default=19)
+    p.add_argument("--num-steps", type=int, default=250000)
+    p.add_argument("--num-steps-stop", type=int, default=40000)
+    p.add_argument("--power", type=float, default=0.9)
+    p.add_argument("--random-seed", type=int, default=1234)
+    p.add_argument("--restore-from", type=str, default="../snapshots/resnet_pretrain.pth")
+    p.add_argument("--save-pred-every", type=int, default=1000)
+    p.add_argument("--snapshot-dir", type=str, default="../snapshots/warmup/")
+    p.add_argument("--weight-decay", type=float, default=0.0005)
+    p.add_argument("--gpu", type=int, default=0)
+    p.add_argument("--compute-dtype", choices=["bf16", "f32"], default="bf16")
+    p.add_argument("--print-every", type=int, default=100)
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = get_arguments(argv)
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(args.gpu)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("trainV1_warmup needs a GPU: no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+    w, h = map(int, args.input_size_target.split(","))
+    state = ms.reference_init(ms.state_shapes(args.num_classes, 0, False), seed=args.random_seed)
+    n = restore(state, args.restore_from)
+    hp = Hyper(num_classes=args.num_classes, open_classes=0, lambda_seg=args.lambda_seg, lr=args.learning_rate,
+               momentum=args.momentum, weight_decay=args.weight_decay, power=args.power, num_steps=args.num_steps)
+    dtype = torch.bfloat16 if args.compute_dtype == "bf16" else torch.float32
+    tr = WarmupTrainer(state, hp, args.batch_size, h, w, dtype=dtype, device=dev, process_group=pg)
+    cd = ms.load_class_dist("bapa")
+    if rank == 0:
+        print(f"restored {n} tensors; {world} GPU(s), batch {args.batch_size}/GPU, {h}x{w}, {args.compute_dtype}")
+        os.makedirs(args.snapshot_dir, exist_ok=True)
+    t0 = time.time()
+    for i_iter in range(args.num_steps):
+        img, lab = ms.synthetic_batch(args.batch_size, h, w, cd, seed=args.random_seed + 1000 * rank + i_iter, device=dev)
+        tr.step(img, lab, i_iter)
+        if i_iter % args.print_every == 0 and rank == 0:
+            l = tr.losses()
+            print("iter = {0:8d}/{1:8d}, loss_seg1 = {2:.3f} loss_seg2 = {3:.3f}  lr = {4:.2e}  ({5:.1f} img/s)".format(
+                i_iter, args.num_steps, l["loss_seg1"], l["loss_seg2"], lr_poly(args.learning_rate, i_iter, args.num_steps, args.power),
+                args.batch_size * world * (i_iter + 1) / max(time.time() - t0, 1e-9)))
+        if i_iter >= args.num_steps_stop - 1:
+            if rank == 0:
+                torch.save({k: v.detach().cpu() for k, v in tr.params.items()},
+                           osp.join(args.snapshot_dir, "GTA5_" + str(args.num_steps_stop) + ".pth"))
+            break
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -147,3 +147,37 @@ def test_dp_hooked_backward_world1_equals_plain(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_g11_warmup_stage_vs_reference_golden(dev):
+    """Warm-up stage (tools/trainV1_warmup.py): two iterations of WarmupTrainer (fp32) against the
+    reference's own run (tests/golden/g11_warmup.npz, small trunk).  Iteration 0: losses 1e-4 relative, sampled parameters
+    after the duplicate-listing SGD 5e-6.  Iteration 1 runs on parameters that already went through one SGD step; there
+    the reference's fp32 CPU path itself sits 1.9e-4 (conv1.weight) / 1.9e-3 (total loss) from the same computation in
+    float64, so the bar is the float64 oracle: |gpu - f64| <= 3 * |reference fp32 - f64| + eps (measured: the GPU
+    reproduces the float64 loss to 7 digits)."""
+    from simt_amd.step import WarmupTrainer
+    d = np.load(os.path.join(G, "g11_warmup.npz"))
+    layers = tuple(int(x) for x in d["layers"])
+    st = so.recipe_state(so.state_shapes(19, 0, False, layers=layers), seed=77, head_scale=8.0)
+    tr = WarmupTrainer(st, Hyper(open_classes=0, lr=2.5e-4), 2, 97, 97, dtype=torch.float32, device=dev, layers=layers)
+    truth = so.OracleWarmupTrainer(st, so.Hyper(open_classes=0, lr=2.5e-4), layers=layers, dtype=torch.float64)
+    keys = [str(k) for k in d["sample_keys"]]
+    for it in range(2):
+        img, lab = so.synthetic_batch(2, 97, 97, CD.numpy(), seed=int(d["seeds"][it]), block=8)
+        tr.step(img.to(dev), lab.to(dev), it)
+        o64 = truth.step(img, lab, it)
+        l = tr.losses()
+        got = np.array([l["total"], l["loss_seg1"], l["loss_seg2"]])
+        gold = d["losses"][it]
+        t64 = np.array([float(o64["total"]), float(o64["loss_seg1"]), float(o64["loss_seg2"])])
+        if it == 0:
+            np.testing.assert_allclose(got, gold, rtol=1e-4)
+        assert np.all(np.abs(got - t64) <= 3 * np.abs(gold - t64) + 1e-4 * np.abs(t64)), f"it {it}: gpu {got} f64 {t64} ref {gold}"
+        for i, k in enumerate(keys):
+            v = tr.params[k].detach().flatten()[:64].cpu().numpy()
+            ref = d["param_samples"][it][i][: len(v)]
+            p64 = truth.st[k].detach().flatten()[:64].numpy()
+            if it == 0:
+                np.testing.assert_allclose(v, ref, rtol=0, atol=5e-6, err_msg=f"{k} it {it}")
+            assert np.abs(v - p64).max() <= 3 * np.abs(ref - p64).max() + 5e-6, f"{k} it {it}"

@@ -241,3 +241,25 @@ def test_optim_listing_multiplicity():
     assert len(g0) == 726 and len(set(g0)) == 240                  # SURVEY quirk 4 (probe numbers)
     assert g0.count("layer3.0.conv1.weight") == 3 and g0.count("layer3.0.downsample.0.weight") == 4
     assert len(g1) == 32
+
+
+def test_g11_warmup_stage_two_iterations():
+    """Warm-up stage (tools/trainV1_warmup.py): the oracle's restatement against the reference's own run
+    (oracle/gen_golden_v1.py; small trunk, two iterations incl. SGD with warmup=True duplicate listings)."""
+    d = L("g11_warmup")
+    layers = tuple(int(x) for x in d["layers"])
+    shapes = so.state_shapes(19, 0, False, layers=layers)
+    g0, g1 = so.optim_param_names(shapes, warmup=True, openset=False)
+    assert [len(g0), len(set(g0)), len(g1)] == [int(x) for x in d["n_listed"]]
+    st = so.recipe_state(shapes, seed=77, head_scale=8.0)
+    hp = so.Hyper(open_classes=0, lr=2.5e-4)
+    tr = so.OracleWarmupTrainer(st, hp, layers=layers)
+    keys = [str(k) for k in d["sample_keys"]]
+    for it in range(2):
+        img, lab = so.synthetic_batch(2, 97, 97, CD.numpy(), seed=int(d["seeds"][it]), block=8)
+        out = tr.step(img, lab, it)
+        np.testing.assert_allclose([float(out["total"]), float(out["loss_seg1"]), float(out["loss_seg2"])], d["losses"][it],
+                                   rtol=2e-5)
+        for i, k in enumerate(keys):
+            v = tr.st[k].detach().flatten()[:64].numpy()
+            np.testing.assert_allclose(v, d["param_samples"][it][i][: len(v)], rtol=0, atol=2e-6, err_msg=f"{k} it {it}")
