@@ -83,12 +83,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)       # (several ranks share a device only in the gloo functional test below)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("SIMT_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI; "gloo" only for functional tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         pg = dist.group.WORLD
     from simt_amd import model_spec as ms
     from simt_amd.step import Hyper, SimTTrainer
@@ -105,9 +111,13 @@ def main():
     img, lab = ms.synthetic_batch(a.batch, H, W, cd, seed=1234 + rank, device=dev)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             import torch.distributed as dist
-            dist.barrier()
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
