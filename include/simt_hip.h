@@ -46,6 +46,9 @@ typedef struct {
   int32_t ldy, ldr, stride, ntaps, relu;
   int32_t dtype_in, dtype_out, tile_n; /* tile_n in {128,64,32}; bf16 -> bf16 also 256 */
   int16_t dy[SIMT_MAX_TAPS], dx[SIMT_MAX_TAPS];
+  const void* mask;    /* [B*Ho*Wo][ldm] dtype_in or NULL: the result is zeroed where mask <= 0 (ReLU backward of the layer
+                        * whose output this gradient belongs to; used by the BN-free VGG trunk, model/deeplab_vgg.py) */
+  int32_t ldm;
 } simt_conv_desc;
 int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);
 /* which kernel instantiation simt_conv_fprop runs for d: returns 0 (conv_igemm_kernel) or 2 (conv_igemm2_kernel<bn,tm,nst>) */
@@ -129,6 +132,12 @@ int simt_maxpool_bwd(const void* dp, const unsigned char* idx, void* da, int B, 
 int simt_scatter_stride(const void* src, void* dx, int B, int H, int W, int C, int Ho, int Wo, int stride, int dtype,
                         simt_stream_t stream);
 int simt_colsum(const void* src, float* out, long M, int ld, int C, int accumulate, int dtype, simt_stream_t stream);
+/* VGG trunk (model/deeplab_vgg.py:24-43): MaxPool2d(2,2) forward (+ arg-max bytes) and its backward fused with the ReLU
+ * mask of the conv output y it pooled; bias gradients of wide layers (C <= 2048) */
+int simt_maxpool2(const void* y, void* p, unsigned char* idx, int B, int H, int W, int C, int dtype, simt_stream_t stream);
+int simt_maxpool2_bwd(const void* dp, const unsigned char* idx, const void* y, void* da, int B, int H, int W, int C, int dtype,
+                      simt_stream_t stream);
+int simt_colsum_wide(const void* src, float* out, long M, int ld, int C, int dtype, simt_stream_t stream);
 
 /* ---- fused SimT head: upsample + softmax + per-pixel loss terms + anchors (tools/trainV2_simt.py:351-409,
  * :202-230 Placeholder_loss, utils/loss.py:14-40) ------------------------------------------------------- */

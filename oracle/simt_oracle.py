@@ -540,3 +540,17 @@ class OracleWarmupTrainer:
                 sgd_step_(ps, gs, bs, ms, lr * g["lr_mult"], hp.weight_decay, hp.momentum, self.first)
             self.first = False
         return {"total": total.detach(), "loss_seg1": l1.detach(), "loss_seg2": l2.detach()}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# DeepLab-VGG16 (model/deeplab_vgg.py:24-51).  PARITY UNPINNED: the reference file is Python-2-only and needs torchvision
+# (absent), no reference test or script exercises it; restated from the file + torchvision's public vgg16 layer list.
+# ------------------------------------------------------------------------------------------------------------
+def vgg_forward(st, x, layers):
+    """layers: [(features index, cin, cout, dilation, pool_after)]; every conv is 3x3, pad = dilation, bias + ReLU;
+    MaxPool2d(2, 2); then the 2-branch classifier (dilations 6, 12; the early `return` of :17-21)."""
+    for (idx, _cin, _cout, dil, pool) in layers:
+        x = F.relu(F.conv2d(x, st[f"features.{idx}.weight"], st[f"features.{idx}.bias"], padding=dil, dilation=dil))
+        if pool:
+            x = F.max_pool2d(x, 2, 2)
+    return _aspp(st, "classifier", x, 2)

@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
                 ("B", i32), ("H", i32), ("W", i32), ("Cin", i32), ("Ho", i32), ("Wo", i32), ("Cout", i32),
                 ("Npad", i32), ("Nstore", i32), ("ldy", i32), ("ldr", i32), ("stride", i32), ("ntaps", i32),
                 ("relu", i32), ("dtype_in", i32), ("dtype_out", i32), ("tile_n", i32),
-                ("dy", C.c_int16 * MAX_TAPS), ("dx", C.c_int16 * MAX_TAPS)]
+                ("dy", C.c_int16 * MAX_TAPS), ("dx", C.c_int16 * MAX_TAPS), ("mask", c_p), ("ldm", i32)]
 
 
 class WgradDesc(C.Structure):
@@ -96,6 +96,9 @@ SIGNATURES = {
     "simt_maxpool_bwd": (_I, [c_p, c_p, c_p, _I, _I, _I, _I, _I, _I, _I, c_p]),
     "simt_scatter_stride": (_I, [c_p, c_p, _I, _I, _I, _I, _I, _I, _I, _I, c_p]),
     "simt_colsum": (_I, [c_p, c_p, _L, _I, _I, _I, _I, c_p]),
+    "simt_maxpool2": (_I, [c_p, c_p, c_p, _I, _I, _I, _I, _I, c_p]),
+    "simt_maxpool2_bwd": (_I, [c_p, c_p, c_p, c_p, _I, _I, _I, _I, _I, c_p]),
+    "simt_colsum_wide": (_I, [c_p, c_p, _L, _I, _I, _I, c_p]),
     "simt_head_nblk": (_I, [_I, _I, _I]),
     "simt_head_part_floats": (_I, [_I, _I]),
     "simt_head_hout_floats": (_I, [_I, _I]),

@@ -679,3 +679,139 @@ extern "C" int simt_colsum(const void* src, float* out, long M, int ld, int C, i
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// VGG trunk pieces (model/deeplab_vgg.py:24-43 -> torchvision vgg16.features): MaxPool2d(2, 2) (floor mode) forward with a
+// 2-bit arg-max index, and its backward fused with the ReLU mask of the conv output it follows.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool2_kernel(const T* y, T* p, unsigned char* idx, int B, int H, int W, int C, int Hp, int Wp, long nvec) {
+  const int vpr = C >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % vpr) << 3;
+    long m = i / vpr;
+    int px = (int)(m % Wp);
+    long t = m / Wp;
+    int py = (int)(t % Hp);
+    int b = (int)(t / Hp);
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[8];
+        load8(y + (((long)b * H + py * 2 + r) * W + px * 2 + s) * C + c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if ((r == 0 && s == 0) || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = r * 2 + s; }
+      }
+    store8(p + i * 8, best);
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) packed |= (unsigned long long)bi[e] << (8 * e);
+    *(unsigned long long*)(idx + i * 8) = packed;
+  }
+}
+
+// da[b,iy,ix,c] = (y > 0) ? dp[b,iy/2,ix/2,c] if idx says (iy&1, ix&1) was the max : 0 ; pixels outside the pooled area -> 0
+template <typename T>
+__global__ void maxpool2_bwd_kernel(const T* dp, const unsigned char* idx, const T* y, T* da, int B, int H, int W, int C, int Hp,
+                                    int Wp, long nvec) {
+  const int vpr = C >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % vpr) << 3;
+    long m = i / vpr;
+    int ix = (int)(m % W);
+    long t = m / W;
+    int iy = (int)(t % H);
+    int b = (int)(t / H);
+    float out[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = 0.f;
+    const int py = iy >> 1, px = ix >> 1;
+    if (py < Hp && px < Wp) {
+      long o = (((long)b * Hp + py) * Wp + px) * C + c;
+      unsigned long long packed = *(const unsigned long long*)(idx + o);
+      float g[8], yv[8];
+      load8(dp + o, g);
+      load8(y + i * 8, yv);
+      const int want = (iy & 1) * 2 + (ix & 1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if ((int)((packed >> (8 * e)) & 0xff) == want && (!y || yv[e] > 0.f)) out[e] = g[e];
+    }
+    store8(da + i * 8, out);
+  }
+}
+
+extern "C" int simt_maxpool2(const void* y, void* p, unsigned char* idx, int B, int H, int W, int C, int dtype, simt_stream_t stream) {
+  SIMT_CHECK(y && p && idx && C % 8 == 0);
+  const int Hp = H / 2, Wp = W / 2;
+  long nvec = (long)B * Hp * Wp * (C / 8);
+  if (dtype == SIMT_BF16)
+    hipLaunchKernelGGL(maxpool2_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (bf16_t*)p,
+                       idx, B, H, W, C, Hp, Wp, nvec);
+  else
+    hipLaunchKernelGGL(maxpool2_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)y, (float*)p, idx,
+                       B, H, W, C, Hp, Wp, nvec);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+extern "C" int simt_maxpool2_bwd(const void* dp, const unsigned char* idx, const void* y, void* da, int B, int H, int W, int C, int dtype,
+                                 simt_stream_t stream) {
+  SIMT_CHECK(dp && idx && y && da && C % 8 == 0);
+  const int Hp = H / 2, Wp = W / 2;
+  long nvec = (long)B * H * W * (C / 8);
+  if (dtype == SIMT_BF16)
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dp, idx,
+                       (const bf16_t*)y, (bf16_t*)da, B, H, W, C, Hp, Wp, nvec);
+  else
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)dp, idx,
+                       (const float*)y, (float*)da, B, H, W, C, Hp, Wp, nvec);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+// Bias gradients of wide layers: out[c] = sum_m src[m*ld + c], c < C (any C multiple of 8).  Two deterministic stages:
+// COLSUMW_G row ranges -> scratch [G][C], then a fixed-order combine.
+#define COLSUMW_G 64
+#define COLSUMW_MAXC 2048
+__device__ float g_colsumw_ws[COLSUMW_G * COLSUMW_MAXC];
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_wide_partial_kernel(const T* src, long M, int ld, int C) {
+  // grid (G, ceil(C/64)); block: 64 channels x 4 row lanes
+  __shared__ float red[4][64];
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), lr = threadIdx.x >> 6;
+  long rows = (M + COLSUMW_G - 1) / COLSUMW_G;
+  long m0 = (long)blockIdx.x * rows, m1 = m0 + rows;
+  if (m1 > M) m1 = M;
+  float s = 0.f;
+  if (c < C)
+    for (long m = m0 + lr; m < m1; m += 4) s += Elem<T>::ld(src + m * ld + c);
+  red[lr][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (lr == 0 && c < C) g_colsumw_ws[(long)blockIdx.x * COLSUMW_MAXC + c] = (red[0][c & 63] + red[1][c & 63]) + (red[2][c & 63] + red[3][c & 63]);
+}
+__global__ void colsum_wide_final_kernel(float* out, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double t = 0.0;
+  for (int b = 0; b < COLSUMW_G; ++b) t += (double)g_colsumw_ws[(long)b * COLSUMW_MAXC + c];
+  out[c] = (float)t;
+}
+extern "C" int simt_colsum_wide(const void* src, float* out, long M, int ld, int C, int dtype, simt_stream_t stream) {
+  SIMT_CHECK(src && out && C > 0 && C <= COLSUMW_MAXC);
+  dim3 grid(COLSUMW_G, (C + 63) / 64);
+  if (dtype == SIMT_BF16)
+    hipLaunchKernelGGL(colsum_wide_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, M, ld, C);
+  else
+    hipLaunchKernelGGL(colsum_wide_partial_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, M, ld, C);
+  SIMT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_wide_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, C);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}

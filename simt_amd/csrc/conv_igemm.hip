@@ -38,6 +38,8 @@ struct ConvKArgs {
   const void* res;
   float* stats;
   const char* zero;
+  const void* mask;
+  int ldm;
   int B, H, W, Cin, Ho, Wo, Cout, Nstore, ldy, ldr, stride, ntaps, relu, M;
   int kc_per_tap;  // Cin*sizeof(T)/128
   int ntiles_n, ntiles_m;
@@ -242,6 +244,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
       }
+      if (a.mask) {
+        float mv[8];
+        load8((const T*)a.mask + (long)m * a.ldm + n, mv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+      }
       store8((TO*)a.y + (long)m * a.ldy + n, v);
     }
   }
@@ -271,16 +279,17 @@ extern "C" int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream) {
   const int esz = d->dtype_in == SIMT_BF16 ? 2 : 4;
   SIMT_CHECK((d->Cin * esz) % 128 == 0);          // K-stage = 128 B of one tap
   const bool v2 = d->dtype_in == SIMT_BF16 && d->tile_n >= 64 &&
-                  (d->dtype_out == SIMT_BF16 || (!d->bias && !d->res && !d->relu && !d->stats && d->tile_n == 256));
+                  (d->dtype_out == SIMT_BF16 || (!d->bias && !d->res && !d->relu && !d->stats && !d->mask && d->tile_n == 256));
   SIMT_CHECK(d->tile_n == 128 || d->tile_n == 64 || d->tile_n == 32 || (v2 && d->tile_n == 256));
   SIMT_CHECK(d->Npad % d->tile_n == 0 && d->Npad >= d->Cout);
   SIMT_CHECK(d->Nstore % 8 == 0 && d->Nstore <= d->Npad && d->Nstore <= d->ldy);
-  SIMT_CHECK(d->ldy % 8 == 0 && (!d->res || d->ldr % 8 == 0));
+  SIMT_CHECK(d->ldy % 8 == 0 && (!d->res || d->ldr % 8 == 0) && (!d->mask || d->ldm % 8 == 0));
   SIMT_CHECK(!(d->dtype_in == SIMT_F32 && d->dtype_out == SIMT_BF16));
   if (v2) return simt_conv_fprop_bf16_v2(d, stream);
   ConvKArgs k;
   k.x = (const char*)d->x; k.w = (const char*)d->w; k.y = d->y; k.bias = d->bias; k.res = d->res;
   k.stats = d->stats; k.zero = (const char*)simt_zero_page();
+  k.mask = d->mask; k.ldm = d->ldm;
   k.B = d->B; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
   k.Nstore = d->Nstore; k.ldy = d->ldy; k.ldr = d->ldr; k.stride = d->stride; k.ntaps = d->ntaps;
   k.relu = d->relu; k.M = d->B * d->Ho * d->Wo;

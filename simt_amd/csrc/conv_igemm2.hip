@@ -29,10 +29,11 @@ struct Conv2KArgs {
   bf16_t* y;
   const float* bias;
   const bf16_t* res;
+  const bf16_t* mask;
   float* stats;
   const char* zero;
   int H, W, Ho, Wo, Cout, Nstore, ldy, ldr, stride, ntaps, relu, M;
-  int kc_per_tap, pix_bytes, wrow_bytes;
+  int kc_per_tap, pix_bytes, wrow_bytes, ldm;
   int ntiles_n, ntiles_m;
   int out_f32;     // 1: y is fp32 and is stored straight from the accumulators (no bias/residual/ReLU/stats)
   int rows;        // pixels per tile (<= BM)
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
     float bias8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = (a.bias && (n + e) < a.Cout) ? a.bias[n + e] : 0.f;
-    const bool plain = !a.bias && !a.res && !a.relu;
+    const bool plain = !a.bias && !a.res && !a.relu && !a.mask;
     for (int r = rg; r < BM; r += RPP) {
       const int m = m0 + r;
       if (m >= m_end) break;
@@ -301,6 +302,12 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
           if (a.relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          if (a.mask) {
+            float mv[8];
+            load8(a.mask + (long)m * a.ldm + n, mv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
           }
           store8(a.y + (long)m * a.ldy + n, v);
           continue;
@@ -408,7 +415,7 @@ static Conv2Variant pick_variant(const simt_conv_desc* d) {
 // otherwise conv_igemm2_kernel<bn, tm, nst>.
 extern "C" int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int* nst) {
   const bool v2 = d->dtype_in == SIMT_BF16 && d->tile_n >= 64 &&
-                  (d->dtype_out == SIMT_BF16 || (!d->bias && !d->res && !d->relu && !d->stats && d->tile_n == 256));
+                  (d->dtype_out == SIMT_BF16 || (!d->bias && !d->res && !d->relu && !d->stats && !d->mask && d->tile_n == 256));
   if (!v2) { *bn = d->tile_n; *tm = 0; *nst = 2; return 0; }
   const Conv2Variant v = pick_variant(d);
   *bn = v.tile_n; *tm = v.tm; *nst = v.nst;
@@ -420,6 +427,7 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
   Conv2KArgs k;
   k.x = (const char*)d->x; k.w = (const char*)d->w; k.y = (bf16_t*)d->y; k.bias = d->bias; k.res = (const bf16_t*)d->res;
   k.stats = d->stats; k.zero = (const char*)simt_zero_page();
+  k.mask = (const bf16_t*)d->mask; k.ldm = d->ldm;
   k.out_f32 = d->dtype_out == SIMT_F32;
   if (k.out_f32) SIMT_CHECK(!d->bias && !d->res && !d->relu && !d->stats && d->Nstore % 4 == 0 && d->ldy % 4 == 0);
   k.H = d->H; k.W = d->W; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout; k.Nstore = d->Nstore; k.ldy = d->ldy; k.ldr = d->ldr;

@@ -295,13 +295,13 @@ class TrunkPlan:
 
     # ------------------------------------------------------------------ forward construction
     def _conv(self, lst, x, wp_info, y, *, Bn, Hi, Wi, Cin, Ho, Wo, Cout, taps, stride=1, bias=None, res=None, stats=None,
-              relu=False, ldy=None, Nstore=None, alg_k=None, alg_flops=None):
+              relu=False, ldy=None, Nstore=None, alg_k=None, alg_flops=None, mask=None):
         """alg_k: algorithmic reduction length per output element (defaults to ntaps*Cin; the K-padded head dgrad and
         the stem pass their true value) -> algorithmic FLOPs = 2 * M * Cout * alg_k."""
         wp, tile, npad = wp_info
         d = ops.make_conv_desc(x, wp, y, B=Bn, H=Hi, W=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, taps=taps, stride=stride,
                                bias=bias, res=res, stats=stats, relu=relu, Npad=npad, tile_n=tile, ldy=ldy,
-                               Nstore=Nstore)
+                               Nstore=Nstore, mask=mask)
         M = Bn * Ho * Wo
         k = alg_k if alg_k is not None else len(taps) * Cin
         tn = {torch.bfloat16: "bf16", torch.float32: "f32"}
@@ -774,7 +774,8 @@ class TrunkPlan:
                                        len(hd.taps) * hd.ck, hd.ck, 1, None, ops.dt_code(self.dtype))
                 row += cout
             self._conv(b, dl, (wt, tile, npad), dfeat, Bn=B, Hi=hd.h, Wi=hd.w, Cin=hd.ck, Ho=hd.h, Wo=hd.w, Cout=hd.cin,
-                       taps=[(-a, -c) for (a, c) in hd.taps], res=dz_prev, alg_k=len(hd.taps) * hd.Q)
+                       taps=[(-a, -c) for (a, c) in hd.taps], res=dz_prev, alg_k=len(hd.taps) * hd.Q,
+                       mask=getattr(hd, "mask", None))
             return dfeat
         # ---- tap-expanded backward: G[m'][t*QP+n] = dlogits[m' - d_t][n]; dW = G^T x feat; dfeat = G x Wt (+ dz_prev)
         nt, QP, nexp = len(hd.taps), hd.QP, hd.nexp
@@ -811,7 +812,7 @@ class TrunkPlan:
                                    None, ops.dt_code(self.dtype))
             row += cout
         self._conv(b, G, (wt, tile, npad), dfeat, Bn=B, Hi=hd.h, Wi=hd.w, Cin=kexp, Ho=hd.h, Wo=hd.w, Cout=hd.cin,
-                   taps=[(0, 0)], res=dz_prev, alg_k=nt * hd.Q)
+                   taps=[(0, 0)], res=dz_prev, alg_k=nt * hd.Q, mask=getattr(hd, "mask", None))
         return dfeat
 
     # ------------------------------------------------------------------ run

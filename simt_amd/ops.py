@@ -65,7 +65,7 @@ def packed_rows(cout, tile_n=None, dtype=None):
 
 
 def make_conv_desc(x, w, y, *, B, H, W, Cin, Ho, Wo, Cout, taps, stride=1, bias=None, res=None, stats=None, relu=False,
-                   Npad=None, Nstore=None, ldy=None, ldr=None, tile_n=None):
+                   Npad=None, Nstore=None, ldy=None, ldr=None, tile_n=None, mask=None, ldm=None):
     d = L.ConvDesc()
     tile_n = tile_n or pick_tile_n(Cout, x.dtype if x.dtype == y.dtype else None)
     d.x, d.w, d.y = _p(x), _p(w), _p(y)
@@ -78,6 +78,8 @@ def make_conv_desc(x, w, y, *, B, H, W, Cin, Ho, Wo, Cout, taps, stride=1, bias=
     d.stride, d.ntaps, d.relu = stride, len(taps), int(relu)
     d.dtype_in, d.dtype_out, d.tile_n = dt_code(x.dtype), dt_code(y.dtype), tile_n
     _fill_taps(d.dy, d.dx, taps)
+    d.mask = _p(mask)
+    d.ldm = ldm if ldm is not None else (mask.shape[-1] if mask is not None else 0)
     return d
 
 

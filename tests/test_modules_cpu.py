@@ -70,3 +70,17 @@ def test_modules_refuse_cpu():
         sig_NTM(19, 3)()
     with pytest.raises(AssertionError):
         CrossEntropy2d()(torch.zeros(1, 19, 4, 4), torch.zeros(1, 4, 4, dtype=torch.long))
+
+
+def test_deeplab_vgg_state_dict_keys_cpu():
+    from model.deeplab_vgg import DeeplabVGG
+    from simt_amd.engine_vgg import vgg_state_shapes
+    m = DeeplabVGG(num_classes=19)
+    sd = m.state_dict()
+    ref = vgg_state_shapes(19)
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(ref[k]), k
+    # torchvision vgg16.features with pool4/pool5 dropped: convs sit at these Sequential indices, fc6/fc7 at 29/31
+    assert [i for i, mod in enumerate(m.features) if isinstance(mod, torch.nn.Conv2d)] == [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 23, 25, 27, 29, 31]
+    assert m.features[23].dilation == (2, 2) and m.features[29].dilation == (4, 4) and m.features[29].out_channels == 1024
