@@ -167,8 +167,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
       if (kt + 1 < nk) wg_wait_vmcnt<6>(); else wg_wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      load_frags(buf);                                    // fragment reads first: their latency gates the MFMAs
       if (kt + 2 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
-      load_frags(buf);
       mma();
       buf = (buf + 1 == NST) ? 0 : buf + 1;
     }
