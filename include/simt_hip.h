@@ -118,6 +118,8 @@ typedef struct {
   void* gout;          /* [M][C] masked gradient (may alias dz) or NULL */
   int64_t M;
   int32_t C, mask_mode, dtype; /* mask_mode: 0 none, 1 z>0, 2 y*scale+shift>0 */
+  float *dgamma, *dbeta;   /* [C] or NULL: gradients of a TRAINABLE affine (model/deeplabv3.py's torchvision BatchNorm) */
+  float *dgamma2, *dbeta2; /* same for the second BN (y2) */
 } simt_bn_bwd_desc;
 int simt_bn_bwd_nblk(long M, int C);
 int simt_bn_bwd(const simt_bn_bwd_desc* d, simt_stream_t stream);
@@ -230,6 +232,12 @@ int simt_entropy2d(const float* x, int n, int c, int h, int w, void* ws, float* 
 int simt_upsample_sum_argmax(const float* la, int ha, int wa, int lda, const float* lb, int hb, int wb, int ldb, int B, int H,
                              int W, int C, int32_t* pred, simt_stream_t stream);
 int simt_confusion_hist(const int64_t* gt, const int32_t* pred, long P, int n, int64_t* hist, simt_stream_t stream);
+/* F.interpolate(bilinear) of an NHWC fp32 map [B][h][w][lds] (first C channels) to NCHW fp32 [B][C][H][W] and its adjoint
+ * (model/deeplabv3.py:137 upsamples inside the model with align_corners=False; align_corners=1 = interp_target) */
+int simt_upsample_nchw(const float* src, int B, int h, int w, int lds, int C, int H, int W, int align_corners, float* dst,
+                       simt_stream_t stream);
+int simt_upsample_nchw_bwd(const float* ddst, int B, int h, int w, int lds, int C, int H, int W, int align_corners,
+                           void* dsrc, int dtype, simt_stream_t stream); /* dsrc [B][h][w][lds] in dtype, first C channels */
 
 #ifdef __cplusplus
 }

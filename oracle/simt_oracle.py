@@ -554,3 +554,42 @@ def vgg_forward(st, x, layers):
         if pool:
             x = F.max_pool2d(x, 2, 2)
     return _aspp(st, "classifier", x, 2)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# DeepLabv3 (model/deeplabv3.py:9-138).  PARITY UNPINNED: the reference file imports torchvision (absent here) and no
+# reference script or test uses it; restated from the file + torchvision's public resnet50 definition (Bottleneck with
+# the stride on the 3x3 conv, a downsample branch in block 0 of every layer, MaxPool2d(3, 2, 1) in floor mode).
+# ------------------------------------------------------------------------------------------------------------
+def v3_forward(st, x, layers=(3, 4, 6), openset=False, train=True, acts=None):
+    """st: {state_dict key: tensor} (keys as model/deeplabv3.py builds them: resnet.resnet_50.*, assp.*, conv, conv_1).
+    acts: optional dict that receives every post-ReLU activation (tests compare ReLU masks with it)."""
+    def keep(name, t):
+        if acts is not None:
+            acts[name] = t.detach()
+        return t
+    r = "resnet.resnet_50."
+    H, W = x.shape[-2:]
+    x = F.relu(_bn(st, r + "bn1", F.conv2d(x, st[r + "conv1.weight"], stride=2, padding=3), train))       # :16
+    x = F.max_pool2d(x, 3, 2, 1)                                                                          # :17
+    for li, n in enumerate(layers):                                                                       # :18-20
+        for bi in range(n):
+            name = f"{r}layer{li + 1}.{bi}"
+            stride = 2 if (li > 0 and bi == 0) else 1
+            out = keep(name + ".a1", F.relu(_bn(st, name + ".bn1", F.conv2d(x, st[name + ".conv1.weight"]), train)))
+            out = keep(name + ".a2", F.relu(_bn(st, name + ".bn2", F.conv2d(out, st[name + ".conv2.weight"], stride=stride, padding=1),
+                                                train)))
+            out = _bn(st, name + ".bn3", F.conv2d(out, st[name + ".conv3.weight"]), train)
+            if bi == 0:
+                x = _bn(st, name + ".downsample.1", F.conv2d(x, st[name + ".downsample.0.weight"], stride=stride), train)
+            x = keep(name + ".z", F.relu(out + x))
+    br = []
+    for (i, k, d) in ((1, 1, 1), (2, 3, 6), (3, 3, 12), (4, 3, 18), (5, 1, 1)):                           # ASSP :82-102
+        y = F.conv2d(x, st[f"assp.conv{i}.weight"], padding=d if k == 3 else 0, dilation=d if k == 3 else 1)
+        br.append(keep(f"assp.a{i}", F.relu(_bn(st, f"assp.bn{i}", y, train))))
+    br[4] = F.interpolate(br[4], size=tuple(br[3].shape[-2:]), mode="bilinear")                           # :102 (identity)
+    x = keep("assp.af", F.relu(_bn(st, "assp.bnf", F.conv2d(torch.cat(br, 1), st["assp.convf.weight"]), train)))   # :104-107
+    y = F.conv2d(x, st["conv.weight"], st["conv.bias"])                                                   # :131
+    if openset:
+        y = torch.cat([y, F.conv2d(x, st["conv_1.weight"], st["conv_1.bias"])], 1)                        # :133-135
+    return F.interpolate(y, size=(H, W), mode="bilinear")                                                 # :137

@@ -37,7 +37,7 @@ class BnBwdDesc(C.Structure):
     _fields_ = [("dz", c_p), ("z", c_p), ("y", c_p), ("mean", c_p), ("rstd", c_p), ("scale", c_p), ("shift", c_p),
                 ("y2", c_p), ("mean2", c_p), ("rstd2", c_p), ("scale2", c_p), ("part", c_p), ("coef", c_p),
                 ("dy", c_p), ("dy2", c_p), ("gout", c_p), ("M", C.c_int64), ("C", i32), ("mask_mode", i32),
-                ("dtype", i32)]
+                ("dtype", i32), ("dgamma", c_p), ("dbeta", c_p), ("dgamma2", c_p), ("dbeta2", c_p)]
 
 
 class HeadDesc(C.Structure):
@@ -118,6 +118,8 @@ SIGNATURES = {
     "simt_wgrad_reduce_exp": (_I, [c_p, c_p, _I, _I, _I, _I, _I, _I, _I, _I, c_p]),
     "simt_upsample_sum_argmax": (_I, [c_p, _I, _I, _I, c_p, _I, _I, _I, _I, _I, _I, _I, c_p, c_p]),
     "simt_confusion_hist": (_I, [c_p, c_p, _L, _I, c_p, c_p]),
+    "simt_upsample_nchw": (_I, [c_p, _I, _I, _I, _I, _I, _I, _I, _I, c_p, c_p]),
+    "simt_upsample_nchw_bwd": (_I, [c_p, _I, _I, _I, _I, _I, _I, _I, _I, c_p, _I, c_p]),
     "simt_loss_ws_bytes": (_I, []),
     "simt_ce2d_fwd": (_I, [c_p, c_p, c_p, _I, _I, _I, _I, _I, _I, c_p, c_p, c_p]),
     "simt_ce2d_bwd": (_I, [c_p, c_p, c_p, _I, _I, _I, _I, _I, _I, c_p, c_p, c_p, c_p]),

@@ -220,7 +220,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dz, const T
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, long count, float* coef) {
+// dgamma / dbeta (trainable affine, e.g. torchvision's BatchNorm in model/deeplabv3.py): dbeta = sum g, dgamma = sum g*xhat
+// are exactly the two sums of the backward; written when the pointers are given (dgamma2: the second BN sharing g).
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, long count, float* coef,
+                                                             float* dgamma, float* dbeta, float* dgamma2, float* dbeta2) {
   __shared__ double red[32][8][3];
   double s[3];
   part_colsum8<3>(part, nblk, C, blockIdx.x * 8, s, red);
@@ -228,6 +231,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part,
   if ((threadIdx.x >> 3) != 0 || c >= C) return;
 #pragma unroll
   for (int j = 0; j < 3; ++j) coef[j * C + c] = (float)(s[j] / (double)count);
+  if (dbeta) dbeta[c] = (float)s[0];
+  if (dgamma) dgamma[c] = (float)s[1];
+  if (dbeta2) dbeta2[c] = (float)s[0];
+  if (dgamma2) dgamma2[c] = (float)s[2];
 }
 
 template <typename T>
@@ -310,7 +317,8 @@ extern "C" int simt_bn_bwd(const simt_bn_bwd_desc* d, simt_stream_t stream) {
                        (const float*)d->y2, d->mean2, d->rstd2, d->part, d->M, d->C, rpb, d->mask_mode);
   }
   SIMT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 7) / 8), dim3(256), 0, st, d->part, nblk, d->C, d->M, d->coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 7) / 8), dim3(256), 0, st, d->part, nblk, d->C, d->M, d->coef,
+                     d->dgamma, d->dbeta, d->dgamma2, d->dbeta2);
   SIMT_LAUNCH_CHECK();
   if (d->dtype == SIMT_BF16) {
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)d->dz,

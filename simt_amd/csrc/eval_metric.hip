@@ -104,3 +104,105 @@ extern "C" int simt_confusion_hist(const int64_t* gt, const int32_t* pred, long 
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
+
+// ---- F.interpolate(mode='bilinear') of NHWC low-res maps to an NCHW fp32 tensor and its adjoint.
+// model/deeplabv3.py:137 upsamples the logits INSIDE the model with the default align_corners=False
+// (src = (dst + 0.5) * in/out - 0.5, clamped at 0); align_corners=True is the interp_target flavour of trainV2_simt.py:301.
+struct UpArgs {
+  const float* src;   // [B][h][w][lds]
+  float* dst;         // [B][C][H][W]
+  int B, h, w, lds, C, H, W, align;
+  float sy, sx;
+};
+__device__ __forceinline__ void up_taps(int d, int in, float scale, int align, int& i0, int& i1, float& l0, float& l1) {
+  float f = align ? scale * (float)d : fmaxf(((float)d + 0.5f) * scale - 0.5f, 0.f);
+  i0 = (int)f;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = f - (float)i0;
+  l0 = 1.f - l1;
+}
+__global__ __launch_bounds__(256) void upsample_nchw_kernel(UpArgs a) {
+  const long total = (long)a.B * a.C * a.H * a.W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % a.W);
+    long t = i / a.W;
+    const int y = (int)(t % a.H); t /= a.H;
+    const int c = (int)(t % a.C);
+    const int b = (int)(t / a.C);
+    int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+    up_taps(y, a.h, a.sy, a.align, y0, y1, wy0, wy1);
+    up_taps(x, a.w, a.sx, a.align, x0, x1, wx0, wx1);
+    const float* p = a.src + (long)b * a.h * a.w * a.lds + c;
+    a.dst[i] = wy0 * (wx0 * p[((long)y0 * a.w + x0) * a.lds] + wx1 * p[((long)y0 * a.w + x1) * a.lds]) +
+               wy1 * (wx0 * p[((long)y1 * a.w + x0) * a.lds] + wx1 * p[((long)y1 * a.w + x1) * a.lds]);
+  }
+}
+// adjoint: dsrc[b][yl][xl][c] = sum over (y, x) of w(y,yl) * w(x,xl) * ddst[b][c][y][x]   (gather form, deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_nchw_bwd_kernel(const float* ddst, T* dsrc, UpArgs a) {
+  const long total = (long)a.B * a.h * a.w * a.C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % a.C);
+    long t = i / a.C;
+    const int xl = (int)(t % a.w); t /= a.w;
+    const int yl = (int)(t % a.h);
+    const int b = (int)(t / a.h);
+    const float ry = a.sy > 0.f ? 1.f / a.sy : 0.f, rx = a.sx > 0.f ? 1.f / a.sx : 0.f;
+    int ylo = a.sy > 0.f ? (int)floorf(((float)yl - 1.f) * ry) - 2 : 0, yhi = a.sy > 0.f ? (int)ceilf(((float)yl + 2.f) * ry) + 2 : a.H - 1;
+    int xlo = a.sx > 0.f ? (int)floorf(((float)xl - 1.f) * rx) - 2 : 0, xhi = a.sx > 0.f ? (int)ceilf(((float)xl + 2.f) * rx) + 2 : a.W - 1;
+    ylo = max(ylo, 0); yhi = min(yhi, a.H - 1); xlo = max(xlo, 0); xhi = min(xhi, a.W - 1);
+    const float* g = ddst + ((long)b * a.C + c) * a.H * a.W;
+    float s = 0.f;
+    for (int y = ylo; y <= yhi; ++y) {
+      int y0, y1; float wy0, wy1;
+      up_taps(y, a.h, a.sy, a.align, y0, y1, wy0, wy1);
+      const float wy = (y0 == yl ? wy0 : 0.f) + (y1 == yl ? wy1 : 0.f);
+      if (wy == 0.f) continue;
+      float row = 0.f;
+      for (int x = xlo; x <= xhi; ++x) {
+        int x0, x1; float wx0, wx1;
+        up_taps(x, a.w, a.sx, a.align, x0, x1, wx0, wx1);
+        const float wx = (x0 == xl ? wx0 : 0.f) + (x1 == xl ? wx1 : 0.f);
+        if (wx != 0.f) row += wx * g[(long)y * a.W + x];
+      }
+      s += wy * row;
+    }
+    Elem<T>::st(dsrc + ((long)(b * a.h + yl) * a.w + xl) * a.lds + c, s);
+  }
+}
+static void fill_up(UpArgs& a, int B, int h, int w, int lds, int C, int H, int W, int align) {
+  a.B = B; a.h = h; a.w = w; a.lds = lds; a.C = C; a.H = H; a.W = W; a.align = align;
+  if (align) {
+    a.sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    a.sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  } else {
+    a.sy = (float)h / (float)H;
+    a.sx = (float)w / (float)W;
+  }
+}
+extern "C" int simt_upsample_nchw(const float* src, int B, int h, int w, int lds, int C, int H, int W, int align_corners, float* dst,
+                                  simt_stream_t stream) {
+  SIMT_CHECK(src && dst && C <= lds);
+  UpArgs a; a.src = src; a.dst = dst;
+  fill_up(a, B, h, w, lds, C, H, W, align_corners);
+  long total = (long)B * C * H * W, grid = (total + 255) / 256;
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(upsample_nchw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+extern "C" int simt_upsample_nchw_bwd(const float* ddst, int B, int h, int w, int lds, int C, int H, int W, int align_corners,
+                                      void* dsrc, int dtype, simt_stream_t stream) {
+  SIMT_CHECK(ddst && dsrc && C <= lds);
+  UpArgs a; a.src = nullptr; a.dst = nullptr;
+  fill_up(a, B, h, w, lds, C, H, W, align_corners);
+  long total = (long)B * h * w * C, grid = (total + 255) / 256;
+  if (grid > 256 * 16) grid = 256 * 16;
+  if (dtype == SIMT_BF16)
+    hipLaunchKernelGGL(upsample_nchw_bwd_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, ddst, (bf16_t*)dsrc, a);
+  else
+    hipLaunchKernelGGL(upsample_nchw_bwd_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, ddst, (float*)dsrc, a);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}

@@ -590,8 +590,15 @@ class TrunkPlan:
                     tap_off, cout, rs, 0, stream=stream)
             self.grad_ready[pname] = len(lst)
 
-    def _bn_bwd(self, lst, *, dz, y, bname, dy, M, Cn, mask_mode, z=None, y2=None, bname2=None, dy2=None, gout=None):
+    def _bn_bwd(self, lst, *, dz, y, bname, dy, M, Cn, mask_mode, z=None, y2=None, bname2=None, dy2=None, gout=None,
+                affine=False):
+        """affine: also write d gamma / d beta into self.grads[bname.weight / .bias] (trainable BatchNorm, engine_v3)."""
         s = self.bn[bname]
+        ag = {}
+        if affine:
+            ag = dict(dgamma=self.grads[bname + ".weight"], dbeta=self.grads[bname + ".bias"])
+            if bname2:
+                ag.update(dgamma2=self.grads[bname2 + ".weight"], dbeta2=self.grads[bname2 + ".bias"])
         s2 = self.bn[bname2] if bname2 else None
         nblk = ops.bn_bwd_nblk(M, Cn)
         part = self.buf("bnb.part", self._bnb_cap, dtype=torch.float32)
@@ -600,7 +607,7 @@ class TrunkPlan:
         d = ops.make_bn_bwd_desc(dz=dz, y=y, mean=s["mean"], rstd=s["rstd"], scale=s["scale"], shift=s["shift"], part=part,
                                  coef=coef, dy=dy, M=M, Cn=Cn, mask_mode=mask_mode, z=z, y2=y2,
                                  mean2=s2["mean"] if s2 else None, rstd2=s2["rstd"] if s2 else None,
-                                 scale2=s2["scale"] if s2 else None, dy2=dy2, gout=gout)
+                                 scale2=s2["scale"] if s2 else None, dy2=dy2, gout=gout, **ag)
         lst.add_desc("simt_bn_bwd", d)
 
     def _build_backward(self):

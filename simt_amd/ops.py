@@ -152,13 +152,14 @@ def bn_bwd_nblk(M, Cn):
 
 
 def make_bn_bwd_desc(*, dz, y, mean, rstd, scale, shift, part, coef, dy, M, Cn, mask_mode, z=None, y2=None, mean2=None,
-                     rstd2=None, scale2=None, dy2=None, gout=None):
+                     rstd2=None, scale2=None, dy2=None, gout=None, dgamma=None, dbeta=None, dgamma2=None, dbeta2=None):
     d = L.BnBwdDesc()
     d.dz, d.z, d.y = _p(dz), _p(z), _p(y)
     d.mean, d.rstd, d.scale, d.shift = _p(mean), _p(rstd), _p(scale), _p(shift)
     d.y2, d.mean2, d.rstd2, d.scale2 = _p(y2), _p(mean2), _p(rstd2), _p(scale2)
     d.part, d.coef, d.dy, d.dy2, d.gout = _p(part), _p(coef), _p(dy), _p(dy2), _p(gout)
     d.M, d.C, d.mask_mode, d.dtype = M, Cn, mask_mode, dt_code(y.dtype)
+    d.dgamma, d.dbeta, d.dgamma2, d.dbeta2 = _p(dgamma), _p(dbeta), _p(dgamma2), _p(dbeta2)
     return d
 
 
