@@ -12,6 +12,8 @@ PyTorch is used for device memory and streams only; all arithmetic happens in li
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -82,6 +84,8 @@ def side_stream(device=None):
     model's forward run there, so their MFMA-bound workgroups share the CUs with the HBM-bound BatchNorm passes of the
     main stream instead of queueing behind them."""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if os.environ.get("SIMT_SINGLE_STREAM") == "1":     # profiling aid: serial schedule, per-kernel durations without CU sharing
+        return torch.cuda.current_stream(dev)
     if dev not in _SIDE_STREAMS:
         _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
     return _SIDE_STREAMS[dev]
@@ -92,6 +96,21 @@ class LaunchList:
 
     def __init__(self):
         self.items = []
+        self.graph = None
+
+    def capture(self):
+        """Capture the whole list (both streams, with its fork/join events) into one hipGraph: run() then costs one graph
+        launch instead of len(self) host calls -- what the launch-bound plans (DeepLabv3 at 512x1024: ~450 launches of
+        ~15 us) need.  Every buffer and descriptor is preallocated, so the captured kernel arguments stay valid; the list
+        is replayed once eagerly first so that lazily created workspaces exist before capture."""
+        self.graph = None
+        self.run()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run()
+        self.graph = g
+        return g
 
     def add(self, name, *args, keep=None, tag=None, flops=0.0, nbytes=0.0, shape=None, stream=0):
         fn = getattr(L.load(), name)
@@ -140,6 +159,9 @@ class LaunchList:
                 b[3] += 1
 
     def run(self, single_stream=False):
+        if self.graph is not None and not single_stream:
+            self.graph.replay()
+            return
         main = torch.cuda.current_stream()
         if single_stream or not any(it.stream for it in self.items):
             st = main.cuda_stream
@@ -823,6 +845,12 @@ class TrunkPlan:
         return dfeat
 
     # ------------------------------------------------------------------ run
+    def capture_graphs(self):
+        """hipGraphs of the forward and (train plans) backward launch lists; repack() stays eager."""
+        self.fwd_list.capture()
+        if self.train:
+            self.bwd_list.capture()
+
     def forward(self, x_nchw=None):
         """x: [B,3,H,W] fp32 CUDA (BGR, mean-subtracted).  Returns {head name: logits [B,h,w,ldp] fp32 (NHWC)}."""
         if x_nchw is not None:
