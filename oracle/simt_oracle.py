@@ -414,13 +414,14 @@ def load_class_dist(name="bapa"):
 class OracleTrainer:
     """State + one-iteration step of the SimT stage, CPU fp32.  Mirrors what main() keeps between iterations."""
 
-    def __init__(self, st, fixed_st, ntm1, ntm2, hp, class_dist, openset=True, dtype=torch.float32):
+    def __init__(self, st, fixed_st, ntm1, ntm2, hp, class_dist, openset=True, dtype=torch.float32, layers=LAYERS):
         """dtype=torch.float64 gives the "exact arithmetic" run used to measure how far fp32 implementations
         (the reference's CPU path included) sit from the true value of an ill-conditioned quantity."""
         self.hp = hp
         self.cd = class_dist
         self.openset = openset
         self.dtype = dtype
+        self.layers = layers
         st = {k: (v.to(dtype) if v.dtype != torch.long else v) for k, v in st.items()}
         fixed_st = {k: (v.to(dtype) if v.dtype != torch.long else v) for k, v in fixed_st.items()}
         ntm1, ntm2 = ntm1.to(dtype), ntm2.to(dtype)
@@ -447,9 +448,14 @@ class OracleTrainer:
         self.first = True
 
     def step(self, image, label, it):
+        """image / label: one micro-batch, or lists of hp.iter_size micro-batches (gradient accumulation,
+        trainV2_simt.py:341-432: the W loop and zero_grad run once, every sub-iteration re-evaluates T, runs both nets,
+        back-propagates loss / iter_size, and the optimisers step once)."""
         hp = self.hp
         c = hp.num_classes
-        image = image.to(self.dtype)
+        images = list(image) if isinstance(image, (list, tuple)) else [image]
+        labels = list(label) if isinstance(label, (list, tuple)) else [label]
+        assert len(images) == len(labels) == getattr(hp, "iter_size", 1)
         lr = lr_poly(hp.lr, it, hp.num_steps, hp.power)
         lr_T = lr_poly(hp.lr_T, it, hp.num_steps, hp.power)
         for v in self.st.values():
@@ -458,16 +464,18 @@ class OracleTrainer:
         for t in self.ntm:
             t.grad = None
         inner_w_loop(self.ntm[0], self.ntm[1], self.w[0], self.w[1], self.wstate, self.cd, hp, lr_T)
-        T1 = sig_ntm_forward(self.ntm[0], self.cd, c)
-        T2 = sig_ntm_forward(self.ntm[1], self.cd, c)
-        size = tuple(label.shape[1:])
-        with torch.no_grad():
-            _, f2 = deeplab_multi_forward(self.fixed, image, False, False)
-        x1, x2 = deeplab_multi_forward(self.st, image, True, self.openset)
-        W1 = sig_w_forward(self.w[0])
-        W2 = sig_w_forward(self.w[1])
-        out = simt_losses(x1, x2, f2, label, T1, T2, W1, W2, hp, size)
-        out["total"].backward()
+        for image, label in zip(images, labels):
+            image = image.to(self.dtype)
+            T1 = sig_ntm_forward(self.ntm[0], self.cd, c)
+            T2 = sig_ntm_forward(self.ntm[1], self.cd, c)
+            size = tuple(label.shape[1:])
+            with torch.no_grad():
+                _, f2 = deeplab_multi_forward(self.fixed, image, False, False, self.layers)
+            x1, x2 = deeplab_multi_forward(self.st, image, True, self.openset, self.layers)
+            W1 = sig_w_forward(self.w[0])
+            W2 = sig_w_forward(self.w[1])
+            out = simt_losses(x1, x2, f2, label, T1, T2, W1, W2, hp, size)
+            out["total"].backward()                   # simt_losses already divides by hp.iter_size (:427)
         with torch.no_grad():
             for g in self.groups:
                 ps, gs, bs, ms = [], [], [], []
@@ -524,9 +532,14 @@ class OracleWarmupTrainer:
         for v in self.st.values():
             if v.dtype != torch.long:
                 v.grad = None
-        x1, x2 = deeplab_multi_forward(self.st, image.to(self.dtype), True, False, layers=self.layers)
-        total, l1, l2 = warmup_losses(x1, x2, label, hp.lambda_seg, tuple(label.shape[1:]))
-        total.backward()
+        images = list(image) if isinstance(image, (list, tuple)) else [image]
+        labels = list(label) if isinstance(label, (list, tuple)) else [label]
+        assert len(images) == len(labels) == hp.iter_size            # trainV1_warmup.py:212-231: loss / iter_size, grads accumulate
+        for image, label in zip(images, labels):
+            x1, x2 = deeplab_multi_forward(self.st, image.to(self.dtype), True, False, layers=self.layers)
+            total, l1, l2 = warmup_losses(x1, x2, label, hp.lambda_seg, tuple(label.shape[1:]))
+            total = total / hp.iter_size
+            total.backward()
         with torch.no_grad():
             for g in self.groups:
                 ps, gs, bs, ms = [], [], [], []

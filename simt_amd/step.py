@@ -60,9 +60,6 @@ def optim_listing(names, layers_root=("layer3", "layer4"), head_prefixes=("layer
 class SimTTrainer:
     def __init__(self, state, fixed_state, ntm1, ntm2, hp, class_dist, B, H, W, *, dtype=torch.bfloat16, device="cuda:0",
                  openset=True, process_group=None, w_init=None, layers=None):
-        if hp.iter_size != 1:
-            raise NotImplementedError("--iter-size > 1 (gradient accumulation, trainV2_simt.py:341) is not implemented; "
-                                      "every shipped configuration of the reference uses 1")
         self.hp, self.B, self.H, self.W, self.dtype = hp, B, H, W, dtype
         dev = self.dev = torch.device(device)
         self.pg = process_group
@@ -136,6 +133,7 @@ class SimTTrainer:
         self._build_sgd()
         self.it_done = 0
         # ---- data parallel: bucketed mean all-reduce overlapped with backward
+        self._grad_acc = torch.zeros_like(self.plan.flat_grad) if hp.iter_size > 1 else None
         self.reducer = None
         if self.pg is not None:
             from .dp import BucketReducer, make_buckets
@@ -170,21 +168,10 @@ class SimTTrainer:
         self.sgd_desc = d
 
     # ------------------------------------------------------------------ one iteration
-    def step(self, image, label, it=None):
-        """image [B,3,H,W] fp32 (device or host), label [B,H,W] int64.  Returns the device tensor `lout`
-        (total, loss_p1, loss_p2, loss_y1, loss_y2, Place, Convex, Volume, Anchor, vol_ok, ...)."""
-        hp = self.hp
-        it = self.it_done if it is None else it
-        lr = lr_poly(hp.lr, it, hp.num_steps, hp.power)
-        lr_T = lr_poly(hp.lr_T, it, hp.num_steps, hp.power)
-        st = ops.stream_ptr()
+    def _micro_batch(self, image, label, st):
+        """Steps 2-5 of the iteration for one micro-batch: both forwards, fused head, NTM terms, backward."""
         self.plan.x_in.copy_(image, non_blocking=True)
         self.label.copy_(label, non_blocking=True)
-        # 1. inner W loop (NTM grads start from zero each iteration: optimizer_t*.zero_grad(), :314-318)
-        self._ntm_grad_flat.zero_()
-        ni = self.inner_desc
-        ni.step0, ni.lr = self.inner_steps * self.it_done, lr_T
-        L.call("simt_ntm_inner_loop", C.byref(ni), st)
         # 2. frozen model -> low-res posterior, on the side stream: its eval-mode convs share the CUs with the HBM-bound
         #    BatchNorm passes of the trainable forward (3.) instead of running before it
         main = torch.cuda.current_stream()
@@ -201,17 +188,51 @@ class SimTTrainer:
         # 3. trainable forward
         self.plan.forward()
         main.wait_event(ev_fix)
-        # 4. fused head + NTM regularisers + gradients of the low-res logits
+        # 4. fused head + NTM regularisers + gradients of the low-res logits (every term scaled by 1 / iter_size, :427;
+        #    the NTM gradients accumulate on top of the inner loop's leak and of earlier micro-batches)
         L.call("simt_head_loss", C.byref(self.head_desc), st)
         L.call("simt_ntm_post", C.byref(self.post_desc), st)
         L.call("simt_head_grad", C.byref(self.head_desc), st)
-        # 5. trunk backward (+ 6. data-parallel mean of the gradients, bucket by bucket, on a side stream)
-        if self.reducer is not None:
-            self.reducer.start()
-            self.plan.backward(hook=self.reducer.ready_upto)
-            self.reducer.finish()
-        else:
+
+    def step(self, image, label, it=None):
+        """image [B,3,H,W] fp32 (device or host), label [B,H,W] int64 -- or, with hp.iter_size > 1 (gradient accumulation,
+        trainV2_simt.py:341-432), sequences of iter_size micro-batches.  Returns the device tensor `lout`
+        (total, loss_p1, loss_p2, loss_y1, loss_y2, Place, Convex, Volume, Anchor, vol_ok, ...) of the last micro-batch."""
+        hp = self.hp
+        it = self.it_done if it is None else it
+        lr = lr_poly(hp.lr, it, hp.num_steps, hp.power)
+        lr_T = lr_poly(hp.lr_T, it, hp.num_steps, hp.power)
+        st = ops.stream_ptr()
+        images = list(image) if isinstance(image, (list, tuple)) else [image]
+        labels = list(label) if isinstance(label, (list, tuple)) else [label]
+        if len(images) != hp.iter_size or len(labels) != hp.iter_size:
+            raise ValueError(f"step() needs {hp.iter_size} micro-batch(es) (hp.iter_size), got {len(images)}")
+        # 1. inner W loop (NTM grads start from zero each iteration: optimizer_t*.zero_grad(), :314-318)
+        self._ntm_grad_flat.zero_()
+        ni = self.inner_desc
+        ni.step0, ni.lr = self.inner_steps * self.it_done, lr_T
+        L.call("simt_ntm_inner_loop", C.byref(ni), st)
+        flat = self.plan.flat_grad
+        for mi, (img, lab) in enumerate(zip(images, labels)):
+            last = mi == hp.iter_size - 1
+            self._micro_batch(img, lab, st)
+            # 5. trunk backward (+ 6. data-parallel mean of the gradients, bucket by bucket, on a side stream)
+            if self.reducer is not None and hp.iter_size == 1:
+                self.reducer.start()
+                self.plan.backward(hook=self.reducer.ready_upto)
+                self.reducer.finish()
+                continue
             self.plan.backward()
+            if hp.iter_size > 1:      # loss.backward() accumulates into .grad (:428): keep the running sum beside the plan's buffer
+                if mi == 0:
+                    self._grad_acc.copy_(flat)
+                elif not last:
+                    L.call("simt_vec_acc", self._grad_acc.data_ptr(), flat.data_ptr(), flat.numel(), 1, st)
+                else:
+                    L.call("simt_vec_acc", flat.data_ptr(), self._grad_acc.data_ptr(), flat.numel(), 1, st)
+                    if self.reducer is not None:   # one exchange of the accumulated gradient (no overlap with backward)
+                        self.reducer.start()
+                        self.reducer.finish()
         # 7. optimisers
         d = self.sgd_desc
         d.lr[0], d.lr[1] = lr, lr * 10.0
@@ -263,7 +284,7 @@ class WarmupTrainer:
         hd.B, hd.h, hd.w, hd.H, hd.W, hd.C, hd.Q = B, h, w, H, W, Cn, Cn
         hd.ldp, hd.ldf, hd.QP, hd.ld_f32, hd.ld_t = self.plan.ldp["x1"], self.plan.ldp["x1"], self.QP, 0, d1.shape[1]
         hd.grad_dtype = ops.dt_code(dtype)
-        hd.th_high, hd.th_low, hd.lambda_seg, hd.lambda_place, hd.gscale = 2.0, -1.0, hp.lambda_seg, 0.0, 1.0
+        hd.th_high, hd.th_low, hd.lambda_seg, hd.lambda_place, hd.gscale = 2.0, -1.0, hp.lambda_seg, 0.0, 1.0 / hp.iter_size
         hd.mode = 1
         self.head_desc = hd
         SimTTrainer._build_sgd(self, roots=("conv1", "layer1", "layer2", "layer3", "layer4"))
@@ -274,23 +295,44 @@ class WarmupTrainer:
             sizes = {n: k for n, (_o, k) in self.plan.grad_offsets.items()}
             buckets = make_buckets(self.plan.grad_order, sizes, self.plan.grad_ready, bucket_elems=8 << 20)
             self.reducer = BucketReducer(self.plan.flat_grad, buckets, group=self.pg)
+        self._grad_acc = None
 
     def step(self, image, label, it=None):
+        """One micro-batch, or sequences of hp.iter_size micro-batches (trainV1_warmup.py:212-231: loss / iter_size,
+        gradients accumulated, one optimiser step)."""
         hp = self.hp
         it = self.it_done if it is None else it
         lr = lr_poly(hp.lr, it, hp.num_steps, hp.power)
         st = ops.stream_ptr()
-        self.plan.x_in.copy_(image, non_blocking=True)
-        self.label.copy_(label, non_blocking=True)
-        self.plan.forward()
-        L.call("simt_head_loss", C.byref(self.head_desc), st)
-        L.call("simt_head_grad", C.byref(self.head_desc), st)
-        if self.reducer is not None:
-            self.reducer.start()
-            self.plan.backward(hook=self.reducer.ready_upto)
-            self.reducer.finish()
-        else:
+        images = list(image) if isinstance(image, (list, tuple)) else [image]
+        labels = list(label) if isinstance(label, (list, tuple)) else [label]
+        if len(images) != hp.iter_size or len(labels) != hp.iter_size:
+            raise ValueError(f"step() needs {hp.iter_size} micro-batch(es) (hp.iter_size), got {len(images)}")
+        flat = self.plan.flat_grad
+        for mi, (img, lab) in enumerate(zip(images, labels)):
+            self.plan.x_in.copy_(img, non_blocking=True)
+            self.label.copy_(lab, non_blocking=True)
+            self.plan.forward()
+            L.call("simt_head_loss", C.byref(self.head_desc), st)
+            L.call("simt_head_grad", C.byref(self.head_desc), st)
+            if self.reducer is not None and hp.iter_size == 1:
+                self.reducer.start()
+                self.plan.backward(hook=self.reducer.ready_upto)
+                self.reducer.finish()
+                continue
             self.plan.backward()
+            if hp.iter_size > 1:
+                if self._grad_acc is None:
+                    self._grad_acc = torch.zeros_like(flat)
+                if mi == 0:
+                    self._grad_acc.copy_(flat)
+                elif mi < hp.iter_size - 1:
+                    L.call("simt_vec_acc", self._grad_acc.data_ptr(), flat.data_ptr(), flat.numel(), 1, st)
+                else:
+                    L.call("simt_vec_acc", flat.data_ptr(), self._grad_acc.data_ptr(), flat.numel(), 1, st)
+                    if self.reducer is not None:
+                        self.reducer.start()
+                        self.reducer.finish()
         d = self.sgd_desc
         d.lr[0], d.lr[1] = lr, lr * 10.0
         d.wd[0], d.wd[1] = hp.weight_decay, hp.weight_decay
@@ -302,4 +344,5 @@ class WarmupTrainer:
 
     def losses(self):
         v = self.hout[:16].cpu().tolist()
-        return {"total": v[14], "loss_seg1": v[0], "loss_seg2": v[1]}
+        # `loss = loss / args.iter_size` (trainV1_warmup.py:227): the reported total is the scaled one, like SimTTrainer's
+        return {"total": v[14] / self.hp.iter_size, "loss_seg1": v[0], "loss_seg2": v[1]}

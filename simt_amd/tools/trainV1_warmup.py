@@ -57,7 +57,7 @@ def main(argv=None):
     w, h = map(int, args.input_size_target.split(","))
     state = ms.reference_init(ms.state_shapes(args.num_classes, 0, False), seed=args.random_seed)
     n = restore(state, args.restore_from)
-    hp = Hyper(num_classes=args.num_classes, open_classes=0, lambda_seg=args.lambda_seg, lr=args.learning_rate,
+    hp = Hyper(num_classes=args.num_classes, open_classes=0, lambda_seg=args.lambda_seg, lr=args.learning_rate, iter_size=args.iter_size,
                momentum=args.momentum, weight_decay=args.weight_decay, power=args.power, num_steps=args.num_steps)
     dtype = torch.bfloat16 if args.compute_dtype == "bf16" else torch.float32
     tr = WarmupTrainer(state, hp, args.batch_size, h, w, dtype=dtype, device=dev, process_group=pg)
@@ -67,7 +67,9 @@ def main(argv=None):
         os.makedirs(args.snapshot_dir, exist_ok=True)
     t0 = time.time()
     for i_iter in range(args.num_steps):
-        img, lab = ms.synthetic_batch(args.batch_size, h, w, cd, seed=args.random_seed + 1000 * rank + i_iter, device=dev)
+        mb = [ms.synthetic_batch(args.batch_size, h, w, cd, seed=args.random_seed + 1000 * rank + i_iter * args.iter_size + j, device=dev)
+              for j in range(args.iter_size)]                         # gradient accumulation: iter_size micro-batches per step
+        img, lab = ([m[0] for m in mb], [m[1] for m in mb]) if args.iter_size > 1 else mb[0]
         tr.step(img, lab, i_iter)
         if i_iter % args.print_every == 0 and rank == 0:
             l = tr.losses()

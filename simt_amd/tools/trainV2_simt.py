@@ -126,7 +126,8 @@ def main(argv=None):
     data = batches(args, args.batch_size, h, w, cd, rank, dev)
     t0 = time.time()
     for i_iter in range(args.num_steps):
-        img, lab = next(data)
+        mb = [next(data) for _ in range(args.iter_size)]           # gradient accumulation: iter_size micro-batches per step
+        img, lab = ([m[0] for m in mb], [m[1] for m in mb]) if args.iter_size > 1 else mb[0]
         tr.step(img, lab, i_iter)
         if i_iter % args.print_every == 0 and rank == 0:
             l = tr.losses()

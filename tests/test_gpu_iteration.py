@@ -181,3 +181,70 @@ def test_g11_warmup_stage_vs_reference_golden(dev):
             if it == 0:
                 np.testing.assert_allclose(v, ref, rtol=0, atol=5e-6, err_msg=f"{k} it {it}")
             assert np.abs(v - p64).max() <= 3 * np.abs(ref - p64).max() + 5e-6, f"{k} it {it}"
+
+
+def test_g12_gradient_accumulation_iter_size2(dev):
+    """--iter-size 2 (trainV2_simt.py:341-432) against the reference's own run (tests/golden/g12_iter_size2.npz: two
+    iterations of two micro-batches, small trunk, fp32).  Iteration 0: losses of the last micro-batch 1e-4, sampled parameters
+    after the step 1e-5 (lr 6e-4 x the sum of two micro-batch gradients), NTM 2e-5.  Iteration 1 (on parameters that already moved) is anchored on the float64 oracle like
+    the warm-up test: |gpu - f64| <= 3 |reference fp32 - f64| + eps (eps = 2e-3 on the losses: the class-posterior CE counts
+    pixels through the 0.8 / 0.2 confidence thresholds, a handful of which move with 1e-5 parameter differences)."""
+    d = np.load(os.path.join(G, "g12_iter_size2.npz"))
+    K, B, H, W, its = [int(v) for v in d["meta"]]
+    layers = tuple(int(v) for v in d["layers"])
+    st = so.recipe_state(so.state_shapes(19, K, True, layers=layers), seed=2024, head_scale=8.0)
+    fst = so.recipe_state(so.state_shapes(19, 0, False, layers=layers), seed=2025, head_scale=8.0)
+    kw = dict(open_classes=K, lambda_convex=0.1, lambda_volume=1.0, lambda_anchor=1.0, lr=6e-4, lr_T=6e-3, iter_size=its)
+    tr = SimTTrainer(st, fst, so.ntm_init(19, K, 911), so.ntm_init(19, K, 912), Hyper(**kw), CD, B, H, W, dtype=torch.float32,
+                     device=dev, layers=layers)
+    truth = so.OracleTrainer(st, fst, so.ntm_init(19, K, 911), so.ntm_init(19, K, 912), so.Hyper(**kw), CD, layers=layers,
+                             dtype=torch.float64)
+    keys = [str(k) for k in d["sample_keys"]]
+    with pytest.raises(ValueError):
+        tr.step(torch.zeros(B, 3, H, W), torch.zeros(B, H, W, dtype=torch.long), 0)      # one micro-batch where two are due
+    for it in range(2):
+        mb = [so.synthetic_batch(B, H, W, CD.numpy(), seed=700 + its * it + j, block=8) for j in range(its)]
+        tr.step([m[0].to(dev) for m in mb], [m[1].to(dev) for m in mb], it)
+        o64 = truth.step([m[0] for m in mb], [m[1] for m in mb], it)
+        l = tr.losses()
+        got = np.array([l[k] for k in LOSS_KEYS])
+        gold = d["losses"][it][:9]
+        t64 = np.array([float(o64[k].detach()) for k in LOSS_KEYS])
+        if it == 0:
+            np.testing.assert_allclose(got, gold, rtol=1e-4, atol=1e-4)
+        assert np.all(np.abs(got - t64) <= 3 * np.abs(gold - t64) + 2e-3 * np.maximum(np.abs(t64), 1.0)), f"it {it}: gpu {got} f64 {t64} ref {gold}"
+        for i, k in enumerate(keys):
+            v = tr.params[k].detach().flatten()[:64].cpu().numpy()
+            ref = d["param_samples"][it][i][: len(v)]
+            p64 = truth.st[k].detach().flatten()[:64].numpy()
+            if it == 0:
+                np.testing.assert_allclose(v, ref, rtol=0, atol=1e-5, err_msg=f"{k} it {it}")
+            assert np.abs(v - p64).max() <= 3 * np.abs(ref - p64).max() + 5e-6, f"{k} it {it}"
+        for j in range(2):
+            n = tr.ntm[j].detach().cpu().numpy()
+            if it == 0:
+                np.testing.assert_allclose(n, d["ntm_after"][it][j], rtol=0, atol=2e-5)
+            n64 = truth.ntm[j].detach().numpy()
+            assert np.abs(n - n64).max() <= 3 * np.abs(d["ntm_after"][it][j] - n64).max() + 2e-5
+
+
+def test_warmup_gradient_accumulation_iter_size2(dev):
+    """trainV1_warmup.py:212-231 with --iter-size 2: WarmupTrainer on two micro-batches against the float64 oracle (whose
+    loop body is pinned by g11; the accumulation is `loss / iter_size` + summed gradients): loss 1e-4; parameters within
+    3x the distance of the same oracle run in fp32 from float64 (+5e-6)."""
+    from simt_amd.step import WarmupTrainer
+    layers = (1, 1, 2, 1)
+    st = so.recipe_state(so.state_shapes(19, 0, False, layers=layers), seed=77, head_scale=8.0)
+    tr = WarmupTrainer(st, Hyper(open_classes=0, lr=2.5e-4, iter_size=2), 2, 97, 97, dtype=torch.float32, device=dev, layers=layers)
+    truth = so.OracleWarmupTrainer(st, so.Hyper(open_classes=0, lr=2.5e-4, iter_size=2), layers=layers, dtype=torch.float64)
+    mb = [so.synthetic_batch(2, 97, 97, CD.numpy(), seed=500 + j, block=8) for j in range(2)]
+    tr.step([m[0].to(dev) for m in mb], [m[1].to(dev) for m in mb], 0)
+    o64 = truth.step([m[0] for m in mb], [m[1] for m in mb], 0)
+    ref32 = so.OracleWarmupTrainer(st, so.Hyper(open_classes=0, lr=2.5e-4, iter_size=2), layers=layers)
+    ref32.step([m[0] for m in mb], [m[1] for m in mb], 0)
+    l = tr.losses()
+    assert abs(l["total"] - float(o64["total"])) < 1e-4 * abs(float(o64["total"])), (l, o64)
+    for k in ("conv1.weight", "layer1.0.conv2.weight", "layer3.1.conv3.weight", "layer6.conv2d_list.1.weight", "layer5.conv2d_list.0.bias"):
+        v, p64 = tr.params[k].detach().cpu().double(), truth.st[k].detach()
+        e_ref = (ref32.st[k].detach().double() - p64).abs().max().item()
+        assert (v - p64).abs().max().item() < 3 * e_ref + 5e-6, (k, e_ref)

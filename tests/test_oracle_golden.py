@@ -263,3 +263,30 @@ def test_g11_warmup_stage_two_iterations():
         for i, k in enumerate(keys):
             v = tr.st[k].detach().flatten()[:64].numpy()
             np.testing.assert_allclose(v, d["param_samples"][it][i][: len(v)], rtol=0, atol=2e-6, err_msg=f"{k} it {it}")
+
+
+def test_g12_gradient_accumulation_iter_size2():
+    """--iter-size 2 (trainV2_simt.py:341-432): two iterations of two micro-batches each, run by the reference itself
+    (oracle/gen_golden_iter2.py).  Small trunk -> well conditioned: losses 2e-5, parameters 2e-6, NTM 1e-5."""
+    d = L("g12_iter_size2")
+    K, B, H, W, its = [int(v) for v in d["meta"]]
+    layers = tuple(int(v) for v in d["layers"])
+    st = so.recipe_state(so.state_shapes(19, K, True, layers=layers), seed=2024, head_scale=8.0)
+    fst = so.recipe_state(so.state_shapes(19, 0, False, layers=layers), seed=2025, head_scale=8.0)
+    hp = so.Hyper(open_classes=K, lambda_convex=0.1, lambda_volume=1.0, lambda_anchor=1.0, lr=6e-4, lr_T=6e-3, iter_size=its)
+    tr = so.OracleTrainer(st, fst, so.ntm_init(19, K, 911), so.ntm_init(19, K, 912), hp, CD, layers=layers)
+    keys = [str(k) for k in d["sample_keys"]]
+    for it in range(2):
+        mb = [so.synthetic_batch(B, H, W, CD.numpy(), seed=700 + its * it + j, block=8) for j in range(its)]
+        out = tr.step([m[0] for m in mb], [m[1] for m in mb], it)
+        got = np.array([float(out[k].detach()) for k in ["total", "loss_p1", "loss_p2", "loss_y1", "loss_y2", "place", "convex",
+                                                            "volume", "anchor"]])
+        tol = 2e-5 if it == 0 else 2e-4
+        np.testing.assert_allclose(got, d["losses"][it][:9], rtol=tol, atol=tol, err_msg=f"iteration {it}")
+        for i, k in enumerate(keys):
+            v = tr.st[k].detach().flatten()[:64].numpy()
+            np.testing.assert_allclose(v, d["param_samples"][it][i][: len(v)], rtol=0, atol=2e-6 if it == 0 else 2e-5,
+                                       err_msg=f"{k} after it {it}")
+        np.testing.assert_allclose(tr.ntm[0].detach().numpy(), d["ntm_after"][it][0], rtol=0, atol=1e-5 if it == 0 else 1e-4)
+        np.testing.assert_allclose(tr.ntm[1].detach().numpy(), d["ntm_after"][it][1], rtol=0, atol=1e-5 if it == 0 else 1e-4)
+    close(tr.w[0].detach(), d["w1"], 1e-4)
