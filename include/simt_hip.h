@@ -104,6 +104,11 @@ int simt_bn_finalize(const float* part, int nblk, int C, long count, const float
 int simt_bn_apply(const void* y, const float* scale, const float* shift, const void* res, const void* y2,
                   const float* scale2, const float* shift2, void* z, long M, int C, int relu, int dtype,
                   simt_stream_t stream);
+/* same, and bits[(m*C + c) / 8] bit (c & 7) = (z[m][c] > 0): the ReLU mask of the block output (model/deeplab_multi.py:99-100)
+ * for simt_bn_bwd's mask_mode 3 -- the backward then reads M*C/8 bytes instead of z (M*C elements) in both of its passes */
+int simt_bn_apply_bits(const void* y, const float* scale, const float* shift, const void* res, const void* y2,
+                       const float* scale2, const float* shift2, void* z, unsigned char* bits, long M, int C, int relu,
+                       int dtype, simt_stream_t stream);
 typedef struct {
   const void* dz;      /* [M][C] upstream gradient */
   const void* z;       /* [M][C] block output (mask_mode 1) or NULL */
@@ -117,7 +122,7 @@ typedef struct {
   void* dy2;           /* [M][C] gradient wrt y2 or NULL */
   void* gout;          /* [M][C] masked gradient (may alias dz) or NULL */
   int64_t M;
-  int32_t C, mask_mode, dtype; /* mask_mode: 0 none, 1 z>0, 2 y*scale+shift>0 */
+  int32_t C, mask_mode, dtype; /* mask_mode: 0 none, 1 z>0, 2 y*scale+shift>0, 3 z = bit mask of simt_bn_apply_bits */
   float *dgamma, *dbeta;   /* [C] or NULL: gradients of a TRAINABLE affine (model/deeplabv3.py's torchvision BatchNorm) */
   float *dgamma2, *dbeta2; /* same for the second BN (y2) */
 } simt_bn_bwd_desc;

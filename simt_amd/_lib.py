@@ -89,6 +89,7 @@ SIGNATURES = {
     "simt_bn_fold": (_I, [c_p, c_p, c_p, c_p, f32, c_p, c_p, _I, c_p]),
     "simt_bn_finalize": (_I, [c_p, _I, _I, _L, c_p, c_p, c_p, c_p, f32, f32, c_p, c_p, c_p, c_p, c_p]),
     "simt_bn_apply": (_I, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, _L, _I, _I, _I, c_p]),
+    "simt_bn_apply_bits": (_I, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, _L, _I, _I, _I, c_p]),
     "simt_bn_bwd_nblk": (_I, [_L, _I]),
     "simt_bn_bwd": (_I, [C.POINTER(BnBwdDesc), c_p]),
     "simt_im2col_stem": (_I, [c_p, c_p, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, c_p]),

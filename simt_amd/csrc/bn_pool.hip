@@ -92,9 +92,10 @@ extern "C" int simt_bn_finalize(const float* part, int nblk, int C, long count, 
 // ---------------------------------------------------------------------------------------------
 // bn_apply:  z = act( y*scale + shift  [+ res]  [+ y2*scale2 + shift2] )
 // ---------------------------------------------------------------------------------------------
+// bits (optional): one byte per 8 channels, bit e = (z[e] > 0): the ReLU mask the backward needs, 16x smaller than z
 template <typename T>
 __global__ void bn_apply_kernel(const T* y, const float* scale, const float* shift, const T* res, const T* y2,
-                                const float* scale2, const float* shift2, T* z, long nvec, int C, int relu) {
+                                const float* scale2, const float* shift2, T* z, unsigned char* bits, long nvec, int C, int relu) {
   const int vpr = C >> 3;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
     int c = (int)(i % vpr) << 3;
@@ -123,6 +124,12 @@ __global__ void bn_apply_kernel(const T* y, const float* scale, const float* shi
       for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
     }
     store8(z + i * 8, v);
+    if (bits) {
+      unsigned b = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b |= (v[e] > 0.f ? 1u : 0u) << e;
+      bits[i] = (unsigned char)b;
+    }
   }
 }
 
@@ -133,24 +140,30 @@ static inline int ew_grid(long nvec) {
   return (int)g;
 }
 
-extern "C" int simt_bn_apply(const void* y, const float* scale, const float* shift, const void* res, const void* y2,
-                             const float* scale2, const float* shift2, void* z, long M, int C, int relu, int dtype,
-                             simt_stream_t stream) {
+extern "C" int simt_bn_apply_bits(const void* y, const float* scale, const float* shift, const void* res, const void* y2,
+                                  const float* scale2, const float* shift2, void* z, unsigned char* bits, long M, int C,
+                                  int relu, int dtype, simt_stream_t stream) {
   SIMT_CHECK(y && scale && shift && z && C % 8 == 0);
   long nvec = M * (C / 8);
   if (dtype == SIMT_BF16)
     hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
-                       scale, shift, (const bf16_t*)res, (const bf16_t*)y2, scale2, shift2, (bf16_t*)z, nvec, C, relu);
+                       scale, shift, (const bf16_t*)res, (const bf16_t*)y2, scale2, shift2, (bf16_t*)z, bits, nvec, C, relu);
   else
     hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)y,
-                       scale, shift, (const float*)res, (const float*)y2, scale2, shift2, (float*)z, nvec, C, relu);
+                       scale, shift, (const float*)res, (const float*)y2, scale2, shift2, (float*)z, bits, nvec, C, relu);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
+}
+extern "C" int simt_bn_apply(const void* y, const float* scale, const float* shift, const void* res, const void* y2,
+                             const float* scale2, const float* shift2, void* z, long M, int C, int relu, int dtype,
+                             simt_stream_t stream) {
+  return simt_bn_apply_bits(y, scale, shift, res, y2, scale2, shift2, z, nullptr, M, C, relu, dtype, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
 // BatchNorm backward (batch statistics, frozen affine).
-//   g   = dz * mask         mask: z>0 (mask_mode 1), y*scale+shift>0 (mask_mode 2), 1 (mask_mode 0)
+//   g   = dz * mask         mask: z>0 (mask_mode 1), y*scale+shift>0 (mask_mode 2), 1 (mask_mode 0),
+//                           bit (c&7) of byte z[(m*C+c)/8] written by simt_bn_apply_bits (mask_mode 3)
 //   xh  = (y - mean)*rstd
 //   reduce:  S1 = sum g, S2 = sum g*xh [, S3 = sum g*xh2 for the downsample BN that shares g]
 //   apply :  dy = scale*(g - S1/M - xh*S2/M)
@@ -193,6 +206,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dz, const T
       } else if (mask_mode == 2) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] = (yv[e] * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
+      } else if (mask_mode == 3) {
+        const unsigned b = ((const unsigned char*)z)[off >> 3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = ((b >> e) & 1u) ? g[e] : 0.f;
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -263,6 +280,10 @@ __global__ void bn_bwd_apply_kernel(const T* dz, const T* z, const T* y, const f
       load8(shift + c, sh);
 #pragma unroll
       for (int e = 0; e < 8; ++e) g[e] = (yv[e] * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
+    } else if (mask_mode == 3) {
+      const unsigned b = ((const unsigned char*)z)[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = ((b >> e) & 1u) ? g[e] : 0.f;
     }
     float o[8];
 #pragma unroll
@@ -300,7 +321,7 @@ extern "C" int simt_bn_bwd_nblk(long M, int C) {
 extern "C" int simt_bn_bwd(const simt_bn_bwd_desc* d, simt_stream_t stream) {
   SIMT_CHECK(d && d->dz && d->y && d->mean && d->rstd && d->scale && d->part && d->coef && d->dy);
   SIMT_CHECK(d->C % 8 == 0 && d->C / 8 <= 256 && 256 % (d->C / 8) == 0);
-  SIMT_CHECK(d->mask_mode != 1 || d->z);
+  SIMT_CHECK((d->mask_mode != 1 && d->mask_mode != 3) || d->z);
   SIMT_CHECK(d->mask_mode != 2 || d->shift);
   SIMT_CHECK(!d->y2 || (d->mean2 && d->rstd2 && d->scale2 && d->dy2));
   hipStream_t st = (hipStream_t)stream;

@@ -427,7 +427,9 @@ class TrunkPlan:
                 self._conv(f, a2, w3, y3, Bn=B, Hi=Ho, Wi=Wo, Cin=planes, Ho=Ho, Wo=Wo, Cout=c4, taps=[(0, 0)],
                            stats=s3["part"])
                 self._bn_train(f, f"{name}.bn3", y3, Mo, c4)
-                rec.update(y1=y1, a1=a1, y2=y2, a2=a2, y3=y3, z=z)
+                # ReLU mask of the block output as one bit per element: what bn3's backward reads instead of z
+                zbits = self.new(Mo, c4 // 8, dtype=torch.uint8)
+                rec.update(y1=y1, a1=a1, y2=y2, a2=a2, y3=y3, z=z, zbits=zbits)
                 if down:
                     yd = self.new(Mo, c4)
                     sd = self._new_bn(f"{name}.downsample.1", Mo, c4)
@@ -435,13 +437,13 @@ class TrunkPlan:
                     self._conv(f, x, wd, yd, Bn=B, Hi=Hc, Wi=Wc, Cin=inpl, Ho=Ho, Wo=Wo, Cout=c4, taps=[(0, 0)],
                                stride=stride, stats=sd["part"])
                     self._bn_train(f, f"{name}.downsample.1", yd, Mo, c4)
-                    f.add("simt_bn_apply", y3.data_ptr(), s3["scale"].data_ptr(), s3["shift"].data_ptr(), None,
-                          yd.data_ptr(), sd["scale"].data_ptr(), sd["shift"].data_ptr(), z.data_ptr(), Mo, c4, 1,
-                          ops.dt_code(dt))
+                    f.add("simt_bn_apply_bits", y3.data_ptr(), s3["scale"].data_ptr(), s3["shift"].data_ptr(), None,
+                          yd.data_ptr(), sd["scale"].data_ptr(), sd["shift"].data_ptr(), z.data_ptr(), zbits.data_ptr(), Mo, c4, 1,
+                          ops.dt_code(dt), tag="simt_bn_apply")
                     rec.update(yd=yd)
                 else:
-                    f.add("simt_bn_apply", y3.data_ptr(), s3["scale"].data_ptr(), s3["shift"].data_ptr(), x.data_ptr(),
-                          None, None, None, z.data_ptr(), Mo, c4, 1, ops.dt_code(dt))
+                    f.add("simt_bn_apply_bits", y3.data_ptr(), s3["scale"].data_ptr(), s3["shift"].data_ptr(), x.data_ptr(),
+                          None, None, None, z.data_ptr(), zbits.data_ptr(), Mo, c4, 1, ops.dt_code(dt), tag="simt_bn_apply")
             else:
                 # eval: BN folded into weights (scale) and bias (shift); ReLU / residual in the conv epilogue
                 a1 = self.buf("e.a1", Mo, planes)
@@ -697,7 +699,7 @@ class TrunkPlan:
             dy3 = self.buf("g.dy3.%d" % par, Mo, c4)
             g = self.buf("g.g", Mo, c4)
             dyd = self.buf("g.dyd.%d" % par, Mo, c4) if down else None
-            self._bn_bwd(b, dz=dz, z=rec["z"], y=rec["y3"], bname=f"{name}.bn3", dy=dy3, M=Mo, Cn=c4, mask_mode=1,
+            self._bn_bwd(b, dz=dz, z=rec["zbits"], y=rec["y3"], bname=f"{name}.bn3", dy=dy3, M=Mo, Cn=c4, mask_mode=3,
                          y2=rec.get("yd"), bname2=f"{name}.downsample.1" if down else None, dy2=dyd,
                          gout=None if down else g)
             # conv3

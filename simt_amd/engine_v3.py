@@ -166,7 +166,8 @@ class V3Plan(TrunkPlan):
                 w3 = self._plan_pack(name + ".conv3", c4, planes, 1)
                 self._conv(f, a2, w3, y3, Bn=B, Hi=Ho, Wi=Wo, Cin=planes, Ho=Ho, Wo=Wo, Cout=c4, taps=[(0, 0)], stats=s3["part"])
                 self._bn_train(f, name + ".bn3", y3, Mo, c4)
-                rec.update(y1=y1, a1=a1, y2=y2, a2=a2, y3=y3)
+                zbits = self.new(Mo, c4 // 8, dtype=torch.uint8)      # ReLU mask of the block output, one bit per element
+                rec.update(y1=y1, a1=a1, y2=y2, a2=a2, y3=y3, zbits=zbits)
                 if down:
                     yd = self.new(Mo, c4)
                     sd = self._new_bn(name + ".downsample.1", Mo, c4)
@@ -174,12 +175,13 @@ class V3Plan(TrunkPlan):
                     self._conv(f, x, wdn, yd, Bn=B, Hi=Hc, Wi=Wc, Cin=inpl, Ho=Ho, Wo=Wo, Cout=c4, taps=[(0, 0)], stride=stride,
                                stats=sd["part"])
                     self._bn_train(f, name + ".downsample.1", yd, Mo, c4)
-                    f.add("simt_bn_apply", y3.data_ptr(), s3["scale"].data_ptr(), s3["shift"].data_ptr(), None, yd.data_ptr(),
-                          sd["scale"].data_ptr(), sd["shift"].data_ptr(), z.data_ptr(), Mo, c4, 1, ops.dt_code(dt))
+                    f.add("simt_bn_apply_bits", y3.data_ptr(), s3["scale"].data_ptr(), s3["shift"].data_ptr(), None, yd.data_ptr(),
+                          sd["scale"].data_ptr(), sd["shift"].data_ptr(), z.data_ptr(), zbits.data_ptr(), Mo, c4, 1, ops.dt_code(dt),
+                          tag="simt_bn_apply")
                     rec.update(yd=yd)
                 else:
-                    f.add("simt_bn_apply", y3.data_ptr(), s3["scale"].data_ptr(), s3["shift"].data_ptr(), x.data_ptr(), None, None,
-                          None, z.data_ptr(), Mo, c4, 1, ops.dt_code(dt))
+                    f.add("simt_bn_apply_bits", y3.data_ptr(), s3["scale"].data_ptr(), s3["shift"].data_ptr(), x.data_ptr(), None, None,
+                          None, z.data_ptr(), zbits.data_ptr(), Mo, c4, 1, ops.dt_code(dt), tag="simt_bn_apply")
             else:
                 res = x
                 if down:
@@ -352,7 +354,7 @@ class V3Plan(TrunkPlan):
             dy3 = self.new(Mo, c4)
             g = None if down else self.new(Mo, c4)
             dyd = self.new(Mo, c4) if down else None
-            self._bnb(b, dz=dz, z=rec["z"], y=rec["y3"], bname=name + ".bn3", dy=dy3, M=Mo, Cn=c4, mask_mode=1, y2=rec.get("yd"),
+            self._bnb(b, dz=dz, z=rec["zbits"], y=rec["y3"], bname=name + ".bn3", dy=dy3, M=Mo, Cn=c4, mask_mode=3, y2=rec.get("yd"),
                       bname2=name + ".downsample.1" if down else None, dy2=dyd, gout=g)
             b.wait(b.record(0), 1)
             self._wgrad(b, dy3, rec["a2"], None, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4, taps=[(0, 0)], stride=1,

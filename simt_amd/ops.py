@@ -142,7 +142,12 @@ def bn_finalize(part, nblk, Cn, count, gamma, beta, running_mean, running_var, m
            momentum, eps, _p(mean), _p(rstd), _p(scale), _p(shift), stream_ptr())
 
 
-def bn_apply(y, scale, shift, z, *, M, Cn, relu=True, res=None, y2=None, scale2=None, shift2=None):
+def bn_apply(y, scale, shift, z, *, M, Cn, relu=True, res=None, y2=None, scale2=None, shift2=None, bits=None):
+    """bits: optional uint8 [M, Cn/8] receiving the ReLU mask (bit c&7 of byte (m*Cn+c)/8 = z>0) for bn_bwd mask_mode 3."""
+    if bits is not None:
+        L.call("simt_bn_apply_bits", _p(y), _p(scale), _p(shift), _p(res), _p(y2), _p(scale2), _p(shift2), _p(z), _p(bits), M, Cn,
+               int(relu), dt_code(y.dtype), stream_ptr())
+        return
     L.call("simt_bn_apply", _p(y), _p(scale), _p(shift), _p(res), _p(y2), _p(scale2), _p(shift2), _p(z), M, Cn,
            int(relu), dt_code(y.dtype), stream_ptr())
 

@@ -80,9 +80,14 @@ def test_bn_train_forward_backward(dev, dtype, Cn, B, H, W, mode):
         mean2, rstd2, scale2, shift2 = finalize(extra.detach(), g2, b2, None, None)
         y2_d = nhwc(extra.detach(), dev, dtype)
         kw = dict(y2=y2_d, scale2=scale2, shift2=shift2)
-    ops.bn_apply(y_d, scale, shift, z_d, M=M, Cn=Cn, relu=True, **kw)
+    bits = torch.zeros(M, Cn // 8, device=dev, dtype=torch.uint8)
+    ops.bn_apply(y_d, scale, shift, z_d, M=M, Cn=Cn, relu=True, bits=bits, **kw)
     torch.cuda.synchronize()
     assert rel(nchw(z_d), z.detach()) < tol
+    # the bit mask is exactly (z > 0) of the stored activation: bit (c & 7) of byte (m*Cn + c) / 8
+    zb = (z_d.reshape(M, Cn // 8, 8).float() > 0).to(torch.int32)
+    want = (zb << torch.arange(8, device=dev, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    assert torch.equal(bits, want)
     assert rel(rm_d.cpu(), rm_ref) < 1e-5 and rel(rv_d.cpu(), rv_ref) < 1e-5
 
     dz_d = nhwc(dz, dev, dtype)
@@ -104,6 +109,14 @@ def test_bn_train_forward_backward(dev, dtype, Cn, B, H, W, mode):
                                  dy=dy_d, M=M, Cn=Cn, mask_mode=2)
     ops.bn_bwd_desc(d)
     torch.cuda.synchronize()
+    if mode in ("downsample", "residual"):
+        # mask_mode 3 (bit mask instead of z) gives bit-identical results to mask_mode 1
+        first = [t.clone() for t in (dy_d, gout)] + ([dy2_d.clone()] if mode == "downsample" else [])
+        d.z, d.mask_mode = bits.data_ptr(), 3
+        ops.bn_bwd_desc(d)
+        torch.cuda.synchronize()
+        again = [dy_d, gout] + ([dy2_d] if mode == "downsample" else [])
+        assert all(torch.equal(a, b) for a, b in zip(first, again))
     # bf16: the mask is taken from the bf16-rounded z, a handful of borderline elements may flip
     assert rel(nchw(dy_d), yr.grad) < (tol if dtype == torch.float32 else 0.1)
     if mode == "residual":
