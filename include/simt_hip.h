@@ -49,6 +49,9 @@ typedef struct {
   const void* mask;    /* [B*Ho*Wo][ldm] dtype_in or NULL: the result is zeroed where mask <= 0 (ReLU backward of the layer
                         * whose output this gradient belongs to; used by the BN-free VGG trunk, model/deeplab_vgg.py) */
   int32_t ldm;
+  const unsigned char* res_bits; /* or NULL: res[m][n] only counts where bit (n & 7) of res_bits[(m*ldr + n) / 8] is set -- the
+                                  * identity-shortcut gradient dz * (z > 0) of a residual block (model/deeplab_multi.py:97-100)
+                                  * taken straight from dz and the bit mask of simt_bn_apply_bits, never materialised */
 } simt_conv_desc;
 int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);
 /* which kernel instantiation simt_conv_fprop runs for d: returns 0 (conv_igemm_kernel) or 2 (conv_igemm2_kernel<bn,tm,nst>) */

@@ -23,7 +23,8 @@ class ConvDesc(C.Structure):
                 ("B", i32), ("H", i32), ("W", i32), ("Cin", i32), ("Ho", i32), ("Wo", i32), ("Cout", i32),
                 ("Npad", i32), ("Nstore", i32), ("ldy", i32), ("ldr", i32), ("stride", i32), ("ntaps", i32),
                 ("relu", i32), ("dtype_in", i32), ("dtype_out", i32), ("tile_n", i32),
-                ("dy", C.c_int16 * MAX_TAPS), ("dx", C.c_int16 * MAX_TAPS), ("mask", c_p), ("ldm", i32)]
+                ("dy", C.c_int16 * MAX_TAPS), ("dx", C.c_int16 * MAX_TAPS), ("mask", c_p), ("ldm", i32),
+                ("res_bits", c_p)]
 
 
 class WgradDesc(C.Structure):

@@ -39,6 +39,7 @@ struct ConvKArgs {
   float* stats;
   const char* zero;
   const void* mask;
+  const unsigned char* res_bits;
   int ldm;
   int B, H, W, Cin, Ho, Wo, Cout, Nstore, ldy, ldr, stride, ntaps, relu, M;
   int kc_per_tap;  // Cin*sizeof(T)/128
@@ -237,6 +238,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKArgs a) {
       if (a.res) {
         float rv[8];
         load8((const T*)a.res + (long)m * a.ldr + n, rv);
+        if (a.res_bits) {
+          const unsigned b = a.res_bits[((long)m * a.ldr + n) >> 3];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rv[e] = ((b >> e) & 1u) ? rv[e] : 0.f;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += rv[e];
       }
@@ -289,7 +295,7 @@ extern "C" int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream) {
   ConvKArgs k;
   k.x = (const char*)d->x; k.w = (const char*)d->w; k.y = d->y; k.bias = d->bias; k.res = d->res;
   k.stats = d->stats; k.zero = (const char*)simt_zero_page();
-  k.mask = d->mask; k.ldm = d->ldm;
+  k.mask = d->mask; k.ldm = d->ldm; k.res_bits = d->res_bits;
   k.B = d->B; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
   k.Nstore = d->Nstore; k.ldy = d->ldy; k.ldr = d->ldr; k.stride = d->stride; k.ntaps = d->ntaps;
   k.relu = d->relu; k.M = d->B * d->Ho * d->Wo;

@@ -30,6 +30,7 @@ struct Conv2KArgs {
   const float* bias;
   const bf16_t* res;
   const bf16_t* mask;
+  const unsigned char* res_bits;
   float* stats;
   const char* zero;
   int H, W, Ho, Wo, Cout, Nstore, ldy, ldr, stride, ntaps, relu, M;
@@ -296,6 +297,11 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
           if (a.res) {
             float rv[8];
             load8(a.res + (long)m * a.ldr + n, rv);
+            if (a.res_bits) {
+              const unsigned b = a.res_bits[((long)m * a.ldr + n) >> 3];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) rv[e] = ((b >> e) & 1u) ? rv[e] : 0.f;
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += rv[e];
           }
@@ -427,7 +433,7 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
   Conv2KArgs k;
   k.x = (const char*)d->x; k.w = (const char*)d->w; k.y = (bf16_t*)d->y; k.bias = d->bias; k.res = (const bf16_t*)d->res;
   k.stats = d->stats; k.zero = (const char*)simt_zero_page();
-  k.mask = (const bf16_t*)d->mask; k.ldm = d->ldm;
+  k.mask = (const bf16_t*)d->mask; k.ldm = d->ldm; k.res_bits = d->res_bits;
   k.out_f32 = d->dtype_out == SIMT_F32;
   if (k.out_f32) SIMT_CHECK(!d->bias && !d->res && !d->relu && !d->stats && d->Nstore % 4 == 0 && d->ldy % 4 == 0);
   k.H = d->H; k.W = d->W; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout; k.Nstore = d->Nstore; k.ldy = d->ldy; k.ldr = d->ldr;

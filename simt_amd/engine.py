@@ -317,13 +317,13 @@ class TrunkPlan:
 
     # ------------------------------------------------------------------ forward construction
     def _conv(self, lst, x, wp_info, y, *, Bn, Hi, Wi, Cin, Ho, Wo, Cout, taps, stride=1, bias=None, res=None, stats=None,
-              relu=False, ldy=None, Nstore=None, alg_k=None, alg_flops=None, mask=None):
+              relu=False, ldy=None, Nstore=None, alg_k=None, alg_flops=None, mask=None, res_bits=None):
         """alg_k: algorithmic reduction length per output element (defaults to ntaps*Cin; the K-padded head dgrad and
         the stem pass their true value) -> algorithmic FLOPs = 2 * M * Cout * alg_k."""
         wp, tile, npad = wp_info
         d = ops.make_conv_desc(x, wp, y, B=Bn, H=Hi, W=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, taps=taps, stride=stride,
                                bias=bias, res=res, stats=stats, relu=relu, Npad=npad, tile_n=tile, ldy=ldy,
-                               Nstore=Nstore, mask=mask)
+                               Nstore=Nstore, mask=mask, res_bits=res_bits)
         M = Bn * Ho * Wo
         k = alg_k if alg_k is not None else len(taps) * Cin
         tn = {torch.bfloat16: "bf16", torch.float32: "f32"}
@@ -697,11 +697,11 @@ class TrunkPlan:
                 b.wait(last_side[par], 0)
             # ---- z = relu(bn3(y3) + shortcut)
             dy3 = self.buf("g.dy3.%d" % par, Mo, c4)
-            g = self.buf("g.g", Mo, c4)
             dyd = self.buf("g.dyd.%d" % par, Mo, c4) if down else None
+            # identity blocks: the shortcut gradient dz * (z > 0) is never written -- the conv that produces dx adds dz under
+            # the bit mask (simt_conv_desc.res_bits)
             self._bn_bwd(b, dz=dz, z=rec["zbits"], y=rec["y3"], bname=f"{name}.bn3", dy=dy3, M=Mo, Cn=c4, mask_mode=3,
-                         y2=rec.get("yd"), bname2=f"{name}.downsample.1" if down else None, dy2=dyd,
-                         gout=None if down else g)
+                         y2=rec.get("yd"), bname2=f"{name}.downsample.1" if down else None, dy2=dyd)
             # conv3
             b.wait(b.record(0), 1)
             self._wgrad(b, dy3, rec["a2"], None, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4, taps=[(0, 0)],
@@ -741,10 +741,11 @@ class TrunkPlan:
                     wtd = self._plan_pack_t(f"{name}.downsample.0", c4, inpl, 1)
                     dxd = self.buf("g.dxd", Mo, inpl)
                     self._conv(b, dyd, wtd[:3], dxd, Bn=B, Hi=Ho, Wi=Wo, Cin=c4, Ho=Ho, Wo=Wo, Cout=inpl, taps=[(0, 0)])
-                    res = dxd
+                    res, rbits = dxd, None
                 else:
-                    res = g
-                self._conv(b, dy1, wt1[:3], dx, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cout=inpl, taps=[(0, 0)], res=res)
+                    res, rbits = dz, rec["zbits"]
+                self._conv(b, dy1, wt1[:3], dx, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cout=inpl, taps=[(0, 0)], res=res,
+                           res_bits=rbits)
             else:
                 assert down
                 wtd = self._plan_pack_t(f"{name}.downsample.0", c4, inpl, 1)

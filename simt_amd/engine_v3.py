@@ -352,10 +352,9 @@ class V3Plan(TrunkPlan):
             c4 = 4 * p
             blk_start = len(b)
             dy3 = self.new(Mo, c4)
-            g = None if down else self.new(Mo, c4)
             dyd = self.new(Mo, c4) if down else None
             self._bnb(b, dz=dz, z=rec["zbits"], y=rec["y3"], bname=name + ".bn3", dy=dy3, M=Mo, Cn=c4, mask_mode=3, y2=rec.get("yd"),
-                      bname2=name + ".downsample.1" if down else None, dy2=dyd, gout=g)
+                      bname2=name + ".downsample.1" if down else None, dy2=dyd)
             b.wait(b.record(0), 1)
             self._wgrad(b, dy3, rec["a2"], None, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4, taps=[(0, 0)], stride=1,
                         parts=[(name + ".conv3.weight", 0, 0, c4, 1, p)])
@@ -395,12 +394,13 @@ class V3Plan(TrunkPlan):
                 if stride != 1:
                     res = self.new(Mi, inpl)
                     b.add("simt_scatter_stride", dxd.data_ptr(), res.data_ptr(), B, Hi, Wi, inpl, Ho, Wo, stride, ops.dt_code(dt))
-            else:
-                res = g
+                rbits = None
+            else:           # identity shortcut: dz under the block-output ReLU bit mask, added by the conv epilogue
+                res, rbits = dz, rec["zbits"]
             wt1 = self._plan_pack_t(name + ".conv1", p, inpl, 1)
             assert wt1[3] == p
             dx = self.new(Mi, inpl)
-            self._conv(b, dy1, wt1[:3], dx, Bn=B, Hi=Hi, Wi=Wi, Cin=p, Ho=Hi, Wo=Wi, Cout=inpl, taps=[(0, 0)], res=res)
+            self._conv(b, dy1, wt1[:3], dx, Bn=B, Hi=Hi, Wi=Wi, Cin=p, Ho=Hi, Wo=Wi, Cout=inpl, taps=[(0, 0)], res=res, res_bits=rbits)
             self.bwd_marks[name] = (blk_start, len(b), dz, dx)
             rec.update(g_dy3=dy3, g_da2=da2, g_dy2=dy2, g_da1=da1, g_dy1=dy1, g_dx=dx, g_dz=dz)
             dz = dx

@@ -65,7 +65,7 @@ def packed_rows(cout, tile_n=None, dtype=None):
 
 
 def make_conv_desc(x, w, y, *, B, H, W, Cin, Ho, Wo, Cout, taps, stride=1, bias=None, res=None, stats=None, relu=False,
-                   Npad=None, Nstore=None, ldy=None, ldr=None, tile_n=None, mask=None, ldm=None):
+                   Npad=None, Nstore=None, ldy=None, ldr=None, tile_n=None, mask=None, ldm=None, res_bits=None):
     d = L.ConvDesc()
     tile_n = tile_n or pick_tile_n(Cout, x.dtype if x.dtype == y.dtype else None)
     d.x, d.w, d.y = _p(x), _p(w), _p(y)
@@ -80,6 +80,7 @@ def make_conv_desc(x, w, y, *, B, H, W, Cin, Ho, Wo, Cout, taps, stride=1, bias=
     _fill_taps(d.dy, d.dx, taps)
     d.mask = _p(mask)
     d.ldm = ldm if ldm is not None else (mask.shape[-1] if mask is not None else 0)
+    d.res_bits = _p(res_bits)
     return d
 
 

@@ -153,6 +153,17 @@ def test_conv_epilogue_bias_res_relu_and_aspp_taps(dev, dtype):
     torch.cuda.synchronize()
     assert _rel(z_d.float().cpu().permute(0, 3, 1, 2), ref) < _tol(dtype)
 
+    # residual counted only where a bit mask is set (identity-shortcut gradient dz * (z > 0), simt_conv_desc.res_bits)
+    keep = torch.rand(B, 64, H, W, generator=g) > 0.4
+    ref = ops_ref.conv2d(xq, w1.to(dtype).float(), bb) + r.to(dtype).float() * keep
+    kb = keep.permute(0, 2, 3, 1).reshape(-1, 8, 8).to(torch.int32)                      # [M, 64/8, 8]
+    bits = (kb << torch.arange(8, dtype=torch.int32)).sum(-1).to(torch.uint8).to(dev)
+    d = ops.make_conv_desc(x_d, wp1, z_d, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=64, taps=[(0, 0)], bias=bb.to(dev),
+                           res=r_d, res_bits=bits)
+    ops.conv_fprop_desc(d)
+    torch.cuda.synchronize()
+    assert _rel(z_d.float().cpu().permute(0, 3, 1, 2), ref) < _tol(dtype)
+
 
 def test_tap_expanded_head_kernels(dev):
     """bf16 throughput form of the ASPP classifier (csrc/head_expand.hip): P = x @ Wexp^T (fp32 out of the bf16 GEMM),
