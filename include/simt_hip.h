@@ -54,7 +54,9 @@ typedef struct {
                                   * taken straight from dz and the bit mask of simt_bn_apply_bits, never materialised */
 } simt_conv_desc;
 int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);
-/* which kernel instantiation simt_conv_fprop runs for d: returns 0 (conv_igemm_kernel) or 2 (conv_igemm2_kernel<bn,tm,nst>) */
+/* which kernel instantiation simt_conv_fprop runs for d: returns 0 (conv_igemm_kernel), 2 (conv_igemm2_kernel<bn,tm,nst>)
+ * or 3 (conv1x1_nloop_kernel<tm>: resident pixel panel, loop over the column tiles; tm = Cin / 64; experimental, only
+ * with the environment variable SIMT_CONV_NLOOP=1) */
 int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int* nst);
 
 /* ---- convolution: wgrad (split-K over pixels, transposed MFMA operands) -------------------------------

@@ -399,6 +399,7 @@ static void pick_rows(int M, int ntn, bool allow160, int* rows, int* tm) {
   }
 }
 
+bool simt_conv_nloop_eligible(const simt_conv_desc* d);   // conv1x1_nloop.hip
 struct Conv2Variant { int tile_n, tm, nst, rows, ntiles_n; };
 static Conv2Variant pick_variant(const simt_conv_desc* d) {
   Conv2Variant v;
@@ -423,6 +424,10 @@ extern "C" int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int*
   const bool v2 = d->dtype_in == SIMT_BF16 && d->tile_n >= 64 &&
                   (d->dtype_out == SIMT_BF16 || (!d->bias && !d->res && !d->relu && !d->stats && !d->mask && d->tile_n == 256));
   if (!v2) { *bn = d->tile_n; *tm = 0; *nst = 2; return 0; }
+  {
+    const char* e = getenv("SIMT_CONV_NLOOP");
+    if (e && e[0] == '1' && simt_conv_nloop_eligible(d)) { *bn = 256; *tm = d->Cin / 64; *nst = 2; return 3; }   // conv1x1_nloop_kernel<K/64>
+  }
   const Conv2Variant v = pick_variant(d);
   *bn = v.tile_n; *tm = v.tm; *nst = v.nst;
   return 2;
