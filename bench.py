@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--skip-unapplied-grads", action="store_true",
+                    help="stop the backward at layer3 (the gradients of conv1/layer1/layer2 are never applied by the SimT stage); "
+                         "NOT the headline configuration: the default computes everything the reference's iteration computes")
     ap.add_argument("--shapes", action="store_true", help="print a per-shape conv timing table to stderr")
     ap.add_argument("--cpu-size", type=int, default=768, help="H=W of the CPU-baseline sample (B=1)")
     return ap.parse_args()
@@ -98,7 +101,7 @@ def main():
     cd = ms.load_class_dist("bapa")
     st = ms.reference_init(ms.state_shapes(19, K, True), seed=1234)
     fst = ms.reference_init(ms.state_shapes(19, 0, False), seed=1234)
-    hp = Hyper(open_classes=K, lr=6e-4, lr_T=6e-3)       # sh_simt.sh:16
+    hp = Hyper(open_classes=K, lr=6e-4, lr_T=6e-3, skip_unapplied_grads=a.skip_unapplied_grads)       # sh_simt.sh:16
     tr = SimTTrainer(st, fst, ms.ntm_init(19, K, 1), ms.ntm_init(19, K, 2), hp, cd, a.batch, H, W, dtype=dtype, device=dev,
                      process_group=pg)
     img, lab = ms.synthetic_batch(a.batch, H, W, cd, seed=1234 + rank, device=dev)
@@ -170,7 +173,8 @@ def main():
                 "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                 "config": {"workload": f"DeepLabv2-ResNet101 + SimT(C=19,K={K}) full training iteration, batch={a.batch}/GPU, "
-                                       f"{H}x{W}, {a.dtype}, {world}xMI355X" + (" DP RCCL all-reduce" if world > 1 else ""),
+                                       f"{H}x{W}, {a.dtype}, {world}xMI355X" + (" DP RCCL all-reduce" if world > 1 else "")
+                                       + (" [backward stops at layer3: unapplied gradients skipped]" if a.skip_unapplied_grads else ""),
                            "global_batch": a.batch * world, "baseline_config": "configs[1]" if world == 1 else "configs[2]",
                            "step_tflops_conv_algorithmic": round(value * flop_img / 1e12, 1),
                            "frac_of_conv_roofline": round(value * flop_img / 1e12 / (world * MFMA_PEAK_TFLOPS[a.dtype]), 4)},

@@ -231,13 +231,17 @@ class TrunkPlan:
     """
 
     def __init__(self, params, B, H, W, heads, *, dtype=torch.bfloat16, train=True, layers=LAYERS, device=None,
-                 need_input_grads=True, grad_names=None):
+                 need_input_grads=True, grad_names=None, grads_from_layer=0):
         self.p = params
         self.B, self.H, self.W = B, H, W
         self.heads = heads
         self.dtype = dtype
         self.train = train
         self.layers = layers
+        # 0: every gradient autograd would compute (the reference's behaviour).  3: stop the backward at the input of layer3 --
+        # the SimT stage never applies the gradients of conv1 / layer1 / layer2 (optim_parameters lists layer3, layer4 and the
+        # heads only, model/deeplab_multi.py:194-237), so the trajectory is identical; see Hyper.skip_unapplied_grads.
+        self.grads_from_layer = grads_from_layer
         self.dev = device or next(iter(params.values())).device
         self.esz = 2 if dtype == torch.bfloat16 else 4
         self.kq = 128 // self.esz            # channel quantum of the K dimension (one 128-B stage)
@@ -687,6 +691,9 @@ class TrunkPlan:
             c4 = 4 * p
             Ho, Wo, Hi, Wi, stride, dil, down = rec["Ho"], rec["Wo"], rec["Hi"], rec["Wi"], rec["stride"], rec["dil"], rec["down"]
             li = int(name[5])
+            if li < self.grads_from_layer:
+                break
+            first_needed = (li == self.grads_from_layer and bi == sum(self.layers[:li - 1]) and self.grads_from_layer > 0)
             last_of_layer = (bi + 1 == sum(self.layers[:li]))
             if last_of_layer and li in heads_by_layer:
                 for hd in heads_by_layer[li]:
@@ -733,6 +740,9 @@ class TrunkPlan:
                 self._wgrad(b, dyd, rec["x"], None, Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4,
                             taps=[(0, 0)], stride=stride, parts=[(f"{name}.downsample.0.weight", 0, 0, c4, 1, inpl)])
             last_side[par] = b.record(1)
+            if first_needed:          # nothing below this block needs a gradient
+                self.bwd_marks[name] = (blk_start, len(b), dz, None)
+                continue
             # input gradient
             wt1 = self._plan_pack_t(f"{name}.conv1", p, inpl, 1)
             assert wt1[3] == p
@@ -757,6 +767,11 @@ class TrunkPlan:
                 b.add("simt_scatter_stride", dxl.data_ptr(), dx.data_ptr(), B, Hi, Wi, inpl, Ho, Wo, stride, ops.dt_code(dt))
             self.bwd_marks[name] = (blk_start, len(b), dz, dx)
             dz = dx
+        if self.grads_from_layer > 0:
+            for n in self.grads:                   # never written: final (zero) from the start, for the DP bucket schedule
+                self.grad_ready.setdefault(n, 0)
+            b.wait(b.record(1), 0)
+            return
         # ---- stem: maxpool -> relu/bn -> conv1 wgrad (computed like the reference does)
         H0, W0, Hp, Wp = self.H0, self.W0, self.Hp, self.Wp
         da0 = self.buf("g.da0", M0, 64)

@@ -30,7 +30,11 @@ class Hyper:
 
     def __init__(self, num_classes=19, open_classes=15, th_high=0.8, th_low=0.2, lambda_seg=0.1, lambda_place=0.1,
                  lambda_convex=0.5, lambda_volume=0.1, lambda_anchor=0.5, iter_size=1, lr=2.5e-4, lr_T=2.5e-4,
-                 momentum=0.9, weight_decay=5e-4, power=0.9, num_steps=250000):
+                 momentum=0.9, weight_decay=5e-4, power=0.9, num_steps=250000, skip_unapplied_grads=False):
+        # skip_unapplied_grads: stop the backward at the input of layer3.  The reference's autograd also produces the gradients of
+        # conv1 / layer1 / layer2, which its SGD never lists (model/deeplab_multi.py:194-237) and zero_grad() discards; with this
+        # switch they are not computed -- identical parameter trajectory and losses, less work.  Off by default (and in bench.py):
+        # the default does everything the reference's iteration does.
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -70,7 +74,8 @@ class SimTTrainer:
         self.fixed_params = {k: v.detach().to(dev, f32 if v.dtype != torch.long else torch.long).clone()
                              for k, v in fixed_state.items()}
         kw = {"layers": layers} if layers is not None else {}
-        self.plan = TrunkPlan(self.params, B, H, W, multi_heads(Cn, K, openset), dtype=dtype, train=True, **kw)
+        self.plan = TrunkPlan(self.params, B, H, W, multi_heads(Cn, K, openset), dtype=dtype, train=True,
+                              grads_from_layer=3 if getattr(hp, "skip_unapplied_grads", False) else 0, **kw)
         self.fixed = TrunkPlan(self.fixed_params, B, H, W, multi_heads(Cn, 0, False), dtype=dtype, train=False, **kw)
         h, w = self.plan.heads[1].h, self.plan.heads[1].w
         self.h, self.w = h, w

@@ -248,3 +248,28 @@ def test_warmup_gradient_accumulation_iter_size2(dev):
         v, p64 = tr.params[k].detach().cpu().double(), truth.st[k].detach()
         e_ref = (ref32.st[k].detach().double() - p64).abs().max().item()
         assert (v - p64).abs().max().item() < 3 * e_ref + 5e-6, (k, e_ref)
+
+
+def test_skip_unapplied_grads_same_trajectory(dev):
+    """Hyper.skip_unapplied_grads stops the backward at the input of layer3 (the SimT stage never applies the gradients of conv1 /
+    layer1 / layer2): losses and EVERY parameter after two iterations are bit-identical to the full backward."""
+    layers = (1, 1, 2, 1)
+    K, B, H, W = 3, 2, 65, 65
+    st = so.recipe_state(so.state_shapes(19, K, True, layers=layers), seed=2024, head_scale=8.0)
+    fst = so.recipe_state(so.state_shapes(19, 0, False, layers=layers), seed=2025, head_scale=8.0)
+    runs = []
+    for skip in (False, True):
+        hp = Hyper(open_classes=K, lambda_convex=0.1, lambda_volume=1.0, lambda_anchor=1.0, lr=6e-4, lr_T=6e-3, skip_unapplied_grads=skip)
+        tr = SimTTrainer(st, fst, so.ntm_init(19, K, 911), so.ntm_init(19, K, 912), hp, CD, B, H, W, dtype=torch.float32, device=dev,
+                         layers=layers)
+        ls = []
+        for it in range(2):
+            img, lab = so.synthetic_batch(B, H, W, CD.numpy(), seed=700 + it, block=8)
+            tr.step(img.to(dev), lab.to(dev), it)
+            ls.append(tr.lout.clone())
+        runs.append((ls, {k: v.clone() for k, v in tr.params.items()}, [n.clone() for n in tr.ntm], len(tr.plan.bwd_list)))
+    (l0, p0, n0, len0), (l1, p1, n1, len1) = runs
+    assert len1 < len0
+    assert all(torch.equal(a, b) for a, b in zip(l0, l1))
+    assert all(torch.equal(p0[k], p1[k]) for k in p0)
+    assert all(torch.equal(a, b) for a, b in zip(n0, n1))
