@@ -45,22 +45,23 @@ struct Conv2KArgs {
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N <= 8, "unsupported vmcnt");
+  static_assert(N >= 0 && N <= 16, "unsupported vmcnt");
+#define SIMT_VMCNT_CASE(K) else if constexpr (N == K) asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory")
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  SIMT_VMCNT_CASE(1); SIMT_VMCNT_CASE(2); SIMT_VMCNT_CASE(3); SIMT_VMCNT_CASE(4); SIMT_VMCNT_CASE(5); SIMT_VMCNT_CASE(6);
+  SIMT_VMCNT_CASE(7); SIMT_VMCNT_CASE(8); SIMT_VMCNT_CASE(9); SIMT_VMCNT_CASE(10); SIMT_VMCNT_CASE(11); SIMT_VMCNT_CASE(12);
+  SIMT_VMCNT_CASE(13); SIMT_VMCNT_CASE(14); SIMT_VMCNT_CASE(15); SIMT_VMCNT_CASE(16);
+#undef SIMT_VMCNT_CASE
 }
 
 // MODE 0 = product.  MODE 1 (loads only) and MODE 2 (MFMA only) are timing-ablation builds selected by the environment
 // variable SIMT_CONV2_MODE; their outputs are meaningless.
-template <int BN, int TMP, int NSTP, int MODE>
-__global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(Conv2KArgs a) {
+// LW = 4: wave specialisation (experiment, off by default).  Four extra waves (one per SIMD) do nothing but fill the ring; the
+// eight consumer waves never issue a global_load_lds and never wait on vmcnt.  NST = 3 variants only.  Measured on MI355X
+// (scratch/convbench.py): 3x3 256->256 51.6 us vs 47.6 us for the default build, 1x1 shapes unchanged -- four waves issue the
+// 13 pieces per stage more slowly than eight waves issue 7 each; the fill path is bound by per-wave issue, not by the consumers.
+template <int BN, int TMP, int NSTP, int MODE, int LW = 0>
+__global__ __launch_bounds__(512 + LW * 64, (LW ? 1 : (NSTP == 2 ? 4 : 2))) void conv_igemm2_kernel(Conv2KArgs a) {
   constexpr int NT = 512, NST = NSTP;   // NST = 3: one workgroup per CU, two stages in flight; NST = 2 (short-K, output-
                                         // bound shapes): two workgroups per CU so one's epilogue overlaps the other's loads
   constexpr int WM = (BN == 64) ? 4 : 2;          // waves along pixels
@@ -83,6 +84,79 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
   const int mt = tile / a.ntiles_n, nt = tile - mt * a.ntiles_n;
   const int m0 = mt * a.rows, n0 = nt * BN;
   const int m_end = min(a.M, m0 + a.rows);
+
+  if constexpr (LW > 0) {
+    static_assert(NSTP == 3, "loader waves: 3-slot ring only");
+    if (wave >= 8) {
+      // ================= loader waves: piece q = i*NL + ltid -> row q>>3, 16-B position q&7 (same swizzle as below)
+      constexpr int NL = LW * 64;
+      constexpr int A_ITL = BM * 8 / NL, B_ITL = BN * 8 / NL;
+      static_assert((BM * 8) % NL == 0 && (BN * 8) % NL == 0 && A_ITL + B_ITL <= 16, "piece counts");
+      const int ltid = tid - NT, lw = wave - 8;
+      const int lcg = (ltid & 7) ^ (((ltid >> 3) >> 1) & 7);     // NL/8 = 32 rows per pass: a multiple of 16, key unchanged
+      unsigned la_off[A_ITL];
+      unsigned long long la_ok[A_ITL];
+#pragma unroll
+      for (int i = 0; i < A_ITL; ++i) {
+        const int m = m0 + i * (NL / 8) + (ltid >> 3);
+        la_ok[i] = 0ull;
+        la_off[i] = 0u;
+        if (m < m_end) {
+          const int hw = a.Ho * a.Wo;
+          const int b = m / hw;
+          const int r = m - b * hw;
+          const int oy = r / a.Wo;
+          const int ox = r - oy * a.Wo;
+          const int iy = oy * a.stride, ix = ox * a.stride;
+          la_off[i] = (unsigned)(((b * a.H + iy) * a.W + ix)) * (unsigned)a.pix_bytes + (unsigned)(lcg * 16);
+          unsigned long long msk = 0ull;
+          for (int t = 0; t < a.ntaps; ++t) {
+            const int yy = iy + a.dy[t], xx = ix + a.dx[t];
+            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) msk |= (1ull << t);
+          }
+          la_ok[i] = msk;
+        }
+      }
+      unsigned lb_off[B_ITL];
+#pragma unroll
+      for (int i = 0; i < B_ITL; ++i)
+        lb_off[i] = (unsigned)(n0 + i * (NL / 8) + (ltid >> 3)) * (unsigned)a.wrow_bytes + (unsigned)(lcg * 16);
+      const char* lz = a.zero + lcg * 16;
+      int l_tap = 0, l_kc = 0, l_kt = 0;
+      auto lissue = [&](int buf) {
+        const int toff = a.toff[l_tap] + l_kc * 128;
+        char* sbase = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_ITL; ++i) {
+          const bool ok = (la_ok[i] >> l_tap) & 1ull;
+          const char* src = ok ? a.x + (unsigned)(la_off[i] + (unsigned)toff) : lz;
+          __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sbase + (i * NL + lw * 64) * 16), 16, 0, 0);
+        }
+        const unsigned wk = (unsigned)l_kt * 128u;
+#pragma unroll
+        for (int i = 0; i < B_ITL; ++i)
+          __builtin_amdgcn_global_load_lds(GPTR(a.w + (lb_off[i] + wk)), LPTR(sbase + A_BYTES + (i * NL + lw * 64) * 16), 16, 0, 0);
+        ++l_kt;
+        if (++l_kc == a.kc_per_tap) { l_kc = 0; ++l_tap; }
+      };
+      const int nkl = a.ntaps * a.kc_per_tap;
+      lissue(0);
+      if (nkl > 1) lissue(1);
+      int lbuf = 0;
+      for (int kt = 0; kt < nkl; ++kt) {
+        if (kt + 1 < nkl) wait_vmcnt<A_ITL + B_ITL>(); else wait_vmcnt<0>();   // stage kt landed, stage kt+1 may be in flight
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkl) lissue(lbuf >= 1 ? lbuf - 1 : 2);                     // slot (kt+2)%3: read by everybody in step kt-1
+        lbuf = (lbuf + 1 == 3) ? 0 : lbuf + 1;
+      }
+      if (!a.out_f32) {            // mirror the consumers' epilogue barriers (tile write, tile read, statistics)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+        if (a.stats) __builtin_amdgcn_s_barrier();
+      }
+      return;
+    }
+  }
 
   // ---- hoisted A-gather metadata: chunk q = i*NT + tid -> row = q>>3, position q&7
   const int c_pos = tid & 7;
@@ -183,7 +257,7 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][j], xf[s][i], acc[j][i], 0, 0, 0);
   };
 
-  if (MODE != 2) {
+  if (MODE != 2 && LW == 0) {
     issue(0);
     if (NST == 3 && nk > 1) issue(1);
   }
@@ -191,12 +265,12 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
   if (wave < 4) {
     // ---- early half: [barrier] issue(kt+2) -> fragments(kt) -> MFMA(kt)
     for (int kt = 0; kt < nk; ++kt) {
-      if (MODE != 2) wait_stage(kt + 1 < nk);
+      if (MODE != 2 && LW == 0) wait_stage(kt + 1 < nk);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if constexpr (MODE == 0 || MODE == 11 || MODE == 13) {
         load_frags(buf);
-        if (kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
+        if (LW == 0 && kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
         if (MODE == 13) __builtin_amdgcn_s_setprio(1);
         mma();
         if (MODE == 13) __builtin_amdgcn_s_setprio(0);
@@ -214,7 +288,7 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
   } else {
     // ---- late half: [barrier] MFMA(kt-1) from registers -> issue(kt+2) -> fragments(kt) (kept for the next stage)
     for (int kt = 0; kt < nk; ++kt) {
-      if (MODE != 2) wait_stage(kt + 1 < nk);
+      if (MODE != 2 && LW == 0) wait_stage(kt + 1 < nk);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my fragment reads of stage kt-1 are done before anyone refills
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -223,7 +297,7 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
         mma();
         if (MODE == 12 || MODE == 13) __builtin_amdgcn_s_setprio(0);
       }
-      if (MODE != 2 && kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
+      if (MODE != 2 && LW == 0 && kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
       if (MODE != 1) load_frags(buf);
       buf = (buf + 1 == NST) ? 0 : buf + 1;
     }
@@ -352,7 +426,7 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
   }
 }
 
-template <int BN, int TM, int NST, int MODE>
+template <int BN, int TM, int NST, int MODE, int LW = 0>
 static int launch_conv2m(const Conv2KArgs& k, hipStream_t st) {
   constexpr int WM = (BN == 64) ? 4 : 2;
   constexpr int BM = WM * TM * 16;
@@ -361,15 +435,20 @@ static int launch_conv2m(const Conv2KArgs& k, hipStream_t st) {
   const size_t lds = ring > epi ? ring : epi;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm2_kernel<BN, TM, NST, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_igemm2_kernel<BN, TM, NST, MODE, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm2_kernel<BN, TM, NST, MODE>), dim3(k.ntiles_m * k.ntiles_n), dim3(512), lds, st, k);
+  hipLaunchKernelGGL((conv_igemm2_kernel<BN, TM, NST, MODE, LW>), dim3(k.ntiles_m * k.ntiles_n), dim3(512 + LW * 64), lds, st, k);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
 
 #include <stdlib.h>
+static int conv2_loader_waves() {          // SIMT_CONV2_LW=1 selects the wave-specialised build (experiment, see the kernel's LW note)
+  static int lw = -1;
+  if (lw < 0) { const char* e = getenv("SIMT_CONV2_LW"); lw = (e && e[0] == '1') ? 1 : 0; }
+  return lw;
+}
 template <int BN, int TM, int NST = 3>
 static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
   static int mode = -1;
@@ -382,6 +461,9 @@ static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
   if (mode == 11) return launch_conv2m<BN, TM, NST, 11>(k, st);
   if (mode == 12) return launch_conv2m<BN, TM, NST, 12>(k, st);
   if (mode == 13) return launch_conv2m<BN, TM, NST, 13>(k, st);
+  if constexpr (NST == 3) {
+    if (conv2_loader_waves()) return launch_conv2m<BN, TM, NST, 0, 4>(k, st);
+  }
   return launch_conv2m<BN, TM, NST, 0>(k, st);
 }
 
