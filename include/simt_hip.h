@@ -52,12 +52,25 @@ typedef struct {
   const unsigned char* res_bits; /* or NULL: res[m][n] only counts where bit (n & 7) of res_bits[(m*ldr + n) / 8] is set -- the
                                   * identity-shortcut gradient dz * (z > 0) of a residual block (model/deeplab_multi.py:97-100)
                                   * taken straight from dz and the bit mask of simt_bn_apply_bits, never materialised */
+  /* Fused first pass of the BatchNorm backward (bf16 v2 kernel only; bnr_mode 0 = off).  When this launch PRODUCES the
+   * gradient dz of a BatchNorm-ed activation (it is the dgrad of the conv that consumed relu(bn(y)), or the dx of the next
+   * block), the epilogue also accumulates, on the values it stores, S1 = sum g and S2 = sum g*xhat with
+   * g = dz * mask, xhat = (y - mean) * rstd -- what bn_bwd_reduce_kernel would re-read dz for -- into
+   * bnr_part[m-tile][3][Cout] (third row zero); simt_bn_bwd then starts at its finalize (simt_bn_bwd_desc.reduce_done_nblk =
+   * simt_conv_mtiles(d)).  mask: bnr_mode 2 = y*scale+shift > 0, 3 = bit mask bnr_bits (simt_bn_apply_bits). */
+  const void* bnr_y;             /* [B*Ho*Wo][bnr_ld] dtype_in: the saved pre-BN activation */
+  const float *bnr_mean, *bnr_rstd, *bnr_scale, *bnr_shift;
+  const unsigned char* bnr_bits;
+  float* bnr_part;
+  int32_t bnr_mode, bnr_ld;
 } simt_conv_desc;
 int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);
 /* which kernel instantiation simt_conv_fprop runs for d: returns 0 (conv_igemm_kernel), 2 (conv_igemm2_kernel<bn,tm,nst>)
  * or 3 (conv1x1_nloop_kernel<tm>: resident pixel panel, loop over the column tiles; tm = Cin / 64; experimental, only
  * with the environment variable SIMT_CONV_NLOOP=1) */
 int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int* nst);
+/* number of pixel tiles (= statistics / bnr_part slots) the launch for d uses; 0 if d does not run on the bf16 v2 kernel */
+int simt_conv_mtiles(const simt_conv_desc* d);
 
 /* ---- convolution: wgrad (split-K over pixels, transposed MFMA operands) -------------------------------
  * slab[split][co][tap*Cin+ci] = sum_{m in split} dy[m][co] * x[pixel(m)*stride + (dy,dx)[tap]][ci]
@@ -130,6 +143,8 @@ typedef struct {
   int32_t C, mask_mode, dtype; /* mask_mode: 0 none, 1 z>0, 2 y*scale+shift>0, 3 z = bit mask of simt_bn_apply_bits */
   float *dgamma, *dbeta;   /* [C] or NULL: gradients of a TRAINABLE affine (model/deeplabv3.py's torchvision BatchNorm) */
   float *dgamma2, *dbeta2; /* same for the second BN (y2) */
+  int32_t reduce_done_nblk; /* > 0: `part` already holds that many [3][C] partial slots (written by the conv that produced dz,
+                             * simt_conv_desc.bnr_*): skip the reduce pass */
 } simt_bn_bwd_desc;
 int simt_bn_bwd_nblk(long M, int C);
 int simt_bn_bwd(const simt_bn_bwd_desc* d, simt_stream_t stream);

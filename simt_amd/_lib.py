@@ -24,7 +24,8 @@ class ConvDesc(C.Structure):
                 ("Npad", i32), ("Nstore", i32), ("ldy", i32), ("ldr", i32), ("stride", i32), ("ntaps", i32),
                 ("relu", i32), ("dtype_in", i32), ("dtype_out", i32), ("tile_n", i32),
                 ("dy", C.c_int16 * MAX_TAPS), ("dx", C.c_int16 * MAX_TAPS), ("mask", c_p), ("ldm", i32),
-                ("res_bits", c_p)]
+                ("res_bits", c_p), ("bnr_y", c_p), ("bnr_mean", c_p), ("bnr_rstd", c_p), ("bnr_scale", c_p), ("bnr_shift", c_p),
+                ("bnr_bits", c_p), ("bnr_part", c_p), ("bnr_mode", i32), ("bnr_ld", i32)]
 
 
 class WgradDesc(C.Structure):
@@ -38,7 +39,7 @@ class BnBwdDesc(C.Structure):
     _fields_ = [("dz", c_p), ("z", c_p), ("y", c_p), ("mean", c_p), ("rstd", c_p), ("scale", c_p), ("shift", c_p),
                 ("y2", c_p), ("mean2", c_p), ("rstd2", c_p), ("scale2", c_p), ("part", c_p), ("coef", c_p),
                 ("dy", c_p), ("dy2", c_p), ("gout", c_p), ("M", C.c_int64), ("C", i32), ("mask_mode", i32),
-                ("dtype", i32), ("dgamma", c_p), ("dbeta", c_p), ("dgamma2", c_p), ("dbeta2", c_p)]
+                ("dtype", i32), ("dgamma", c_p), ("dbeta", c_p), ("dgamma2", c_p), ("dbeta2", c_p), ("reduce_done_nblk", i32)]
 
 
 class HeadDesc(C.Structure):
@@ -82,6 +83,7 @@ SIGNATURES = {
     "simt_last_error": (C.c_char_p, []),
     "simt_abi_version": (_I, []),
     "simt_conv_fprop": (_I, [C.POINTER(ConvDesc), c_p]),
+    "simt_conv_mtiles": (_I, [C.POINTER(ConvDesc)]),
     "simt_conv_variant": (_I, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "simt_conv_wgrad": (_I, [C.POINTER(WgradDesc), c_p]),
     "simt_wgrad_reduce": (_I, [c_p, c_p, _I, _I, _I, _I, _I, _I, _I, _I, _I, c_p]),

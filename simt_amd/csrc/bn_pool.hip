@@ -326,9 +326,11 @@ extern "C" int simt_bn_bwd(const simt_bn_bwd_desc* d, simt_stream_t stream) {
   SIMT_CHECK(!d->y2 || (d->mean2 && d->rstd2 && d->scale2 && d->dy2));
   hipStream_t st = (hipStream_t)stream;
   const int rpb = bn_bwd_rows_per_block(d->M, d->C);
-  const int nblk = (int)((d->M + rpb - 1) / rpb);
+  const int nblk = d->reduce_done_nblk > 0 ? d->reduce_done_nblk : (int)((d->M + rpb - 1) / rpb);
   const long nvec = d->M * (d->C / 8);
-  if (d->dtype == SIMT_BF16) {
+  if (d->reduce_done_nblk > 0) {
+    SIMT_CHECK(!d->y2);     // the conv epilogue reduces for ONE BatchNorm (no downsample partner)
+  } else if (d->dtype == SIMT_BF16) {
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)d->dz,
                        (const bf16_t*)d->z, (const bf16_t*)d->y, d->mean, d->rstd, d->scale, d->shift,
                        (const bf16_t*)d->y2, d->mean2, d->rstd2, d->part, d->M, d->C, rpb, d->mask_mode);

@@ -31,6 +31,11 @@ struct Conv2KArgs {
   const bf16_t* res;
   const bf16_t* mask;
   const unsigned char* res_bits;
+  const bf16_t* bnr_y;                 // fused first pass of the BatchNorm backward (simt_conv_desc.bnr_*)
+  const float *bnr_mean, *bnr_rstd, *bnr_scale, *bnr_shift;
+  const unsigned char* bnr_bits;
+  float* bnr_part;
+  int bnr_mode, bnr_ld;
   float* stats;
   const char* zero;
   int H, W, Ho, Wo, Cout, Nstore, ldy, ldr, stride, ntaps, relu, M;
@@ -349,12 +354,59 @@ __global__ __launch_bounds__(512 + LW * 64, (LW ? 1 : (NSTP == 2 ? 4 : 2))) void
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = (a.bias && (n + e) < a.Cout) ? a.bias[n + e] : 0.f;
     const bool plain = !a.bias && !a.res && !a.relu && !a.mask;
+    float bmu[8], brs[8], bsc[8], bsh[8];          // fused BN-backward reduce: per-channel constants of the BatchNorm whose dz this is
+    if (a.bnr_mode) {
+      load8(a.bnr_mean + n, bmu);
+      load8(a.bnr_rstd + n, brs);
+      if (a.bnr_mode == 2) { load8(a.bnr_scale + n, bsc); load8(a.bnr_shift + n, bsh); }
+    }
     for (int r = rg; r < BM; r += RPP) {
       const int m = m0 + r;
       if (m >= m_end) break;
       const uint2 lo = *(const uint2*)(sC + r * CP + vcol * 2);
       const uint2 hi = *(const uint2*)(sC + r * CP + vcol * 2 + 8);
       uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      if (a.bnr_mode) {
+        // the value that is stored (bf16), masked like the backward would mask it, reduced against xhat of the saved activation
+        float v[8];
+        v[0] = __uint_as_float(o.x << 16); v[1] = __uint_as_float(o.x & 0xffff0000u);
+        v[2] = __uint_as_float(o.y << 16); v[3] = __uint_as_float(o.y & 0xffff0000u);
+        v[4] = __uint_as_float(o.z << 16); v[5] = __uint_as_float(o.z & 0xffff0000u);
+        v[6] = __uint_as_float(o.w << 16); v[7] = __uint_as_float(o.w & 0xffff0000u);
+        if (!plain) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+          if (a.res) {
+            float rv[8];
+            load8(a.res + (long)m * a.ldr + n, rv);
+            if (a.res_bits) {
+              const unsigned b = a.res_bits[((long)m * a.ldr + n) >> 3];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) rv[e] = ((b >> e) & 1u) ? rv[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          }
+          store8(a.y + (long)m * a.ldy + n, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));        // what the separate reduce pass would read back
+        } else {
+          *(uint4*)(a.y + (long)m * a.ldy + n) = o;
+        }
+        float yv[8];
+        load8(a.bnr_y + (long)m * a.bnr_ld + n, yv);
+        if (a.bnr_mode == 2) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (yv[e] * bsc[e] + bsh[e]) > 0.f ? v[e] : 0.f;
+        } else {
+          const unsigned b = a.bnr_bits[((long)m * a.bnr_ld + n) >> 3];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = ((b >> e) & 1u) ? v[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * ((yv[e] - bmu[e]) * brs[e]); }
+        continue;
+      }
       if (!plain || a.stats) {
         float v[8];
         v[0] = __uint_as_float(o.x << 16); v[1] = __uint_as_float(o.x & 0xffff0000u);
@@ -396,7 +448,7 @@ __global__ __launch_bounds__(512 + LW * 64, (LW ? 1 : (NSTP == 2 ? 4 : 2))) void
       *(uint4*)(a.y + (long)m * a.ldy + n) = o;
     }
   }
-  if (a.stats) {
+  if (a.stats || a.bnr_mode) {
     // combine the RPP row groups in fixed order: sR[rg][2][BN] floats behind the tile
     float* sR = (float*)(smem + BM * CP);
 #pragma unroll
@@ -413,6 +465,12 @@ __global__ __launch_bounds__(512 + LW * 64, (LW ? 1 : (NSTP == 2 ? 4 : 2))) void
         for (int q = 0; q < RPP; ++q) {
           t1 += sR[(q * 2 + 0) * BN + tid];
           t2 += sR[(q * 2 + 1) * BN + tid];
+        }
+        if (a.bnr_mode) {      // [m-tile][3][Cout]: S1, S2 and the (unused) second-BN row
+          a.bnr_part[((long)mt * 3 + 0) * a.Cout + nn] = t1;
+          a.bnr_part[((long)mt * 3 + 1) * a.Cout + nn] = t2;
+          a.bnr_part[((long)mt * 3 + 2) * a.Cout + nn] = 0.f;
+          return;
         }
         a.stats[((long)mt * 2 + 0) * a.Cout + nn] = t1;
         a.stats[((long)mt * 2 + 1) * a.Cout + nn] = t2;
@@ -515,12 +573,26 @@ extern "C" int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int*
   return 2;
 }
 
+extern "C" int simt_conv_mtiles(const simt_conv_desc* d) {
+  int bn, tm, nst;
+  if (simt_conv_variant(d, &bn, &tm, &nst) != 2) return 0;
+  const Conv2Variant v = pick_variant(d);
+  const int M = d->B * d->Ho * d->Wo;
+  return (M + v.rows - 1) / v.rows;
+}
+
 // Called by simt_conv_fprop (conv_igemm.hip) for bf16 -> bf16 problems with tile_n in {64, 128, 256}.
 int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
   Conv2KArgs k;
   k.x = (const char*)d->x; k.w = (const char*)d->w; k.y = (bf16_t*)d->y; k.bias = d->bias; k.res = (const bf16_t*)d->res;
   k.stats = d->stats; k.zero = (const char*)simt_zero_page();
   k.mask = (const bf16_t*)d->mask; k.ldm = d->ldm; k.res_bits = d->res_bits;
+  k.bnr_mode = d->bnr_mode; k.bnr_ld = d->bnr_ld; k.bnr_y = (const bf16_t*)d->bnr_y; k.bnr_mean = d->bnr_mean; k.bnr_rstd = d->bnr_rstd;
+  k.bnr_scale = d->bnr_scale; k.bnr_shift = d->bnr_shift; k.bnr_bits = d->bnr_bits; k.bnr_part = d->bnr_part;
+  if (k.bnr_mode) {
+    SIMT_CHECK(d->dtype_out == SIMT_BF16 && !d->stats && !d->relu && !d->mask && d->bnr_y && d->bnr_mean && d->bnr_rstd && d->bnr_part);
+    SIMT_CHECK(d->bnr_ld % 8 == 0 && (d->bnr_mode == 2 ? (d->bnr_scale && d->bnr_shift) : (d->bnr_mode == 3 && d->bnr_bits)));
+  }
   k.out_f32 = d->dtype_out == SIMT_F32;
   if (k.out_f32) SIMT_CHECK(!d->bias && !d->res && !d->relu && !d->stats && d->Nstore % 4 == 0 && d->ldy % 4 == 0);
   k.H = d->H; k.W = d->W; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout; k.Nstore = d->Nstore; k.ldy = d->ldy; k.ldr = d->ldr;

@@ -321,13 +321,13 @@ class TrunkPlan:
 
     # ------------------------------------------------------------------ forward construction
     def _conv(self, lst, x, wp_info, y, *, Bn, Hi, Wi, Cin, Ho, Wo, Cout, taps, stride=1, bias=None, res=None, stats=None,
-              relu=False, ldy=None, Nstore=None, alg_k=None, alg_flops=None, mask=None, res_bits=None):
+              relu=False, ldy=None, Nstore=None, alg_k=None, alg_flops=None, mask=None, res_bits=None, bnr=None):
         """alg_k: algorithmic reduction length per output element (defaults to ntaps*Cin; the K-padded head dgrad and
         the stem pass their true value) -> algorithmic FLOPs = 2 * M * Cout * alg_k."""
         wp, tile, npad = wp_info
         d = ops.make_conv_desc(x, wp, y, B=Bn, H=Hi, W=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, taps=taps, stride=stride,
                                bias=bias, res=res, stats=stats, relu=relu, Npad=npad, tile_n=tile, ldy=ldy,
-                               Nstore=Nstore, mask=mask, res_bits=res_bits)
+                               Nstore=Nstore, mask=mask, res_bits=res_bits, bnr=bnr)
         M = Bn * Ho * Wo
         k = alg_k if alg_k is not None else len(taps) * Cin
         tn = {torch.bfloat16: "bf16", torch.float32: "f32"}
@@ -340,6 +340,7 @@ class TrunkPlan:
         lst.add_desc("simt_conv_fprop", d, tag=tag, flops=alg_flops if alg_flops is not None else 2.0 * M * Cout * k,
                      nbytes=float(nbytes),
                      shape=f"M{M} N{Cout} K{len(taps) * Cin} taps{len(taps)} s{stride}")
+        return d
 
     def _bn_train(self, lst, bname, y, M, Cn):
         """stats partials were written by the conv epilogue into self.bn[bname]['part']."""
@@ -619,8 +620,27 @@ class TrunkPlan:
                     tap_off, cout, rs, 0, stream=stream)
             self.grad_ready[pname] = len(lst)
 
+    def _bnr(self, bname, y, mode, bits=None):
+        """Fused first pass of `bname`'s backward for the conv that produces its dz (bf16 v2 kernel; see simt_conv_desc.bnr_*).
+        Returns None when the fusion does not apply (fp32 parity plans run the separate reduce kernel)."""
+        if self.dtype != torch.bfloat16 or os.environ.get("SIMT_BN_FUSE") == "0":
+            return None
+        sb = self.bn[bname]
+        return {"y": y, "mean": sb["mean"], "rstd": sb["rstd"], "scale": sb["scale"], "shift": sb["shift"], "bits": bits, "mode": mode,
+                "part": self.buf("bnb.part", self._bnb_cap, dtype=torch.float32)}
+
+    def _fused_nblk(self, d, bnr):
+        """Slot count the conv wrote (0: the launch does not run on the v2 kernel -> the descriptor's fusion is switched off)."""
+        if bnr is None:
+            return 0
+        n = L.load().simt_conv_mtiles(C.byref(d))
+        if n == 0:
+            d.bnr_mode = 0
+        assert n * 3 * d.Cout <= self._bnb_cap
+        return n
+
     def _bn_bwd(self, lst, *, dz, y, bname, dy, M, Cn, mask_mode, z=None, y2=None, bname2=None, dy2=None, gout=None,
-                affine=False):
+                affine=False, reduce_done_nblk=0):
         """affine: also write d gamma / d beta into self.grads[bname.weight / .bias] (trainable BatchNorm, engine_v3)."""
         s = self.bn[bname]
         ag = {}
@@ -636,7 +656,7 @@ class TrunkPlan:
         d = ops.make_bn_bwd_desc(dz=dz, y=y, mean=s["mean"], rstd=s["rstd"], scale=s["scale"], shift=s["shift"], part=part,
                                  coef=coef, dy=dy, M=M, Cn=Cn, mask_mode=mask_mode, z=z, y2=y2,
                                  mean2=s2["mean"] if s2 else None, rstd2=s2["rstd"] if s2 else None,
-                                 scale2=s2["scale"] if s2 else None, dy2=dy2, gout=gout, **ag)
+                                 scale2=s2["scale"] if s2 else None, dy2=dy2, gout=gout, reduce_done_nblk=reduce_done_nblk, **ag)
         lst.add_desc("simt_bn_bwd", d)
 
     def _build_backward(self):
@@ -685,6 +705,7 @@ class TrunkPlan:
         e0 = b.record(0)
         b.wait(e0, 1)
         last_side = {0: None, 1: None}
+        pending_bn3 = 0       # slots of bn3-backward partials the previous iteration's dx GEMM already reduced (0: none)
         for bi in range(n_blocks - 1, -1, -1):
             rec = self.block_io[bi]
             name, Mo, Mi, p, inpl = rec["name"], rec["Mo"], rec["Mi"], rec["planes"], rec["inpl"]
@@ -709,16 +730,20 @@ class TrunkPlan:
             # identity blocks: the shortcut gradient dz * (z > 0) is never written -- the conv that produces dx adds dz under
             # the bit mask (simt_conv_desc.res_bits)
             self._bn_bwd(b, dz=dz, z=rec["zbits"], y=rec["y3"], bname=f"{name}.bn3", dy=dy3, M=Mo, Cn=c4, mask_mode=3,
-                         y2=rec.get("yd"), bname2=f"{name}.downsample.1" if down else None, dy2=dyd)
+                         y2=rec.get("yd"), bname2=f"{name}.downsample.1" if down else None, dy2=dyd,
+                         reduce_done_nblk=pending_bn3)
+            pending_bn3 = 0
             # conv3
             b.wait(b.record(0), 1)
             self._wgrad(b, dy3, rec["a2"], None, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4, taps=[(0, 0)],
                         stride=1, parts=[(f"{name}.conv3.weight", 0, 0, c4, 1, p)])
             wt3 = self._plan_pack_t(f"{name}.conv3", c4, p, 1)
             da2 = self.buf("g.da", Mo, p)
-            self._conv(b, dy3, wt3[:3], da2, Bn=B, Hi=Ho, Wi=Wo, Cin=wt3[3], Ho=Ho, Wo=Wo, Cout=p, taps=[(0, 0)])
+            bnr = self._bnr(f"{name}.bn2", rec["y2"], 2)
+            dsc = self._conv(b, dy3, wt3[:3], da2, Bn=B, Hi=Ho, Wi=Wo, Cin=wt3[3], Ho=Ho, Wo=Wo, Cout=p, taps=[(0, 0)], bnr=bnr)
             dy2 = self.buf("g.dy2.%d" % par, Mo, p)
-            self._bn_bwd(b, dz=da2, y=rec["y2"], bname=f"{name}.bn2", dy=dy2, M=Mo, Cn=p, mask_mode=2)
+            self._bn_bwd(b, dz=da2, y=rec["y2"], bname=f"{name}.bn2", dy=dy2, M=Mo, Cn=p, mask_mode=2,
+                         reduce_done_nblk=self._fused_nblk(dsc, bnr))
             # conv2 (3x3 dilated)
             b.wait(b.record(0), 1)
             t3 = ops.conv_taps(3, 3, dil, dil)
@@ -728,10 +753,12 @@ class TrunkPlan:
             da1 = self.buf("g.da", Mo, p)
             # dy2 has p channels; the dgrad operand is K-padded to ck >= p: equal here because p % kq == 0
             assert wt2[3] == p and wt3[3] == c4
-            self._conv(b, dy2, wt2[:3], da1, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cout=p,
-                       taps=[(-a, -c) for (a, c) in t3])
+            bnr = self._bnr(f"{name}.bn1", rec["y1"], 2)
+            dsc = self._conv(b, dy2, wt2[:3], da1, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cout=p,
+                             taps=[(-a, -c) for (a, c) in t3], bnr=bnr)
             dy1 = self.buf("g.dy1.%d" % par, Mo, p)
-            self._bn_bwd(b, dz=da1, y=rec["y1"], bname=f"{name}.bn1", dy=dy1, M=Mo, Cn=p, mask_mode=2)
+            self._bn_bwd(b, dz=da1, y=rec["y1"], bname=f"{name}.bn1", dy=dy1, M=Mo, Cn=p, mask_mode=2,
+                         reduce_done_nblk=self._fused_nblk(dsc, bnr))
             # conv1 (+ downsample) wgrads
             b.wait(b.record(0), 1)
             self._wgrad(b, dy1, rec["x"], None, Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Ho, Wo=Wo, Cd=p, ldd=p, taps=[(0, 0)],
@@ -755,8 +782,18 @@ class TrunkPlan:
                     res, rbits = dxd, None
                 else:
                     res, rbits = dz, rec["zbits"]
-                self._conv(b, dy1, wt1[:3], dx, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cout=inpl, taps=[(0, 0)], res=res,
-                           res_bits=rbits)
+                # this dx is the dz of the block below: reduce for its bn3 backward here, unless that block has a downsample
+                # partner (third sum) or receives a head's gradient on top
+                bnr = None
+                if bi > 0:
+                    prev = self.block_io[bi - 1]
+                    pli = int(prev["name"][5])
+                    head_fed = (bi == sum(self.layers[:pli])) and pli in heads_by_layer
+                    if not prev["down"] and not head_fed and pli >= self.grads_from_layer:
+                        bnr = self._bnr(f"{prev['name']}.bn3", prev["y3"], 3, bits=prev["zbits"])
+                dsc = self._conv(b, dy1, wt1[:3], dx, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cout=inpl, taps=[(0, 0)], res=res,
+                                 res_bits=rbits, bnr=bnr)
+                pending_bn3 = self._fused_nblk(dsc, bnr)
             else:
                 assert down
                 wtd = self._plan_pack_t(f"{name}.downsample.0", c4, inpl, 1)

@@ -65,7 +65,8 @@ def packed_rows(cout, tile_n=None, dtype=None):
 
 
 def make_conv_desc(x, w, y, *, B, H, W, Cin, Ho, Wo, Cout, taps, stride=1, bias=None, res=None, stats=None, relu=False,
-                   Npad=None, Nstore=None, ldy=None, ldr=None, tile_n=None, mask=None, ldm=None, res_bits=None):
+                   Npad=None, Nstore=None, ldy=None, ldr=None, tile_n=None, mask=None, ldm=None, res_bits=None, bnr=None):
+    """bnr: fused first pass of the BatchNorm backward -- dict(y, mean, rstd, part, mode (2 | 3), scale, shift | bits)."""
     d = L.ConvDesc()
     tile_n = tile_n or pick_tile_n(Cout, x.dtype if x.dtype == y.dtype else None)
     d.x, d.w, d.y = _p(x), _p(w), _p(y)
@@ -81,6 +82,10 @@ def make_conv_desc(x, w, y, *, B, H, W, Cin, Ho, Wo, Cout, taps, stride=1, bias=
     d.mask = _p(mask)
     d.ldm = ldm if ldm is not None else (mask.shape[-1] if mask is not None else 0)
     d.res_bits = _p(res_bits)
+    if bnr:
+        d.bnr_y, d.bnr_mean, d.bnr_rstd, d.bnr_part = _p(bnr["y"]), _p(bnr["mean"]), _p(bnr["rstd"]), _p(bnr["part"])
+        d.bnr_scale, d.bnr_shift, d.bnr_bits = _p(bnr.get("scale")), _p(bnr.get("shift")), _p(bnr.get("bits"))
+        d.bnr_mode, d.bnr_ld = bnr["mode"], bnr["y"].shape[-1]
     return d
 
 
@@ -158,7 +163,8 @@ def bn_bwd_nblk(M, Cn):
 
 
 def make_bn_bwd_desc(*, dz, y, mean, rstd, scale, shift, part, coef, dy, M, Cn, mask_mode, z=None, y2=None, mean2=None,
-                     rstd2=None, scale2=None, dy2=None, gout=None, dgamma=None, dbeta=None, dgamma2=None, dbeta2=None):
+                     rstd2=None, scale2=None, dy2=None, gout=None, dgamma=None, dbeta=None, dgamma2=None, dbeta2=None,
+                     reduce_done_nblk=0):
     d = L.BnBwdDesc()
     d.dz, d.z, d.y = _p(dz), _p(z), _p(y)
     d.mean, d.rstd, d.scale, d.shift = _p(mean), _p(rstd), _p(scale), _p(shift)
@@ -166,6 +172,7 @@ def make_bn_bwd_desc(*, dz, y, mean, rstd, scale, shift, part, coef, dy, M, Cn, 
     d.part, d.coef, d.dy, d.dy2, d.gout = _p(part), _p(coef), _p(dy), _p(dy2), _p(gout)
     d.M, d.C, d.mask_mode, d.dtype = M, Cn, mask_mode, dt_code(y.dtype)
     d.dgamma, d.dbeta, d.dgamma2, d.dbeta2 = _p(dgamma), _p(dbeta), _p(dgamma2), _p(dbeta2)
+    d.reduce_done_nblk = reduce_done_nblk
     return d
 
 

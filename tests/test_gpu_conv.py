@@ -300,3 +300,54 @@ def test_conv1x1_resident_panel_kernel(dev, case, monkeypatch):
         st = kw["stats"].cpu().double().sum(0)                       # the caller sums every slot
         stored = y_d.float().cpu().double().reshape(M, Cout)
         assert _rel(st[0], stored.sum(0)) < 2e-3 and _rel(st[1], (stored * stored).sum(0)) < 2e-3
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("shape", [(2, 19, 23, 256, 1024, "res_bits"), (2, 19, 23, 1024, 256, "plain"), (1, 15, 17, 128, 128, "plain3x3")])
+def test_conv_epilogue_fused_bn_backward_reduce(dev, mode, shape):
+    """simt_conv_desc.bnr_*: the dgrad GEMM that produces dz also accumulates S1 = sum dz*mask and S2 = sum dz*mask*xhat of the
+    BatchNorm whose output gradient dz is (what bn_bwd_reduce_kernel re-reads dz for).  Checked against torch on the STORED bf16
+    dz: 2e-3 of max|S|, for both mask flavours and for the plain / residual-under-bit-mask epilogues."""
+    import ctypes as C
+    from simt_amd import _lib as L
+    B, H, W, Cin, Cout, kind = shape
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(Cin + Cout + mode)
+    k = 3 if kind == "plain3x3" else 1
+    taps = ops.conv_taps(3, 3, 2, 2) if k == 3 else [(0, 0)]
+    M = B * H * W
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev, dtype)
+    tile = ops.pick_tile_n(Cout, dtype)
+    npad = ops.round_up(Cout, tile)
+    wp = (torch.randn(npad, len(taps) * Cin, generator=g) * (1.0 / (len(taps) * Cin)) ** 0.5).to(dev, dtype)
+    dz = torch.empty(M, Cout, device=dev, dtype=dtype)
+    y = torch.randn(M, Cout, generator=g).to(dev, dtype)
+    mean, shift = torch.randn(Cout, generator=g).to(dev) * 0.2, torch.randn(Cout, generator=g).to(dev) * 0.3
+    rstd, scale = (torch.rand(Cout, generator=g) + 0.5).to(dev), (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    bits = torch.randint(0, 256, (M, Cout // 8), generator=g, dtype=torch.uint8).to(dev)
+    part = torch.full((M // 128 + 2, 3, Cout), float("nan"), device=dev)
+    bnr = {"y": y, "mean": mean, "rstd": rstd, "scale": scale, "shift": shift, "bits": bits, "mode": mode, "part": part}
+    kw = {}
+    if kind == "res_bits":
+        kw = dict(res=torch.randn(M, Cout, generator=g).to(dev, dtype),
+                  res_bits=torch.randint(0, 256, (M, Cout // 8), generator=g, dtype=torch.uint8).to(dev))
+    d = ops.make_conv_desc(x, wp, dz, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=Cout, taps=taps, Npad=npad, tile_n=tile, bnr=bnr, **kw)
+    nblk = L.load().simt_conv_mtiles(C.byref(d))
+    assert 0 < nblk <= part.shape[0]
+    ops.conv_fprop_desc(d)
+    d0 = ops.make_conv_desc(x, wp, torch.empty_like(dz), B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=Cout, taps=taps, Npad=npad, tile_n=tile, **kw)
+    ref_dz = torch.empty_like(dz)
+    d0.y = ref_dz.data_ptr()
+    ops.conv_fprop_desc(d0)
+    torch.cuda.synchronize()
+    assert torch.equal(dz, ref_dz)                                 # the fusion does not change what is stored
+    gz, yy = dz.double(), y.double()
+    if mode == 2:
+        msk = (y.float() * scale + shift) > 0
+    else:
+        msk = ((bits.unsqueeze(-1).to(torch.int32) >> torch.arange(8, device=dev, dtype=torch.int32)) & 1).reshape(M, Cout).bool()
+    gm = gz * msk
+    s1, s2 = gm.sum(0), (gm * ((yy - mean.double()) * rstd.double())).sum(0)
+    got = part[:nblk].double().sum(0)
+    assert torch.isfinite(got).all()
+    assert _rel(got[0].cpu(), s1.cpu()) < 2e-3 and _rel(got[1].cpu(), s2.cpu()) < 2e-3 and got[2].abs().max().item() == 0.0
