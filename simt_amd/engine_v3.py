@@ -363,9 +363,11 @@ class V3Plan(TrunkPlan):
                             stride=stride, parts=[(name + ".downsample.0.weight", 0, 0, c4, 1, inpl)])
             wt3 = self._plan_pack_t(name + ".conv3", c4, p, 1)
             da2 = self.new(Mo, p)
-            self._conv(b, dy3, wt3[:3], da2, Bn=B, Hi=Ho, Wi=Wo, Cin=wt3[3], Ho=Ho, Wo=Wo, Cout=p, taps=[(0, 0)])
+            bnr = self._bnr(name + ".bn2", rec["y2"], 2)       # first pass of bn2's backward inside the GEMM that produces da2
+            dsc = self._conv(b, dy3, wt3[:3], da2, Bn=B, Hi=Ho, Wi=Wo, Cin=wt3[3], Ho=Ho, Wo=Wo, Cout=p, taps=[(0, 0)], bnr=bnr)
             dy2 = self.new(Mo, p)
-            self._bnb(b, dz=da2, y=rec["y2"], bname=name + ".bn2", dy=dy2, M=Mo, Cn=p, mask_mode=2)
+            self._bnb(b, dz=da2, y=rec["y2"], bname=name + ".bn2", dy=dy2, M=Mo, Cn=p, mask_mode=2,
+                      reduce_done_nblk=self._fused_nblk(dsc, bnr))
             # conv2: 3x3, stride s.  dgrad of a strided conv = stride-1 correlation of the zero-inserted dY with mirrored taps
             b.wait(b.record(0), 1)
             t3 = ops.conv_taps(3, 3, 1, 1)
@@ -378,10 +380,12 @@ class V3Plan(TrunkPlan):
                 src = self.new(Mi, p)
                 b.add("simt_scatter_stride", dy2.data_ptr(), src.data_ptr(), B, Hi, Wi, p, Ho, Wo, stride, ops.dt_code(dt))
             da1 = self.new(Mi, p)
-            self._conv(b, src, wt2[:3], da1, Bn=B, Hi=Hi, Wi=Wi, Cin=p, Ho=Hi, Wo=Wi, Cout=p, taps=[(-a, -c) for (a, c) in t3],
-                       alg_flops=2.0 * Mo * p * 9 * p)
+            bnr = self._bnr(name + ".bn1", rec["y1"], 2)
+            dsc = self._conv(b, src, wt2[:3], da1, Bn=B, Hi=Hi, Wi=Wi, Cin=p, Ho=Hi, Wo=Wi, Cout=p, taps=[(-a, -c) for (a, c) in t3],
+                             alg_flops=2.0 * Mo * p * 9 * p, bnr=bnr)
             dy1 = self.new(Mi, p)
-            self._bnb(b, dz=da1, y=rec["y1"], bname=name + ".bn1", dy=dy1, M=Mi, Cn=p, mask_mode=2)
+            self._bnb(b, dz=da1, y=rec["y1"], bname=name + ".bn1", dy=dy1, M=Mi, Cn=p, mask_mode=2,
+                      reduce_done_nblk=self._fused_nblk(dsc, bnr))
             b.wait(b.record(0), 1)
             self._wgrad(b, dy1, rec["x"], None, Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Hi, Wo=Wi, Cd=p, ldd=p, taps=[(0, 0)], stride=1,
                         parts=[(name + ".conv1.weight", 0, 0, p, 1, inpl)])
