@@ -300,7 +300,7 @@ extern "C" int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream) {
   SIMT_CHECK(d->Nstore % 8 == 0 && d->Nstore <= d->Npad && d->Nstore <= d->ldy);
   SIMT_CHECK(d->ldy % 8 == 0 && (!d->res || d->ldr % 8 == 0) && (!d->mask || d->ldm % 8 == 0));
   SIMT_CHECK(!(d->dtype_in == SIMT_F32 && d->dtype_out == SIMT_BF16));
-  if (v2 && nloop_enabled() && !d->bnr_mode && simt_conv_nloop_eligible(d)) return simt_conv_fprop_bf16_nloop(d, stream);
+  if (v2 && nloop_enabled() && simt_conv_nloop_eligible(d)) return simt_conv_fprop_bf16_nloop(d, stream);
   if (v2) return simt_conv_fprop_bf16_v2(d, stream);
   SIMT_CHECK(!d->bnr_mode);   // the fused BN-backward reduce exists in the bf16 v2 kernel only
   ConvKArgs k;

@@ -566,16 +566,19 @@ extern "C" int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int*
   if (!v2) { *bn = d->tile_n; *tm = 0; *nst = 2; return 0; }
   {
     const char* e = getenv("SIMT_CONV_NLOOP");
-    if (e && e[0] == '1' && simt_conv_nloop_eligible(d)) { *bn = 256; *tm = d->Cin / 64; *nst = 2; return 3; }   // conv1x1_nloop_kernel<K/64>
+    if (e && e[0] == '1' && simt_conv_nloop_eligible(d)) { *bn = 128; *tm = d->Cin / 64; *nst = 3; return 3; }   // conv1x1_nloop_kernel<K/64>
   }
   const Conv2Variant v = pick_variant(d);
   *bn = v.tile_n; *tm = v.tm; *nst = v.nst;
   return 2;
 }
 
+int simt_conv_nloop_mtiles(const simt_conv_desc* d);      // conv1x1_nloop.hip
 extern "C" int simt_conv_mtiles(const simt_conv_desc* d) {
   int bn, tm, nst;
-  if (simt_conv_variant(d, &bn, &tm, &nst) != 2) return 0;
+  const int gen = simt_conv_variant(d, &bn, &tm, &nst);
+  if (gen == 3) return simt_conv_nloop_mtiles(d);
+  if (gen != 2) return 0;
   const Conv2Variant v = pick_variant(d);
   const int M = d->B * d->Ho * d->Wo;
   return (M + v.rows - 1) / v.rows;
