@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);   // D = [k][co]
   };
 
   if (nk > 0) issue(0);
@@ -186,18 +186,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
     if (nk > 0) mma();
   }
 
-  // slab[split][co][k]: lane&15 -> 16 consecutive k (64-B segments), 4 rows per accumulator
+  // slab[split][co][k]: the X columns are the MFMA's row operand, so every accumulator quad is 4 consecutive k of one dY
+  // channel -> one 16-byte store per quad (four lanes = 64 contiguous bytes of a slab row) instead of four 4-byte stores
   float* out = a.slab + (long)split * a.Cd * a.Ktot;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int co = co0 + wm * 64 + i * 16 + (lane >> 4) * 4 + e;
-        const int k = k0 + wn * 64 + j * 16 + (lane & 15);
-        if (co < a.Cd && k < a.Ktot) out[(long)co * a.Ktot + k] = acc[i][j][e];
-      }
+    for (int j = 0; j < 4; ++j) {
+      const int co = co0 + wm * 64 + i * 16 + (lane & 15);
+      const int k = k0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      if (co < a.Cd && k < a.Ktot) *(f32x4*)(out + (long)co * a.Ktot + k) = acc[i][j];
+    }
 }
 
 // Called by simt_conv_wgrad (conv_wgrad.hip) for bf16 problems with Cd >= 128.
@@ -206,7 +205,7 @@ int simt_conv_wgrad_bf16_v2(const simt_wgrad_desc* d, simt_stream_t stream) {
   k.dy = (const char*)d->dy; k.x = (const char*)d->x; k.slab = d->slab; k.zero = (const char*)simt_zero_page();
   k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Ho = d->Ho; k.Wo = d->Wo; k.Cd = d->Cd; k.ldd = d->ldd;
   k.stride = d->stride; k.ntaps = d->ntaps; k.M = d->B * d->Ho * d->Wo; k.Ktot = d->ntaps * d->Cin;
-  SIMT_CHECK(k.M < (1 << 24));
+  SIMT_CHECK(k.M < (1 << 24) && k.Ktot % 4 == 0);      // 16-byte slab stores
   SIMT_CHECK((long)k.M * d->ldd * 2 < (1l << 32) && (long)d->B * d->H * d->W * d->Cin * 2 < (1l << 32));
   SIMT_CHECK(d->stride == 1 ? (d->H == d->Ho && d->W == d->Wo) : true);
   k.nsplit = d->nsplit;
