@@ -143,8 +143,12 @@ class SimTTrainer:
         if self.pg is not None:
             from .dp import BucketReducer, make_buckets
             sizes = {n: k for n, (_o, k) in self.plan.grad_offsets.items()}
-            buckets = make_buckets(self.plan.grad_order, sizes, self.plan.grad_ready, bucket_elems=8 << 20)
-            self.reducer = BucketReducer(self.plan.flat_grad, buckets, group=self.pg, extra=[self._ntm_grad_flat])
+            # with skip_unapplied_grads the tail of the flat buffer (layer2, layer1, stem: never written, never applied) is not exchanged
+            order = [n for n in self.plan.grad_order if self.plan.grad_ready.get(n, 0) > 0]
+            assert order == self.plan.grad_order[:len(order)]
+            end = sum(sizes[n] for n in order)
+            buckets = make_buckets(order, sizes, self.plan.grad_ready, bucket_elems=8 << 20)
+            self.reducer = BucketReducer(self.plan.flat_grad[:end], buckets, group=self.pg, extra=[self._ntm_grad_flat])
 
     # ------------------------------------------------------------------ optimiser plumbing
     def _build_sgd(self, roots=("layer3", "layer4")):
