@@ -231,7 +231,7 @@ class TrunkPlan:
     """
 
     def __init__(self, params, B, H, W, heads, *, dtype=torch.bfloat16, train=True, layers=LAYERS, device=None,
-                 need_input_grads=True, grad_names=None, grads_from_layer=0):
+                 need_input_grads=True, grad_names=None, grads_from_layer=0, stem_from=None):
         self.p = params
         self.B, self.H, self.W = B, H, W
         self.heads = heads
@@ -242,6 +242,9 @@ class TrunkPlan:
         # the SimT stage never applies the gradients of conv1 / layer1 / layer2 (optim_parameters lists layer3, layer4 and the
         # heads only, model/deeplab_multi.py:194-237), so the trajectory is identical; see Hyper.skip_unapplied_grads.
         self.grads_from_layer = grads_from_layer
+        # stem_from: another plan of the same geometry / dtype fed with the SAME image (the frozen model of the SimT stage): its
+        # im2col matrix is reused instead of being rebuilt; the caller orders the streams (step.py)
+        self.stem_from = stem_from
         self.dev = device or next(iter(params.values())).device
         self.esz = 2 if dtype == torch.bfloat16 else 4
         self.kq = 128 // self.esz            # channel quantum of the K dimension (one 128-B stage)
@@ -371,14 +374,19 @@ class TrunkPlan:
         f = self.fwd_list
         H0, W0, Hp, Wp = self.H0, self.W0, self.Hp, self.Wp
         M0, Mp = B * H0 * W0, B * Hp * Wp
-        self.x_in = self.new(B, 3, self.H, self.W, dtype=torch.float32)
         self.saved = {}
         # ---- stem (model/deeplab_multi.py:127-133,172-176)
         KS = 192
-        A = self.new(M0, KS)
+        if self.stem_from is not None:
+            o = self.stem_from
+            assert (o.B, o.H, o.W, o.dtype) == (B, self.H, self.W, dt)
+            self.x_in, A = o.x_in, o.saved["stem.A"]
+        else:
+            self.x_in = self.new(B, 3, self.H, self.W, dtype=torch.float32)
+            A = self.new(M0, KS)
+            f.add("simt_im2col_stem", self.x_in.data_ptr(), A.data_ptr(), B, 3, self.H, self.W, H0, W0, 7, 7, 2, 3, KS,
+                  ops.dt_code(dt))
         self.saved["stem.A"] = A
-        f.add("simt_im2col_stem", self.x_in.data_ptr(), A.data_ptr(), B, 3, self.H, self.W, H0, W0, 7, 7, 2, 3, KS,
-              ops.dt_code(dt))
         y0 = self.new(M0, 64)
         pool = self.new(Mp, 64)
         pidx = self.new(Mp, 64, dtype=torch.uint8)

@@ -76,7 +76,12 @@ class SimTTrainer:
         kw = {"layers": layers} if layers is not None else {}
         self.plan = TrunkPlan(self.params, B, H, W, multi_heads(Cn, K, openset), dtype=dtype, train=True,
                               grads_from_layer=3 if getattr(hp, "skip_unapplied_grads", False) else 0, **kw)
-        self.fixed = TrunkPlan(self.fixed_params, B, H, W, multi_heads(Cn, 0, False), dtype=dtype, train=False, **kw)
+        # the frozen model sees the same image: it reuses the trainable plan's stem im2col matrix (one im2col per micro-batch)
+        self.fixed = TrunkPlan(self.fixed_params, B, H, W, multi_heads(Cn, 0, False), dtype=dtype, train=False,
+                               stem_from=self.plan, **kw)
+        assert self.plan.fwd_list.items[0].tag == "simt_im2col_stem"
+        self._fwd_rest = LaunchList()
+        self._fwd_rest.items = self.plan.fwd_list.items[1:]
         h, w = self.plan.heads[1].h, self.plan.heads[1].w
         self.h, self.w = h, w
         Q = self.Q
@@ -181,6 +186,11 @@ class SimTTrainer:
         """Steps 2-5 of the iteration for one micro-batch: both forwards, fused head, NTM terms, backward."""
         self.plan.x_in.copy_(image, non_blocking=True)
         self.label.copy_(label, non_blocking=True)
+        # the stem im2col (first launch of the trainable forward) feeds BOTH nets: run it before forking
+        head = self.plan.fwd_list.items[0]
+        rc = head.fn(*head.args, st)
+        if rc != 0:
+            L.check(rc)
         # 2. frozen model -> low-res posterior, on the side stream: its eval-mode convs share the CUs with the HBM-bound
         #    BatchNorm passes of the trainable forward (3.) instead of running before it
         main = torch.cuda.current_stream()
@@ -189,13 +199,12 @@ class SimTTrainer:
         ev_in.record(main)
         with torch.cuda.stream(side):
             side.wait_event(ev_in)
-            self.fixed.x_in.copy_(self.plan.x_in, non_blocking=True)
             self.fixed.forward()
             ops.softmax_rows(self.fixed.out["x2"], self.ldf, self.fixp, self.ldf, self.B * self.h * self.w, self.C)
             ev_fix = torch.cuda.Event()
             ev_fix.record(side)
-        # 3. trainable forward
-        self.plan.forward()
+        # 3. trainable forward (its im2col already ran above)
+        self._fwd_rest.run()
         main.wait_event(ev_fix)
         # 4. fused head + NTM regularisers + gradients of the low-res logits (every term scaled by 1 / iter_size, :427;
         #    the NTM gradients accumulate on top of the inner loop's leak and of earlier micro-batches)
