@@ -10,6 +10,7 @@
 // source address so the 8 pixel rows a 32-lane half touches land in distinct 32-B slots.
 // Stride-1 convolutions need no per-stage division for the tap-shifted source pixel: input pixel = m + dy*W + dx.
 #include "common.h"
+#include <stdlib.h>
 
 struct Wgrad2KArgs {
   const char* dy;
@@ -27,6 +28,11 @@ template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 }
 
+// MODE 0 = product; 1 = loads only, 2 = fragment reads + MFMA only (timing ablations, env SIMT_WGRAD2_MODE)
+// Measured (scratch/wgradbench.py): 3x3 256<-256 83 us = loads-only 52 + MFMA-only 43 with little overlap; the 1x1 shapes are
+// LOAD-bound (41 us, loads-only 39, MFMA-only 23): two ring stages = 96 KB in flight per CU against HBM latency.  A ninth
+// wave prefetching one dword per 128-B line four stages ahead made them slower (62-67 us): it doubles the line requests.
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
   constexpr int NT = 512, NST = 3, BP = 64;
   constexpr int ROWB = 256;                  // bytes per LDS row (128 channels)
@@ -159,17 +165,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);   // D = [k][co]
   };
 
-  if (nk > 0) issue(0);
-  if (nk > 1) issue(1);
+  if (MODE != 2) {
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+  }
   int buf = 0;
   if (wave < 4) {
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) wg_wait_vmcnt<6>(); else wg_wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      load_frags(buf);                                    // fragment reads first: their latency gates the MFMAs
-      if (kt + 2 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
-      mma();
+      if (MODE != 1) load_frags(buf);                     // fragment reads first: their latency gates the MFMAs
+      if (MODE != 2 && kt + 2 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
+      if (MODE != 1) mma();
       buf = (buf + 1 == NST) ? 0 : buf + 1;
     }
   } else {
@@ -178,12 +186,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kt > 0) mma();
-      if (kt + 2 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
-      load_frags(buf);
+      if (MODE != 1 && kt > 0) mma();
+      if (MODE != 2 && kt + 2 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
+      if (MODE != 1) load_frags(buf);
       buf = (buf + 1 == NST) ? 0 : buf + 1;
     }
-    if (nk > 0) mma();
+    if (MODE != 1 && nk > 0) mma();
   }
 
   // slab[split][co][k]: the X columns are the MFMA's row operand, so every accumulator quad is 4 consecutive k of one dY
@@ -216,14 +224,19 @@ int simt_conv_wgrad_bf16_v2(const simt_wgrad_desc* d, simt_stream_t stream) {
   k.rcpWo = 1.0f / (float)d->Wo;
   k.rcpHoWo = 1.0f / (float)(d->Ho * d->Wo);
   for (int i = 0; i < SIMT_MAX_TAPS; ++i) { k.tdy[i] = d->dy_[i]; k.tdx[i] = d->dx_[i]; }
-  static bool attr_set = false;
   const int lds = 3 * 3 * 64 * 256;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("SIMT_WGRAD2_MODE");
+    mode = e ? atoi(e) : 0;
+    (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   const int grid = k.cotiles * k.ktiles * k.nsplit;
-  hipLaunchKernelGGL(conv_wgrad2_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, k);
+  if (mode == 1) hipLaunchKernelGGL(conv_wgrad2_kernel<1>, dim3(grid), dim3(512), lds, (hipStream_t)stream, k);
+  else if (mode == 2) hipLaunchKernelGGL(conv_wgrad2_kernel<2>, dim3(grid), dim3(512), lds, (hipStream_t)stream, k);
+  else hipLaunchKernelGGL(conv_wgrad2_kernel<0>, dim3(grid), dim3(512), lds, (hipStream_t)stream, k);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
