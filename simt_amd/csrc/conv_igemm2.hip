@@ -61,12 +61,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 
 // MODE 0 = product.  MODE 1 (loads only) and MODE 2 (MFMA only) are timing-ablation builds selected by the environment
 // variable SIMT_CONV2_MODE; their outputs are meaningless.
-// LW = 4: wave specialisation (experiment, off by default).  Four extra waves (one per SIMD) do nothing but fill the ring; the
-// eight consumer waves never issue a global_load_lds and never wait on vmcnt.  NST = 3 variants only.  Measured on MI355X
-// (scratch/convbench.py): 3x3 256->256 51.6 us vs 47.6 us for the default build, 1x1 shapes unchanged -- four waves issue the
-// 13 pieces per stage more slowly than eight waves issue 7 each; the fill path is bound by per-wave issue, not by the consumers.
+// LW = 4 / 8: wave specialisation (experiments, off by default; SIMT_CONV2_LW=4|8).  Extra waves do nothing but fill the ring;
+// the eight consumer waves never issue a global_load_lds and never wait on vmcnt.  NST = 3 variants only.  Measured on MI355X
+// (scratch/convbench.py, 3x3 256->256): default 48-50 us, LW=4 51.6 us (four waves issue the 13 pieces per stage more slowly
+// than eight waves issue 7 each), LW=8 (8 loaders + 8 consumers at 125 VGPRs, single-buffered fragments) 50.5 us = unchanged.
+// Three very different schedules, one time: the kernel is bound by a shared resource, not by issue slots.  Per 64-deep stage the
+// LDS sees 52 KB of DMA writes (loads-only ablation: 31 us = ~30 B/clk/CU of L2->LDS fill) and 144 KB of fragment reads
+// (562 cycles at 256 B/clk) next to 1 280 cycles of MFMA per SIMD; the fill rate is the floor.  The lever is fewer staged bytes
+// per FLOP (2-D halo tiles for the 3x3 pixel operand), not scheduling.
 template <int BN, int TMP, int NSTP, int MODE, int LW = 0>
-__global__ __launch_bounds__(512 + LW * 64, (LW ? 1 : (NSTP == 2 ? 4 : 2))) void conv_igemm2_kernel(Conv2KArgs a) {
+__global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ? 4 : 2))) void conv_igemm2_kernel(Conv2KArgs a) {
   constexpr int NT = 512, NST = NSTP;   // NST = 3: one workgroup per CU, two stages in flight; NST = 2 (short-K, output-
                                         // bound shapes): two workgroups per CU so one's epilogue overlaps the other's loads
   constexpr int WM = (BN == 64) ? 4 : 2;          // waves along pixels
@@ -95,9 +99,11 @@ __global__ __launch_bounds__(512 + LW * 64, (LW ? 1 : (NSTP == 2 ? 4 : 2))) void
     if (wave >= 8) {
       // ================= loader waves: piece q = i*NL + ltid -> row q>>3, 16-B position q&7 (same swizzle as below)
       constexpr int NL = LW * 64;
-      constexpr int A_ITL = BM * 8 / NL, B_ITL = BN * 8 / NL;
-      static_assert((BM * 8) % NL == 0 && (BN * 8) % NL == 0 && A_ITL + B_ITL <= 16, "piece counts");
+      constexpr int A_ITL = (BM * 8 + NL - 1) / NL, B_ITL = BN * 8 / NL;
+      constexpr bool A_TAILL = (BM * 8) % NL != 0;         // last pixel pass only issued by the first waves
+      static_assert((BN * 8) % NL == 0 && A_ITL + B_ITL <= 16, "piece counts");
       const int ltid = tid - NT, lw = wave - 8;
+      const bool l_tail_wave = !A_TAILL || lw < (BM * 8 - (A_ITL - 1) * NL) / 64;
       const int lcg = (ltid & 7) ^ (((ltid >> 3) >> 1) & 7);     // NL/8 = 32 rows per pass: a multiple of 16, key unchanged
       unsigned la_off[A_ITL];
       unsigned long long la_ok[A_ITL];
@@ -133,6 +139,7 @@ __global__ __launch_bounds__(512 + LW * 64, (LW ? 1 : (NSTP == 2 ? 4 : 2))) void
         char* sbase = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < A_ITL; ++i) {
+          if (i == A_ITL - 1 && !l_tail_wave) break;
           const bool ok = (la_ok[i] >> l_tap) & 1ull;
           const char* src = ok ? a.x + (unsigned)(la_off[i] + (unsigned)toff) : lz;
           __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sbase + (i * NL + lw * 64) * 16), 16, 0, 0);
@@ -149,7 +156,9 @@ __global__ __launch_bounds__(512 + LW * 64, (LW ? 1 : (NSTP == 2 ? 4 : 2))) void
       if (nkl > 1) lissue(1);
       int lbuf = 0;
       for (int kt = 0; kt < nkl; ++kt) {
-        if (kt + 1 < nkl) wait_vmcnt<A_ITL + B_ITL>(); else wait_vmcnt<0>();   // stage kt landed, stage kt+1 may be in flight
+        if (kt + 1 >= nkl) wait_vmcnt<0>();                                     // stage kt landed, stage kt+1 may be in flight
+        else if (A_TAILL && !l_tail_wave) wait_vmcnt<A_ITL - 1 + B_ITL>();
+        else wait_vmcnt<A_ITL + B_ITL>();
         __builtin_amdgcn_s_barrier();
         if (kt + 2 < nkl) lissue(lbuf >= 1 ? lbuf - 1 : 2);                     // slot (kt+2)%3: read by everybody in step kt-1
         lbuf = (lbuf + 1 == 3) ? 0 : lbuf + 1;
@@ -267,7 +276,30 @@ __global__ __launch_bounds__(512 + LW * 64, (LW ? 1 : (NSTP == 2 ? 4 : 2))) void
     if (NST == 3 && nk > 1) issue(1);
   }
   int buf = 0;
-  if (wave < 4) {
+  if constexpr (LW == 8) {
+    // ---- consumers of the 8 + 8 build: 128 VGPRs per wave (4 waves per SIMD) -> fragments of ONE 32-deep K half at a time
+    for (int kt = 0; kt < nk; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* px = smem + buf * STAGE + xbase;
+      const char* pw = smem + buf * STAGE + wbase;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int coff = ((4 * s + kq) ^ sw) << 4;
+        bf16x8 x1[TM], w1[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) x1[i] = *(const bf16x8*)(px + i * 16 * 128 + coff);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) w1[j] = *(const bf16x8*)(pw + j * 16 * 128 + coff);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j], x1[i], acc[j][i], 0, 0, 0);
+      }
+      buf = (buf + 1 == NST) ? 0 : buf + 1;
+    }
+  } else if (wave < 4) {
     // ---- early half: [barrier] issue(kt+2) -> fragments(kt) -> MFMA(kt)
     for (int kt = 0; kt < nk; ++kt) {
       if (MODE != 2 && LW == 0) wait_stage(kt + 1 < nk);
@@ -504,8 +536,8 @@ static int launch_conv2m(const Conv2KArgs& k, hipStream_t st) {
 #include <stdlib.h>
 static int conv2_loader_waves() {          // SIMT_CONV2_LW=1 selects the wave-specialised build (experiment, see the kernel's LW note)
   static int lw = -1;
-  if (lw < 0) { const char* e = getenv("SIMT_CONV2_LW"); lw = (e && e[0] == '1') ? 1 : 0; }
-  return lw;
+  if (lw < 0) { const char* e = getenv("SIMT_CONV2_LW"); lw = e ? atoi(e) : 0; }
+  return lw;     // 0 (default), 4 or 8 loader waves
 }
 template <int BN, int TM, int NST = 3>
 static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
@@ -520,7 +552,8 @@ static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
   if (mode == 12) return launch_conv2m<BN, TM, NST, 12>(k, st);
   if (mode == 13) return launch_conv2m<BN, TM, NST, 13>(k, st);
   if constexpr (NST == 3) {
-    if (conv2_loader_waves()) return launch_conv2m<BN, TM, NST, 0, 4>(k, st);
+    if (conv2_loader_waves() == 4) return launch_conv2m<BN, TM, NST, 0, 4>(k, st);
+    if (conv2_loader_waves() == 8) return launch_conv2m<BN, TM, NST, 0, 8>(k, st);
   }
   return launch_conv2m<BN, TM, NST, 0>(k, st);
 }
