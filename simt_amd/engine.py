@@ -725,8 +725,12 @@ class TrunkPlan:
             first_needed = (li == self.grads_from_layer and bi == sum(self.layers[:li - 1]) and self.grads_from_layer > 0)
             last_of_layer = (bi + 1 == sum(self.layers[:li]))
             if last_of_layer and li in heads_by_layer:
-                for hd in heads_by_layer[li]:
-                    dz = self._build_head_bwd(hd, dz, Mo, c4, bi)
+                hds = heads_by_layer[li]
+                for hi, hd in enumerate(hds):
+                    # the LAST head GEMM of this layer produces the block's final dz: reduce for its bn3 backward there
+                    bnr = self._bnr(f"{name}.bn3", rec["y3"], 3, bits=rec["zbits"]) if (hi == len(hds) - 1 and not down) else None
+                    dz = self._build_head_bwd(hd, dz, Mo, c4, bi, bnr=bnr)
+                    pending_bn3 = self._head_bnr_nblk
             assert dz is not None, "no gradient reaches the last block (a head must sit on the last layer)"
             blk_start = len(b)
             par = bi & 1
@@ -829,8 +833,11 @@ class TrunkPlan:
                     taps=[(0, 0)], stride=1, parts=[("conv1.weight", 0, 0, 64, 1, 147)])
         b.wait(b.record(1), 0)        # join: the optimiser (stream 0) sees every gradient
 
-    def _build_head_bwd(self, hd, dz_prev, Mo, c4, bi):
-        """wgrad/bias grads of the fused ASPP GEMM and its dgrad into the feature gradient (added to dz_prev)."""
+    def _build_head_bwd(self, hd, dz_prev, Mo, c4, bi, bnr=None):
+        """wgrad/bias grads of the fused ASPP GEMM and its dgrad into the feature gradient (added to dz_prev).  bnr: fused first
+        pass of the feature block's bn3 backward (the dgrad GEMM produces that block's dz); the slot count is left in
+        self._head_bnr_nblk."""
+        self._head_bnr_nblk = 0
         B, b = self.B, self.bwd_list
         dl = self.dlogits[hd.name]
         Mh = B * hd.h * hd.w
@@ -866,9 +873,12 @@ class TrunkPlan:
                     self.pack_list.add("simt_pack_weight", w.data_ptr(), wt.data_ptr(), cout, hd.cin, 9, row, 9 * i,
                                        len(hd.taps) * hd.ck, hd.ck, 1, None, ops.dt_code(self.dtype))
                 row += cout
-            self._conv(b, dl, (wt, tile, npad), dfeat, Bn=B, Hi=hd.h, Wi=hd.w, Cin=hd.ck, Ho=hd.h, Wo=hd.w, Cout=hd.cin,
-                       taps=[(-a, -c) for (a, c) in hd.taps], res=dz_prev, alg_k=len(hd.taps) * hd.Q,
-                       mask=getattr(hd, "mask", None))
+            if getattr(hd, "mask", None) is not None:
+                bnr = None
+            dsc = self._conv(b, dl, (wt, tile, npad), dfeat, Bn=B, Hi=hd.h, Wi=hd.w, Cin=hd.ck, Ho=hd.h, Wo=hd.w, Cout=hd.cin,
+                             taps=[(-a, -c) for (a, c) in hd.taps], res=dz_prev, alg_k=len(hd.taps) * hd.Q,
+                             mask=getattr(hd, "mask", None), bnr=bnr)
+            self._head_bnr_nblk = self._fused_nblk(dsc, bnr)
             return dfeat
         # ---- tap-expanded backward: G[m'][t*QP+n] = dlogits[m' - d_t][n]; dW = G^T x feat; dfeat = G x Wt (+ dz_prev)
         nt, QP, nexp = len(hd.taps), hd.QP, hd.nexp
@@ -904,8 +914,11 @@ class TrunkPlan:
                 self.pack_list.add("simt_pack_weight", w.data_ptr(), wt.data_ptr(), cout, hd.cin, 9, row, 9 * i, kexp, QP, 1,
                                    None, ops.dt_code(self.dtype))
             row += cout
-        self._conv(b, G, (wt, tile, npad), dfeat, Bn=B, Hi=hd.h, Wi=hd.w, Cin=kexp, Ho=hd.h, Wo=hd.w, Cout=hd.cin,
-                   taps=[(0, 0)], res=dz_prev, alg_k=nt * hd.Q, mask=getattr(hd, "mask", None))
+        if getattr(hd, "mask", None) is not None:
+            bnr = None
+        dsc = self._conv(b, G, (wt, tile, npad), dfeat, Bn=B, Hi=hd.h, Wi=hd.w, Cin=kexp, Ho=hd.h, Wo=hd.w, Cout=hd.cin,
+                         taps=[(0, 0)], res=dz_prev, alg_k=nt * hd.Q, mask=getattr(hd, "mask", None), bnr=bnr)
+        self._head_bnr_nblk = self._fused_nblk(dsc, bnr)
         return dfeat
 
     # ------------------------------------------------------------------ run
