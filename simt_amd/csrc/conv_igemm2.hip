@@ -392,92 +392,94 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
       load8(a.bnr_rstd + n, brs);
       if (a.bnr_mode == 2) { load8(a.bnr_scale + n, bsc); load8(a.bnr_shift + n, bsh); }
     }
+    // Operands the epilogue reads from global memory (residual, its bit mask, the saved activation of the fused BatchNorm-backward
+    // reduce, the VGG ReLU mask) are fetched ONE ROW AHEAD: their HBM latency overlaps the previous row's arithmetic and stores.
+    struct Aux { uint4 res, by, mk; unsigned rbits, ybits; };
+    auto fetch = [&](int m) {
+      Aux x;
+      x.res = x.by = x.mk = make_uint4(0u, 0u, 0u, 0u);
+      x.rbits = x.ybits = 0xffu;
+      if (a.res) {
+        x.res = *(const uint4*)(a.res + (long)m * a.ldr + n);
+        if (a.res_bits) x.rbits = a.res_bits[((long)m * a.ldr + n) >> 3];
+      }
+      if (a.bnr_mode) {
+        x.by = *(const uint4*)(a.bnr_y + (long)m * a.bnr_ld + n);
+        if (a.bnr_mode == 3) x.ybits = a.bnr_bits[((long)m * a.bnr_ld + n) >> 3];
+      }
+      if (a.mask) x.mk = *(const uint4*)(a.mask + (long)m * a.ldm + n);
+      return x;
+    };
+    auto unpack = [](const uint4& q, float* v) {
+      v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
+      v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+      v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xffff0000u);
+      v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xffff0000u);
+    };
+    const bool aux = a.res || a.bnr_mode || a.mask;
+    Aux nxt;
+    nxt.res = nxt.by = nxt.mk = make_uint4(0u, 0u, 0u, 0u);
+    nxt.rbits = nxt.ybits = 0xffu;
+    if (aux && rg < BM && m0 + rg < m_end) nxt = fetch(m0 + rg);
     for (int r = rg; r < BM; r += RPP) {
       const int m = m0 + r;
       if (m >= m_end) break;
+      const Aux cur = nxt;
+      if (aux && r + RPP < BM && m + RPP < m_end) nxt = fetch(m + RPP);
       const uint2 lo = *(const uint2*)(sC + r * CP + vcol * 2);
       const uint2 hi = *(const uint2*)(sC + r * CP + vcol * 2 + 8);
-      uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      const uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      if (plain && !a.stats && !a.bnr_mode) {
+        *(uint4*)(a.y + (long)m * a.ldy + n) = o;
+        continue;
+      }
+      float v[8];
+      unpack(o, v);
+      if (a.stats) {                               // forward: statistics of the stored value, before bias / residual / ReLU
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+      }
+      if (plain) {
+        *(uint4*)(a.y + (long)m * a.ldy + n) = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+        if (a.res) {
+          float rv[8];
+          unpack(cur.res, rv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += ((cur.rbits >> e) & 1u) ? rv[e] : 0.f;
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if (a.mask) {
+          float mv[8];
+          unpack(cur.mk, mv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+        }
+        store8(a.y + (long)m * a.ldy + n, v);
+      }
       if (a.bnr_mode) {
-        // the value that is stored (bf16), masked like the backward would mask it, reduced against xhat of the saved activation
-        float v[8];
-        v[0] = __uint_as_float(o.x << 16); v[1] = __uint_as_float(o.x & 0xffff0000u);
-        v[2] = __uint_as_float(o.y << 16); v[3] = __uint_as_float(o.y & 0xffff0000u);
-        v[4] = __uint_as_float(o.z << 16); v[5] = __uint_as_float(o.z & 0xffff0000u);
-        v[6] = __uint_as_float(o.w << 16); v[7] = __uint_as_float(o.w & 0xffff0000u);
+        // backward: S1 = sum g, S2 = sum g * xhat on the value as stored (bf16), masked like the backward masks it
         if (!plain) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bias8[e];
-          if (a.res) {
-            float rv[8];
-            load8(a.res + (long)m * a.ldr + n, rv);
-            if (a.res_bits) {
-              const unsigned b = a.res_bits[((long)m * a.ldr + n) >> 3];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) rv[e] = ((b >> e) & 1u) ? rv[e] : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rv[e];
-          }
-          store8(a.y + (long)m * a.ldy + n, v);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));        // what the separate reduce pass would read back
-        } else {
-          *(uint4*)(a.y + (long)m * a.ldy + n) = o;
+          for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
         }
         float yv[8];
-        load8(a.bnr_y + (long)m * a.bnr_ld + n, yv);
+        unpack(cur.by, yv);
         if (a.bnr_mode == 2) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (yv[e] * bsc[e] + bsh[e]) > 0.f ? v[e] : 0.f;
         } else {
-          const unsigned b = a.bnr_bits[((long)m * a.bnr_ld + n) >> 3];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = ((b >> e) & 1u) ? v[e] : 0.f;
+          for (int e = 0; e < 8; ++e) v[e] = ((cur.ybits >> e) & 1u) ? v[e] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * ((yv[e] - bmu[e]) * brs[e]); }
-        continue;
       }
-      if (!plain || a.stats) {
-        float v[8];
-        v[0] = __uint_as_float(o.x << 16); v[1] = __uint_as_float(o.x & 0xffff0000u);
-        v[2] = __uint_as_float(o.y << 16); v[3] = __uint_as_float(o.y & 0xffff0000u);
-        v[4] = __uint_as_float(o.z << 16); v[5] = __uint_as_float(o.z & 0xffff0000u);
-        v[6] = __uint_as_float(o.w << 16); v[7] = __uint_as_float(o.w & 0xffff0000u);
-        if (a.stats) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
-        }
-        if (!plain) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bias8[e];
-          if (a.res) {
-            float rv[8];
-            load8(a.res + (long)m * a.ldr + n, rv);
-            if (a.res_bits) {
-              const unsigned b = a.res_bits[((long)m * a.ldr + n) >> 3];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) rv[e] = ((b >> e) & 1u) ? rv[e] : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rv[e];
-          }
-          if (a.relu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-          }
-          if (a.mask) {
-            float mv[8];
-            load8(a.mask + (long)m * a.ldm + n, mv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
-          }
-          store8(a.y + (long)m * a.ldy + n, v);
-          continue;
-        }
-      }
-      *(uint4*)(a.y + (long)m * a.ldy + n) = o;
     }
   }
   if (a.stats || a.bnr_mode) {
