@@ -14,6 +14,7 @@
 // split over pixel ranges (split-K); partial tiles go to an f32 slab [split][Cout][Ktot] that
 // simt_wgrad_reduce sums in fixed order (bitwise reproducible) into the OIHW fp32 gradient.
 #include "common.h"
+#include <stdio.h>
 
 struct WgradKArgs {
   const char* dy;
@@ -237,8 +238,16 @@ extern "C" int simt_conv_wgrad(const simt_wgrad_desc* d, simt_stream_t stream) {
   const int epc = 16 / esz;
   SIMT_CHECK(d->Cin % epc == 0 && d->Cd % epc == 0 && d->ldd % epc == 0 && d->Cd <= d->ldd);
   SIMT_CHECK(d->nsplit >= 1);
-  if (d->dtype == SIMT_BF16 && d->Cd >= 128 && d->ntaps * d->Cin >= 256 && (d->stride != 1 || (d->H == d->Ho && d->W == d->Wo)))
-    return simt_conv_wgrad_bf16_v2(d, stream);
+  {
+    static int min_cd = -1, min_k = 0;
+    if (min_cd < 0) {
+      const char* e = getenv("SIMT_WGRAD2_MIN");          // "cd,k" thresholds of the 128x256-tile kernel (experiments)
+      min_cd = 64; min_k = 64;     // partial tiles are zero-filled; even at Cd = K = 64 it beats the 128x128 kernel (44 vs 59 us)
+      if (e) sscanf(e, "%d,%d", &min_cd, &min_k);
+    }
+    if (d->dtype == SIMT_BF16 && d->Cd >= min_cd && d->ntaps * d->Cin >= min_k && (d->stride != 1 || (d->H == d->Ho && d->W == d->Wo)))
+      return simt_conv_wgrad_bf16_v2(d, stream);
+  }
   WgradKArgs k;
   k.dy = (const char*)d->dy; k.x = (const char*)d->x; k.slab = d->slab; k.zero = (const char*)simt_zero_page();
   k.B = d->B; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Ho = d->Ho; k.Wo = d->Wo; k.Cd = d->Cd; k.ldd = d->ldd;

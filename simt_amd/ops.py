@@ -108,13 +108,13 @@ def conv_wgrad_desc(d):
 
 
 def wgrad_nsplit(M, Cd, Ktot, dtype, target_wg=768):
-    """Split factor over the pixel dimension.  bf16 / Cd >= 128 / Ktot >= 256 runs the 128x256-tile kernel with one
+    """Split factor over the pixel dimension.  bf16 / Cd >= 64 / Ktot >= 64 runs the 128x256-tile kernel with one
     workgroup per CU: aim at a whole number of 256-CU rounds; otherwise the 128x128 kernel at ~3 workgroups per CU."""
-    if dtype == torch.bfloat16 and Cd >= 128 and Ktot >= 256:
+    if dtype == torch.bfloat16 and Cd >= 64 and Ktot >= 64:
         tiles = ((Cd + 127) // 128) * ((Ktot + 255) // 256)
         max_split = max(1, M // (64 * 8))
         best, best_cost = 1, None
-        for ns in range(1, min(max_split, 64) + 1):
+        for ns in range(1, min(max_split, 256) + 1):     # one-tile problems (layer1, stem) need up to 256 splits to fill the chip
             rounds = -(-tiles * ns // 256)
             stages = -(-M // (ns * 64))
             cost = rounds * (stages + 6)            # + epilogue/prologue per workgroup
