@@ -842,13 +842,15 @@ class TrunkPlan:
         dl = self.dlogits[hd.name]
         Mh = B * hd.h * hd.w
         nd = len(hd.dilations)
-        # bias gradients: column sums of dlogits, written straight into every live branch's bias gradient
+        # bias gradients: ONE column sum of dlogits over all Q columns, then copied into every live branch's bias gradient
+        # (the branches of a group are summed in the forward, so their bias gradients are equal)
+        colq = self.new(hd.ck, dtype=torch.float32, zero=True)
+        b.add("simt_colsum", dl.data_ptr(), colq.data_ptr(), Mh, hd.ck, hd.Q, 0, ops.dt_code(self.dtype), stream=1)
         row = 0
         for prefix, cout in hd.groups:
             for i in range(nd):
                 gname = f"{prefix}.conv2d_list.{i}.bias"
-                b.add("simt_colsum", dl.data_ptr() + row * self.esz, self.grads[gname].data_ptr(), Mh, hd.ck, cout, 0,
-                      ops.dt_code(self.dtype), stream=1)
+                b.add("simt_vec_acc", self.grads[gname].data_ptr(), colq.data_ptr() + 4 * row, cout, 0, stream=1)
                 self.grad_ready[gname] = len(b)
             row += cout
         dfeat = self.buf("g.dfeat%d" % hd.feat_layer, Mo, c4)
