@@ -32,9 +32,7 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(SgdArgs a) {
   long long end = start + a.chunk;
   if (end > s.n) end = s.n;
   const float lr = a.lr[s.group], wd = a.wd[s.group];
-  for (long long i = start + threadIdx.x; i < end; i += 256) {
-    float p = s.p[i], g = s.g[i];
-    float buf = a.first_step ? 0.f : s.buf[i];
+  auto upd = [&](float& p, float g, float& buf) {
     for (int r = 0; r < s.mult; ++r) {
       float d = wd != 0.f ? g + wd * p : g;
       if (a.momentum != 0.f) {
@@ -43,6 +41,26 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(SgdArgs a) {
       }
       p = p - lr * d;
     }
+  };
+  long long i0 = start;
+  // 16-byte path (the flat gradient buffer packs tensors back to back, so a segment's gradient may start unaligned)
+  if ((((uintptr_t)(s.p + start) | (uintptr_t)(s.g + start) | (uintptr_t)(s.buf + start)) & 15) == 0) {
+    const long long n4 = (end - start) >> 2;
+    for (long long q = threadIdx.x; q < n4; q += 256) {
+      const long long i = start + (q << 2);
+      float4 p = *(const float4*)(s.p + i);
+      const float4 g = *(const float4*)(s.g + i);
+      float4 b = a.first_step ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(s.buf + i);
+      upd(p.x, g.x, b.x); upd(p.y, g.y, b.y); upd(p.z, g.z, b.z); upd(p.w, g.w, b.w);
+      *(float4*)(s.p + i) = p;
+      if (a.momentum != 0.f) *(float4*)(s.buf + i) = b;
+    }
+    i0 = start + (n4 << 2);
+  }
+  for (long long i = i0 + threadIdx.x; i < end; i += 256) {
+    float p = s.p[i], g = s.g[i];
+    float buf = a.first_step ? 0.f : s.buf[i];
+    upd(p, g, buf);
     s.p[i] = p;
     if (a.momentum != 0.f) s.buf[i] = buf;
   }
