@@ -584,13 +584,13 @@ struct PackJob {
 // One block = one 32 (cout) x 32 (cin) tile of one job, all RS taps: the OIHW source is read as 32 contiguous runs of
 // 32*RS floats, transposed through LDS, and written with the destination's fastest index across lanes (2-byte scattered
 // stores made the first version of this kernel 10x slower than the bytes it moves).
-__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackJob* jobs, const int* chunks, int /*chunk*/) {
-  __shared__ float tile[9 * 32 * 33];
-  const PackJob j = jobs[chunks[2 * blockIdx.x]];
-  const int tidx = chunks[2 * blockIdx.x + 1];
+// RSC > 0: compile-time tap count (1x1 and 3x3 cover all but the 7x7 stem): the (co, ci, t) index arithmetic of the read pass is
+// multiply-shift instead of runtime integer division.
+template <int RSC>
+__device__ __forceinline__ void pack_tile(const PackJob& j, int tidx, float* tile) {
   const int ntc = (j.Cin + 31) >> 5;
   const int co0 = (tidx / ntc) << 5, ci0 = (tidx % ntc) << 5;
-  const int RS = j.RS;
+  const int RS = RSC > 0 ? RSC : j.RS;
   const int nci = min(32, j.Cin - ci0), nco = min(32, j.Cout - co0);
   for (int tb = 0; tb < RS; tb += 9) {          // RS <= 9 in one pass (3x3); larger kernels in slices of 9 taps
     const int nt = min(9, RS - tb);
@@ -620,6 +620,14 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackJob* j
       if (j.dtype == SIMT_BF16) ((bf16_t*)j.dst)[o] = f2bf(v); else ((float*)j.dst)[o] = v;
     }
   }
+}
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackJob* jobs, const int* chunks, int /*chunk*/) {
+  __shared__ float tile[9 * 32 * 33];
+  const PackJob j = jobs[chunks[2 * blockIdx.x]];
+  const int tidx = chunks[2 * blockIdx.x + 1];
+  if (j.RS == 1) pack_tile<1>(j, tidx, tile);
+  else if (j.RS == 9) pack_tile<9>(j, tidx, tile);
+  else pack_tile<0>(j, tidx, tile);
 }
 extern "C" int simt_pack_weight_multi(const void* jobs, const void* chunks, int nchunks, int chunk, simt_stream_t stream) {
   SIMT_CHECK(jobs && chunks && nchunks > 0);
