@@ -829,42 +829,73 @@ extern "C" int simt_maxpool2_bwd(const void* dp, const unsigned char* idx, const
   return SIMT_OK;
 }
 
-// Bias gradients of wide layers: out[c] = sum_m src[m*ld + c], c < C (any C multiple of 8).  Two deterministic stages:
-// COLSUMW_G row ranges -> scratch [G][C], then a fixed-order combine.
-#define COLSUMW_G 64
+// Bias gradients of wide layers: out[c] = sum_m src[m*ld + c], c < C (C a multiple of 8, <= 2048).  Two deterministic stages:
+// COLSUMW_G row ranges -> scratch [G][C] (16-byte loads: a block covers 256 / (C/8) rows per pass), then a fixed-order combine.
+// (The first version read 2 bytes per lane from 64 x C/64 blocks: 610 us per launch on the 2M x 64 gradient of VGG's conv1_1.)
+#define COLSUMW_G 1024
 #define COLSUMW_MAXC 2048
 __device__ float g_colsumw_ws[COLSUMW_G * COLSUMW_MAXC];
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_wide_partial_kernel(const T* src, long M, int ld, int C) {
-  // grid (G, ceil(C/64)); block: 64 channels x 4 row lanes
-  __shared__ float red[4][64];
-  const int c = blockIdx.y * 64 + (threadIdx.x & 63), lr = threadIdx.x >> 6;
-  long rows = (M + COLSUMW_G - 1) / COLSUMW_G;
-  long m0 = (long)blockIdx.x * rows, m1 = m0 + rows;
-  if (m1 > M) m1 = M;
-  float s = 0.f;
-  if (c < C)
-    for (long m = m0 + lr; m < m1; m += 4) s += Elem<T>::ld(src + m * ld + c);
-  red[lr][threadIdx.x & 63] = s;
+__global__ __launch_bounds__(256) void colsum_wide_partial_kernel(const T* src, long M, int ld, int C, int rows_per_block) {
+  __shared__ float red[256][8 + 1];
+  const int vpr = C >> 3;              // 16-byte (bf16) / 32-byte (fp32) vectors per row, <= 256
+  const int rpar = 256 / vpr;          // rows in parallel
+  const int tid = threadIdx.x, vc = tid % vpr, rl = tid / vpr;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  if (rl < rpar) {
+    long r = r0 + rl;
+    for (; r + 3 * rpar < r1; r += 4 * rpar) {        // four independent 16-byte loads in flight per thread
+      float v[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) load8(src + (r + u * rpar) * ld + (vc << 3), v[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += v[u][e];
+    }
+    for (; r < r1; r += rpar) {
+      float v[8];
+      load8(src + r * ld + (vc << 3), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[tid][e] = s[e];
   __syncthreads();
-  if (lr == 0 && c < C) g_colsumw_ws[(long)blockIdx.x * COLSUMW_MAXC + c] = (red[0][c & 63] + red[1][c & 63]) + (red[2][c & 63] + red[3][c & 63]);
+  for (int cc = tid; cc < C; cc += 256) {          // fixed-order fold of the rpar row lanes
+    const int v = cc >> 3, e = cc & 7;
+    float t = 0.f;
+    for (int q = 0; q < rpar; ++q) t += red[q * vpr + v][e];
+    g_colsumw_ws[(long)blockIdx.x * C + cc] = t;
+  }
 }
-__global__ void colsum_wide_final_kernel(float* out, int C) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double t = 0.0;
-  for (int b = 0; b < COLSUMW_G; ++b) t += (double)g_colsumw_ws[(long)b * COLSUMW_MAXC + c];
-  out[c] = (float)t;
+__global__ __launch_bounds__(256) void colsum_wide_final_kernel(float* out, int C, int nblk) {
+  // 8 channels x 32 row lanes per block, at most nblk/32 dependent loads per thread (the serial version spent ~0.5 ms here)
+  __shared__ double red[32][8][1];
+  double s[1];
+  part_colsum8<1>(g_colsumw_ws, nblk, C, blockIdx.x * 8, s, red);
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  if ((threadIdx.x >> 3) == 0 && c < C) out[c] = (float)s[0];
 }
 extern "C" int simt_colsum_wide(const void* src, float* out, long M, int ld, int C, int dtype, simt_stream_t stream) {
-  SIMT_CHECK(src && out && C > 0 && C <= COLSUMW_MAXC);
-  dim3 grid(COLSUMW_G, (C + 63) / 64);
+  SIMT_CHECK(src && out && C > 0 && C <= COLSUMW_MAXC && C % 8 == 0 && 256 % (C / 8) == 0 && ld % 8 == 0);
+  const int rpar = 256 / (C / 8);
+  long rpb = (M + COLSUMW_G - 1) / COLSUMW_G;
+  rpb = ((rpb + rpar - 1) / rpar) * rpar;
+  if (rpb < rpar) rpb = rpar;
+  const int nblk = (int)((M + rpb - 1) / rpb);
   if (dtype == SIMT_BF16)
-    hipLaunchKernelGGL(colsum_wide_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, M, ld, C);
+    hipLaunchKernelGGL(colsum_wide_partial_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, M, ld, C, (int)rpb);
   else
-    hipLaunchKernelGGL(colsum_wide_partial_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, M, ld, C);
+    hipLaunchKernelGGL(colsum_wide_partial_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)src, M, ld, C, (int)rpb);
   SIMT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_wide_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, C);
+  hipLaunchKernelGGL(colsum_wide_final_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, out, C, nblk);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
