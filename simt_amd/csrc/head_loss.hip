@@ -404,21 +404,30 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
 //   [16+2QC+2QMAX  .. +QMAX)      anchor pixel index1 (as float bits of int), then index2 [QMAX]
 //   [16+2QC+4QMAX  .. +QC)        dTy1 = d(loss_y1)/dT1 (mean-normalised, unweighted), then dTy2
 // --------------------------------------------------------------------------------------------------------
-// Column sums of the block partials, 32 columns x 8 row lanes per block (fixed combination order, double precision):
-// replaces a single block walking 2048 rows serially (2.5 ms at 4x768x768).
+// Column sums of the block partials, 8 columns x 32 row lanes per block, four independent loads per thread and pass (fixed
+// combination order, double precision): a single block walking 2048 rows took 2.5 ms at 4x768x768, 32 columns x 8 lanes 71 us.
 __global__ __launch_bounds__(256) void head_reduce_kernel(const float* part, int nblk, int stride, int ncols, double* sums) {
-  __shared__ double red[8][32];
-  const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double red[32][8];
+  const int cl = threadIdx.x & 7, r = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   double s = 0.0;
-  if (c < ncols)
-    for (int b = r; b < nblk; b += 8) s += (double)part[(long)b * stride + c];
+  if (c < ncols) {
+    int b = r;
+    for (; b + 96 < nblk; b += 128) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = part[(long)(b + 32 * u) * stride + c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += (double)v[u];
+    }
+    for (; b < nblk; b += 32) s += (double)part[(long)b * stride + c];
+  }
   red[r][cl] = s;
   __syncthreads();
   if (r == 0 && c < ncols) {
     double t = 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) t += red[q][cl];
+    for (int q = 0; q < 32; ++q) t += red[q][cl];
     sums[c] = t;
   }
 }
@@ -715,7 +724,7 @@ extern "C" int simt_head_loss(const simt_head_desc* d, simt_stream_t stream) {
   {
     const int ncols = NSCAL + 2 * d->Q * d->C;
     double* sums = (double*)(d->hout + ((16 + 4 * d->Q * d->C + 4 * QMAX + 1) & ~1));
-    hipLaunchKernelGGL(head_reduce_kernel, dim3((ncols + 31) / 32), dim3(256), 0, st, d->part, nblk, ncols, ncols, sums);
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((ncols + 7) / 8), dim3(256), 0, st, d->part, nblk, ncols, ncols, sums);
     SIMT_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, st, a, nblk);
