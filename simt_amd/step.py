@@ -226,10 +226,17 @@ class SimTTrainer:
         if len(images) != hp.iter_size or len(labels) != hp.iter_size:
             raise ValueError(f"step() needs {hp.iter_size} micro-batch(es) (hp.iter_size), got {len(images)}")
         # 1. inner W loop (NTM grads start from zero each iteration: optimizer_t*.zero_grad(), :314-318)
-        self._ntm_grad_flat.zero_()
-        ni = self.inner_desc
-        ni.step0, ni.lr = self.inner_steps * self.it_done, lr_T
-        L.call("simt_ntm_inner_loop", C.byref(ni), st)
+        # It only feeds the head (T, W) and the Adam step: it runs on the side stream, ahead of the frozen model's forward, instead
+        # of in front of the trainable forward (150 us of a single-block kernel off the critical path).
+        main, side = torch.cuda.current_stream(), side_stream(self.dev)
+        ev0 = torch.cuda.Event()
+        ev0.record(main)                       # the previous step's Adam / head kernels (main stream) come first
+        with torch.cuda.stream(side):
+            side.wait_event(ev0)
+            self._ntm_grad_flat.zero_()
+            ni = self.inner_desc
+            ni.step0, ni.lr = self.inner_steps * self.it_done, lr_T
+            L.call("simt_ntm_inner_loop", C.byref(ni), side.cuda_stream)
         flat = self.plan.flat_grad
         for mi, (img, lab) in enumerate(zip(images, labels)):
             last = mi == hp.iter_size - 1
