@@ -97,12 +97,17 @@ template <typename T>
 __global__ void bn_apply_kernel(const T* y, const float* scale, const float* shift, const T* res, const T* y2,
                                 const float* scale2, const float* shift2, T* z, unsigned char* bits, long nvec, int C, int relu) {
   const int vpr = C >> 3;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-    int c = (int)(i % vpr) << 3;
-    float v[8], sc[8], sh[8];
+  // the grid stride (gridDim * 256) is a multiple of vpr (vpr divides 256, checked by the launcher): a thread's 8 channels never
+  // change, so the per-channel constants are loaded once instead of on every iteration (they were 2-5x the bytes of the data)
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (int)(i0 % vpr) << 3;
+  float sc[8], sh[8], sc2[8], sh2[8];
+  load8(scale + c, sc);
+  load8(shift + c, sh);
+  if (y2) { load8(scale2 + c, sc2); load8(shift2 + c, sh2); }
+  for (long i = i0; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
     load8(y + i * 8, v);
-    load8(scale + c, sc);
-    load8(shift + c, sh);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
     if (res) {
@@ -114,10 +119,8 @@ __global__ void bn_apply_kernel(const T* y, const float* scale, const float* shi
     if (y2) {
       float r[8];
       load8(y2 + i * 8, r);
-      load8(scale2 + c, sc);
-      load8(shift2 + c, sh);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += r[e] * sc[e] + sh[e];
+      for (int e = 0; e < 8; ++e) v[e] += r[e] * sc2[e] + sh2[e];
     }
     if (relu) {
 #pragma unroll
@@ -143,7 +146,7 @@ static inline int ew_grid(long nvec) {
 extern "C" int simt_bn_apply_bits(const void* y, const float* scale, const float* shift, const void* res, const void* y2,
                                   const float* scale2, const float* shift2, void* z, unsigned char* bits, long M, int C,
                                   int relu, int dtype, simt_stream_t stream) {
-  SIMT_CHECK(y && scale && shift && z && C % 8 == 0);
+  SIMT_CHECK(y && scale && shift && z && C % 8 == 0 && 256 % (C / 8) == 0);
   long nvec = M * (C / 8);
   if (dtype == SIMT_BF16)
     hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
@@ -260,24 +263,27 @@ __global__ void bn_bwd_apply_kernel(const T* dz, const T* z, const T* y, const f
                                     const float* mean2, const float* rstd2, const float* scale2, T* dy, T* dy2, T* gout,
                                     long nvec, int C, int mask_mode) {
   const int vpr = C >> 3;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-    int c = (int)(i % vpr) << 3;
-    float g[8], yv[8], mu[8], rs[8], sc[8], c1[8], c2[8];
+  // per-channel constants once per thread (the grid stride is a multiple of vpr, see bn_apply_kernel)
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (int)(i0 % vpr) << 3;
+  float mu[8], rs[8], sc[8], c1[8], c2[8], sh[8], mu2[8], rs2[8], sc2[8], c3[8];
+  load8(mean + c, mu);
+  load8(rstd + c, rs);
+  load8(scale + c, sc);
+  load8(coef + c, c1);
+  load8(coef + C + c, c2);
+  if (mask_mode == 2) load8(shift + c, sh);
+  if (y2) { load8(mean2 + c, mu2); load8(rstd2 + c, rs2); load8(scale2 + c, sc2); load8(coef + 2 * C + c, c3); }
+  for (long i = i0; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    float g[8], yv[8];
     load8(dz + i * 8, g);
     load8(y + i * 8, yv);
-    load8(mean + c, mu);
-    load8(rstd + c, rs);
-    load8(scale + c, sc);
-    load8(coef + c, c1);
-    load8(coef + C + c, c2);
     if (mask_mode == 1) {
       float zv[8];
       load8(z + i * 8, zv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) g[e] = zv[e] > 0.f ? g[e] : 0.f;
     } else if (mask_mode == 2) {
-      float sh[8];
-      load8(shift + c, sh);
 #pragma unroll
       for (int e = 0; e < 8; ++e) g[e] = (yv[e] * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
     } else if (mask_mode == 3) {
@@ -290,14 +296,10 @@ __global__ void bn_bwd_apply_kernel(const T* dz, const T* z, const T* y, const f
     for (int e = 0; e < 8; ++e) o[e] = sc[e] * (g[e] - c1[e] - ((yv[e] - mu[e]) * rs[e]) * c2[e]);
     store8(dy + i * 8, o);
     if (y2) {
-      float y2v[8], c3[8];
+      float y2v[8];
       load8(y2 + i * 8, y2v);
-      load8(mean2 + c, mu);
-      load8(rstd2 + c, rs);
-      load8(scale2 + c, sc);
-      load8(coef + 2 * C + c, c3);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = sc[e] * (g[e] - c1[e] - ((y2v[e] - mu[e]) * rs[e]) * c3[e]);
+      for (int e = 0; e < 8; ++e) o[e] = sc2[e] * (g[e] - c1[e] - ((y2v[e] - mu2[e]) * rs2[e]) * c3[e]);
       store8(dy2 + i * 8, o);
     }
     if (gout) store8(gout + i * 8, g);
