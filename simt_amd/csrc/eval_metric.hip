@@ -138,9 +138,37 @@ __global__ __launch_bounds__(256) void upsample_nchw_kernel(UpArgs a) {
                wy1 * (wx0 * p[((long)y1 * a.w + x0) * a.lds] + wx1 * p[((long)y1 * a.w + x1) * a.lds]);
   }
 }
-// adjoint: dsrc[b][yl][xl][c] = sum over (y, x) of w(y,yl) * w(x,xl) * ddst[b][c][y][x]   (gather form, deterministic)
+// adjoint: dsrc[b][yl][xl][c] = sum over (y, x) of w(y,yl) * w(x,xl) * ddst[b][c][y][x]   (gather form, deterministic).
+// Separable: pass 1 folds x (tmp[b][c][y][xl] = sum_x w(x,xl) ddst[b][c][y][x]), pass 2 folds y -- the one-pass version
+// evaluated ~2 700 weight pairs per low-res element (0.67 ms at 4 x 25 x 512 x 1024).
+__device__ __forceinline__ void up_range(int l, int in, int out, float scale, int& lo, int& hi) {
+  if (scale > 0.f) {
+    const float r = 1.f / scale;
+    lo = (int)floorf(((float)l - 1.f) * r) - 2;
+    hi = (int)ceilf(((float)l + 2.f) * r) + 2;
+  } else { lo = 0; hi = out - 1; }
+  lo = max(lo, 0); hi = min(hi, out - 1);
+}
+__global__ __launch_bounds__(256) void upsample_bwd_x_kernel(const float* ddst, float* tmp, UpArgs a) {
+  const long total = (long)a.B * a.C * a.H * a.w;          // tmp[b][c][y][xl]
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xl = (int)(i % a.w);
+    const long row = i / a.w;                              // (b*C + c)*H + y
+    int xlo, xhi;
+    up_range(xl, a.w, a.W, a.sx, xlo, xhi);
+    const float* g = ddst + row * a.W;
+    float s = 0.f;
+    for (int x = xlo; x <= xhi; ++x) {
+      int x0, x1; float wx0, wx1;
+      up_taps(x, a.w, a.sx, a.align, x0, x1, wx0, wx1);
+      const float wx = (x0 == xl ? wx0 : 0.f) + (x1 == xl ? wx1 : 0.f);
+      s += wx * g[x];
+    }
+    tmp[i] = s;
+  }
+}
 template <typename T>
-__global__ __launch_bounds__(256) void upsample_nchw_bwd_kernel(const float* ddst, T* dsrc, UpArgs a) {
+__global__ __launch_bounds__(256) void upsample_bwd_y_kernel(const float* tmp, T* dsrc, UpArgs a) {
   const long total = (long)a.B * a.h * a.w * a.C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % a.C);
@@ -148,25 +176,15 @@ __global__ __launch_bounds__(256) void upsample_nchw_bwd_kernel(const float* dds
     const int xl = (int)(t % a.w); t /= a.w;
     const int yl = (int)(t % a.h);
     const int b = (int)(t / a.h);
-    const float ry = a.sy > 0.f ? 1.f / a.sy : 0.f, rx = a.sx > 0.f ? 1.f / a.sx : 0.f;
-    int ylo = a.sy > 0.f ? (int)floorf(((float)yl - 1.f) * ry) - 2 : 0, yhi = a.sy > 0.f ? (int)ceilf(((float)yl + 2.f) * ry) + 2 : a.H - 1;
-    int xlo = a.sx > 0.f ? (int)floorf(((float)xl - 1.f) * rx) - 2 : 0, xhi = a.sx > 0.f ? (int)ceilf(((float)xl + 2.f) * rx) + 2 : a.W - 1;
-    ylo = max(ylo, 0); yhi = min(yhi, a.H - 1); xlo = max(xlo, 0); xhi = min(xhi, a.W - 1);
-    const float* g = ddst + ((long)b * a.C + c) * a.H * a.W;
+    int ylo, yhi;
+    up_range(yl, a.h, a.H, a.sy, ylo, yhi);
+    const float* g = tmp + ((long)(b * a.C + c) * a.H) * a.w + xl;
     float s = 0.f;
     for (int y = ylo; y <= yhi; ++y) {
       int y0, y1; float wy0, wy1;
       up_taps(y, a.h, a.sy, a.align, y0, y1, wy0, wy1);
       const float wy = (y0 == yl ? wy0 : 0.f) + (y1 == yl ? wy1 : 0.f);
-      if (wy == 0.f) continue;
-      float row = 0.f;
-      for (int x = xlo; x <= xhi; ++x) {
-        int x0, x1; float wx0, wx1;
-        up_taps(x, a.w, a.sx, a.align, x0, x1, wx0, wx1);
-        const float wx = (x0 == xl ? wx0 : 0.f) + (x1 == xl ? wx1 : 0.f);
-        if (wx != 0.f) row += wx * g[(long)y * a.W + x];
-      }
-      s += wy * row;
+      s += wy * g[(long)y * a.w];
     }
     Elem<T>::st(dsrc + ((long)(b * a.h + yl) * a.w + xl) * a.lds + c, s);
   }
@@ -192,17 +210,30 @@ extern "C" int simt_upsample_nchw(const float* src, int B, int h, int w, int lds
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
+// scratch for the separable adjoint: [B][C][H][w] fp32, grown on demand (hipMalloc outside any capture: first call)
+static float* g_upbwd_tmp = nullptr;
+static size_t g_upbwd_cap = 0;
 extern "C" int simt_upsample_nchw_bwd(const float* ddst, int B, int h, int w, int lds, int C, int H, int W, int align_corners,
                                       void* dsrc, int dtype, simt_stream_t stream) {
   SIMT_CHECK(ddst && dsrc && C <= lds);
   UpArgs a; a.src = nullptr; a.dst = nullptr;
   fill_up(a, B, h, w, lds, C, H, W, align_corners);
+  const size_t need = (size_t)B * C * H * w * sizeof(float);
+  if (need > g_upbwd_cap) {
+    if (g_upbwd_tmp) (void)hipFree(g_upbwd_tmp);
+    if (hipMalloc((void**)&g_upbwd_tmp, need) != hipSuccess) { g_upbwd_tmp = nullptr; g_upbwd_cap = 0; SIMT_CHECK(!"hipMalloc of the upsample scratch failed"); }
+    g_upbwd_cap = need;
+  }
+  long t1 = (long)B * C * H * w, g1 = (t1 + 255) / 256;
+  if (g1 > 256 * 32) g1 = 256 * 32;
+  hipLaunchKernelGGL(upsample_bwd_x_kernel, dim3((unsigned)g1), dim3(256), 0, (hipStream_t)stream, ddst, g_upbwd_tmp, a);
+  SIMT_LAUNCH_CHECK();
   long total = (long)B * h * w * C, grid = (total + 255) / 256;
   if (grid > 256 * 16) grid = 256 * 16;
   if (dtype == SIMT_BF16)
-    hipLaunchKernelGGL(upsample_nchw_bwd_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, ddst, (bf16_t*)dsrc, a);
+    hipLaunchKernelGGL(upsample_bwd_y_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g_upbwd_tmp, (bf16_t*)dsrc, a);
   else
-    hipLaunchKernelGGL(upsample_nchw_bwd_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, ddst, (float*)dsrc, a);
+    hipLaunchKernelGGL(upsample_bwd_y_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, g_upbwd_tmp, (float*)dsrc, a);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
