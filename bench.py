@@ -152,11 +152,11 @@ def main():
         peak = MFMA_PEAK_TFLOPS[a.dtype]
         tot_ms = sum(v[0] for v in acc.values())
         traffic, tsrc = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")
         if os.path.exists(pmc):       # HBM bytes per launch from rocprofv3 PMC passes of this same command (see the file)
             for kname, v in json.load(open(pmc))["kernels"].items():
                 if kname.replace("void ", "").strip() == dom:
-                    traffic, tsrc = v["hbm_bytes_per_launch_corrected"], "profiles/r01g_pmc_traffic.json"
+                    traffic, tsrc = v["hbm_bytes_per_launch_corrected"], "profiles/r01h_pmc_traffic.json"
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
                 "alg_bytes_per_launch": int(by / n), "launches_per_step": n,
