@@ -86,3 +86,31 @@ def test_evaluator_end_to_end_small(dev):
     h = fast_hist(gt.numpy().flatten(), got.flatten().astype(np.int64), 19)
     assert np.array_equal(ev.hist.cpu().numpy().reshape(19, 19), h)
     assert miou == round(float(np.nanmean(per_class_iu(h))) * 100, 2)
+
+
+@pytest.mark.parametrize("align", [0, 1])
+@pytest.mark.parametrize("shape", [(2, 7, 9, 25, 32, 56, 72), (1, 32, 64, 19, 24, 512, 1024)])
+def test_upsample_nchw_forward_and_adjoint(dev, align, shape):
+    """simt_upsample_nchw / _bwd (DeepLabv3's in-model F.interpolate, model/deeplabv3.py:137, and the align_corners=True flavour
+    of trainV2_simt.py:301) against torch's bilinear interpolate and its autograd adjoint: 1e-5 of max|ref| (fp32)."""
+    import torch.nn.functional as F
+    from simt_amd import _lib as L, ops
+    B, h, w, C, lds, H, W = shape
+    g = torch.Generator().manual_seed(h * w + align)
+    src = torch.zeros(B, h, w, lds)
+    src[..., :C] = torch.randn(B, h, w, C, generator=g)
+    src_d = src.to(dev)
+    dst = torch.empty(B, C, H, W, device=dev)
+    L.call("simt_upsample_nchw", src_d.data_ptr(), B, h, w, lds, C, H, W, align, dst.data_ptr(), ops.stream_ptr())
+    x = src[..., :C].permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ref = F.interpolate(x, size=(H, W), mode="bilinear", align_corners=bool(align))
+    assert (dst.cpu() - ref.detach()).abs().max().item() < 1e-5 * ref.abs().max().item()
+    up = torch.randn(B, C, H, W, generator=g)
+    (ref * up).sum().backward()
+    for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+        dsrc = torch.zeros(B, h, w, lds, device=dev, dtype=dt)
+        L.call("simt_upsample_nchw_bwd", up.to(dev).data_ptr(), B, h, w, lds, C, H, W, align, dsrc.data_ptr(), ops.dt_code(dt),
+               ops.stream_ptr())
+        got = dsrc[..., :C].float().cpu().permute(0, 3, 1, 2)
+        assert (got - x.grad).abs().max().item() < tol * x.grad.abs().max().item()
+        assert (dsrc[..., C:] == 0).all()
