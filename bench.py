@@ -2,20 +2,28 @@
 """Throughput benchmark of the SimT training iteration on MI355X (BASELINE.json metric: training images/sec at
 768x768, DeepLabv2-R101+SimT).
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a torch.distributed environment: this process spawns `python -m torch.distributed.run --nproc-per-node N ...
+bench.py` BEFORE touching the GPU and passes the child's output through (one rank per GPU over RCCL).  Launched by
+torch.distributed.run directly (RANK / WORLD_SIZE set) it is one rank of that job; WORLD_SIZE must then equal --gpus.
 
 A step = one full SimT iteration (tools/trainV2_simt.py:308-436 of the reference) on one synthetic batch per GPU:
 10-step W inner loop, frozen-model forward, trainable forward (train-mode BN), fused head losses, backward (dgrad +
 wgrad of all 104 trunk convs and the heads), gradient all-reduce (N>1), SGD with duplicate listings + Adam on NTM,
-weight re-packing.  Inputs are resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+weight re-packing.  `value`: inputs resident in HBM when the timed region starts (the contract of this benchmark); the
+PCIe-inclusive rate (uint8 frames uploaded from pinned host memory every step, converted on the device) is reported beside it
+as "h2d_inclusive".  Rank 0 prints ONE JSON line.
 
 Extra objects: "roofline" (dominant kernel class = the implicit-GEMM conv, algorithmic FLOPs / HIP-event time measured
-live in a separate, untimed replay) and "cpu_baseline" (the CPU oracle -- a port of the reference -- timed on the
-host cores on a bounded sample; rank 0, N=1 only).
+live in a separate, untimed replay), "cpu_baseline" (the CPU oracle -- a port of the reference -- timed on the host cores on a
+bounded sample; rank 0, N=1 only), "trained_like_pass" (same workload with checkpoint-like weights so that both confidence
+thresholds are live), "h2d_inclusive".
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,32 +35,44 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense, /opt/skills/guides/MI355X_MICROARCH.md
 FLOP_PER_IMAGE_768 = 3.33e12                            # conv MACs x2, fixed fwd + fwd + bwd
+PMC_FILES = ("r02_pmc_traffic.json", "r01h_pmc_traffic.json")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE config 2: 4)")
     ap.add_argument("--size", type=int, nargs=2, default=[768, 768], metavar=("H", "W"))
     ap.add_argument("--open-classes", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra-passes", action="store_true", help="skip the trained-like and PCIe-inclusive passes")
     ap.add_argument("--skip-unapplied-grads", action="store_true",
                     help="stop the backward at layer3 (the gradients of conv1/layer1/layer2 are never applied by the SimT stage); "
                          "NOT the headline configuration: the default computes everything the reference's iteration computes")
     ap.add_argument("--shapes", action="store_true", help="print a per-shape conv timing table to stderr")
-    ap.add_argument("--cpu-size", type=int, default=768, help="H=W of the CPU-baseline sample (B=1)")
+    ap.add_argument("--cpu-iters", type=int, default=3, help="timed CPU-baseline iterations per point (after one warm-up)")
     return ap.parse_args()
 
 
-def cpu_baseline(K, size):
-    """The oracle (CPU restatement of the reference, pinned by tests/golden) on the host cores: one full iteration at
-    B=1 -- a bounded sample (~10 s) of the same workload.  16 threads: PyTorch's CPU convs slow down when a 2-socket box
-    is oversubscribed (measured earlier on this pool at 768x768: 8 thr 9.9 s, 16 thr 7.3 s, 32 thr 9.4 s, 128 thr 58 s);
-    `cores` reports the count actually used.  Checker-as-baseline only; never on the product path."""
+def spawn_ranks(n):
+    """--gpus N from a plain `python bench.py`: become the launcher.  Nothing in this process has touched the GPU yet."""
+    port = 29500 + (os.getpid() % 2000)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(K, iters):
+    """The oracle (CPU restatement of the reference, pinned by tests/golden) on the host cores: `iters` timed iterations (after one
+    warm-up) at B=1 on config c2's shape (768x768) and on config c1 (512x512) -- a bounded sample of the same workload.  16 threads:
+    PyTorch's CPU convs slow down when a 2-socket box is oversubscribed (measured on this pool at 768x768: 8 thr 9.9 s, 16 thr
+    7.3 s, 32 thr 9.4 s, 128 thr 58 s); `cores` reports the count actually used.  Checker-as-baseline only; never on the product path."""
     from oracle import simt_oracle as so
     cd = so.load_class_dist()
     st = so.recipe_state(so.state_shapes(19, K, True), seed=1234, trained_like=False)
@@ -64,33 +84,49 @@ def cpu_baseline(K, size):
     torch.set_num_threads(nthr)
     img, lab = so.synthetic_batch(1, 129, 129, cd.numpy(), seed=1)
     tr.step(img, lab, 0)                                  # warm-up (thread pool, allocator)
-    img, lab = so.synthetic_batch(1, size, size, cd.numpy(), seed=2)
-    t0 = time.perf_counter()
-    tr.step(img, lab, 1)
-    dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 5), "unit": "images/s", "cores": nthr, "kind": "port",
-            "sample": f"1 iteration, B=1, {size}x{size}, K={K}, fp32, torch CPU, {nthr} threads of {ncpu} ({dt:.1f} s)"}
+    pts = {}
+    it = 1
+    for size in (768, 512):
+        ts = []
+        for k in range(iters):
+            img, lab = so.synthetic_batch(1, size, size, cd.numpy(), seed=2 + it)
+            t0 = time.perf_counter()
+            tr.step(img, lab, it)
+            ts.append(time.perf_counter() - t0)
+            it += 1
+        ts.sort()
+        pts[size] = ts[len(ts) // 2]
+    return {"value": round(1.0 / pts[768], 5), "unit": "images/s", "cores": nthr, "kind": "port",
+            "sample": f"median of {iters} iterations, B=1, 768x768, K={K}, fp32, torch CPU, {nthr} threads of {ncpu} ({pts[768]:.1f} s each)",
+            "c1_512x512": {"value": round(1.0 / pts[512], 5), "s_per_iter": round(pts[512], 2)}}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1)       # (several ranks share a device only in the gloo functional test below)
+    backend = os.environ.get("SIMT_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI; "gloo" only for functional tests on one GPU
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit(f"{world} ranks over RCCL need {world} GPUs, this node shows {ndev}")
+    local = local % max(ndev, 1)       # (several ranks share a device only in the gloo functional test)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("SIMT_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI; "gloo" only for functional tests
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world
         pg = dist.group.WORLD
     from simt_amd import model_spec as ms
     from simt_amd.step import Hyper, SimTTrainer
@@ -99,12 +135,14 @@ def main():
     K = a.open_classes
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     cd = ms.load_class_dist("bapa")
-    st = ms.reference_init(ms.state_shapes(19, K, True), seed=1234)
-    fst = ms.reference_init(ms.state_shapes(19, 0, False), seed=1234)
     hp = Hyper(open_classes=K, lr=6e-4, lr_T=6e-3, skip_unapplied_grads=a.skip_unapplied_grads)       # sh_simt.sh:16
-    tr = SimTTrainer(st, fst, ms.ntm_init(19, K, 1), ms.ntm_init(19, K, 2), hp, cd, a.batch, H, W, dtype=dtype, device=dev,
-                     process_group=pg)
-    img, lab = ms.synthetic_batch(a.batch, H, W, cd, seed=1234 + rank, device=dev)
+
+    def make_trainer(trained_like):
+        init = ms.trained_like_init if trained_like else ms.reference_init
+        st = init(ms.state_shapes(19, K, True), seed=1234)
+        fst = init(ms.state_shapes(19, 0, False), seed=1234 if not trained_like else 4321)
+        return SimTTrainer(st, fst, ms.ntm_init(19, K, 1), ms.ntm_init(19, K, 2), hp, cd, a.batch, H, W, dtype=dtype, device=dev,
+                           process_group=pg)
 
     def barrier():
         torch.cuda.synchronize()
@@ -116,19 +154,34 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        tr.step(img, lab)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        tr.step(img, lab)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(tr, batches, steps, warmup):
+        """`steps` iterations between barriers; returns (seconds for all steps [max over ranks], median per-step ms from HIP events)."""
+        for _ in range(warmup):
+            tr.step(*next(batches))
+        barrier()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        evs[0].record()
+        for i in range(steps):
+            tr.step(*next(batches))
+            evs[i + 1].record()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+        return dt, per[len(per) // 2]
+
+    def resident(seed):
+        img, lab = ms.synthetic_batch(a.batch, H, W, cd, seed=seed, device=dev)
+        while True:
+            yield img, lab
+
+    tr = make_trainer(False)
+    dt, med = timed(tr, resident(1234 + rank), a.steps, a.warmup)
     ms_step = dt / a.steps * 1e3
     value = a.batch * world * a.steps / dt
 
@@ -152,11 +205,12 @@ def main():
         peak = MFMA_PEAK_TFLOPS[a.dtype]
         tot_ms = sum(v[0] for v in acc.values())
         traffic, tsrc = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")
-        if os.path.exists(pmc):       # HBM bytes per launch from rocprofv3 PMC passes of this same command (see the file)
-            for kname, v in json.load(open(pmc))["kernels"].items():
-                if kname.replace("void ", "").strip() == dom:
-                    traffic, tsrc = v["hbm_bytes_per_launch_corrected"], "profiles/r01h_pmc_traffic.json"
+        for fn in PMC_FILES:                 # HBM bytes per launch from rocprofv3 PMC passes of this same command (see the file)
+            pmc = os.path.join(ROOT, "profiles", fn)
+            if traffic is None and os.path.exists(pmc):
+                for kname, v in json.load(open(pmc))["kernels"].items():
+                    if kname.replace("void ", "").strip() == dom:
+                        traffic, tsrc = v["hbm_bytes_per_launch_corrected"], "profiles/" + fn
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
                 "alg_bytes_per_launch": int(by / n), "launches_per_step": n,
@@ -164,21 +218,58 @@ def main():
                 "share_of_step_kernel_time": round(ms_k / tot_ms, 3),
                 "classes": {k: {"ms": round(v[0], 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[1] else None,
                                 "n": v[3]} for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])[:16]}}
+
+    extra = {}
+    if not a.no_extra_passes:
+        # ---- PCIe-inclusive: decoded uint8 frames in pinned host memory -> upload + device conversion every step, one batch ahead
+        from simt_amd.data.pipeline import DevicePrefetcher, InputPrep
+        rgb, lab8 = ms.synthetic_batch_u8(a.batch, H, W, cd, seed=1234 + rank)
+        rgb, lab8 = rgb.pin_memory(), lab8.pin_memory()
+        prep = InputPrep(a.batch, (H, W), (W, H), dev)
+
+        def host_frames():
+            while True:
+                yield rgb, lab8, None
+        pf = DevicePrefetcher(host_frames(), prep)
+        feed = ((x, l) for (x, l, _m) in pf)
+        n2 = max(5, min(a.steps, 20))
+        dt2, med2 = timed(tr, feed, n2, 2)
+        extra["h2d_inclusive"] = {"value": round(a.batch * world * n2 / dt2, 3), "ms_per_step": round(dt2 / n2 * 1e3, 3), "steps": n2,
+                                  "bytes_per_step_per_gpu": int(rgb.numel() + lab8.numel()),
+                                  "what": "uint8 RGB + uint8 labels from pinned host memory each step (double-buffered copy stream), "
+                                          "BGR-mean / CHW / int64 conversion on the device (csrc/input_prep.hip)"}
+        del pf, feed, prep
+        # ---- checkpoint-like weights: the frozen model's posteriors cross both confidence thresholds
+        del tr
+        torch.cuda.empty_cache()
+        tr = make_trainer(True)
+        dt3, med3 = timed(tr, resident(1234 + rank), n2, 3)
+        hout = tr.hout.cpu()
+        P = a.batch * H * W
+        extra["trained_like_pass"] = {"value": round(a.batch * world * n2 / dt3, 3), "ms_per_step": round(dt3 / n2 * 1e3, 3), "steps": n2,
+                                      "pixels_with_confidence_label": int(hout[6].item()), "pixels": P,
+                                      "what": "same workload with ms.trained_like_init weights (non-trivial BN statistics, scaled "
+                                              "classifiers): both --Threshold-high and --Threshold-low branches are populated"}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(K, a.cpu_size)
+        cpu = cpu_baseline(K, a.cpu_iters)
     if rank == 0:
         flop_img = FLOP_PER_IMAGE_768 * (H * W) / (768.0 * 768.0)
+        mode = ("bf16 storage / fp32 accumulate = throughput mode (parity claims 'loss within 1e-4' are made by the fp32 mode of the same "
+                "kernels; bf16 is held to the float64 bf16-storage model, tests/test_gpu_prod_shapes.py)") if a.dtype == "bf16" else "fp32 parity mode"
         line = {"metric": "training images/sec at 768x768, DeepLabv2-R101+SimT", "value": round(value, 3),
                 "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
+                "ms_per_step_median": round(med, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                 "config": {"workload": f"DeepLabv2-ResNet101 + SimT(C=19,K={K}) full training iteration, batch={a.batch}/GPU, "
                                        f"{H}x{W}, {a.dtype}, {world}xMI355X" + (" DP RCCL all-reduce" if world > 1 else "")
                                        + (" [backward stops at layer3: unapplied gradients skipped]" if a.skip_unapplied_grads else ""),
                            "global_batch": a.batch * world, "baseline_config": "configs[1]" if world == 1 else "configs[2]",
+                           "numerics": mode, "inputs": "resident in HBM (see h2d_inclusive for the PCIe-inclusive rate)",
                            "step_tflops_conv_algorithmic": round(value * flop_img / 1e12, 1),
                            "frac_of_conv_roofline": round(value * flop_img / 1e12 / (world * MFMA_PEAK_TFLOPS[a.dtype]), 4)},
                 "roofline": roof, "cpu_baseline": cpu}
+        line.update(extra)
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

@@ -264,6 +264,22 @@ int simt_upsample_nchw(const float* src, int B, int h, int w, int lds, int C, in
 int simt_upsample_nchw_bwd(const float* ddst, int B, int h, int w, int lds, int C, int H, int W, int align_corners,
                            void* dsrc, int dtype, simt_stream_t stream); /* dsrc [B][h][w][lds] in dtype, first C channels */
 
+/* ---- input pipeline (dataset/cityscapes_dataset.py:101-120 after PNG decoding) -----------------------------------------
+ * The reference resizes with Pillow on the CPU (Image.resize BICUBIC / NEAREST) and converts to float32 BGR - mean, CHW.
+ * simt_resample_u8 applies ONE pass of Pillow's 8-bit separable resampler (Resample.c: 22-bit fixed-point coefficients,
+ * result = clip8(((1 << 21) + sum) >> 22)) along x (axis 1: [N][H][W][C] -> [N][H][out][C]) or y (axis 0: -> [N][out][W][C]);
+ * bounds [out][2] = (first source index, count) and kk [out][ksize] are the tables of precompute_coeffs /
+ * normalize_coeffs_8bpc, computed by the caller in double: the output equals Pillow's byte for byte.  C in {1, 3}.
+ * simt_image_to_input: [N][H][W][3] u8 RGB -> [N][3][H][W] fp32, channel c = rgb[2 - c] - mean_c (BGR - IMG_MEAN, :113-116);
+ * rgb_order = 1 keeps RGB (the reference's --random-mirror branch reverses the channel axis, :108-111).
+ * simt_label_nearest: dst[n][y][x] = (int64) src[n][ytab[y]][xtab[flip_x ? Wo-1-x : x]] (ImagingScaleAffine index tables). */
+int simt_resample_u8(const unsigned char* src, unsigned char* dst, int N, int H, int W, int C, int out, int axis,
+                     const int* bounds, const int* kk, int ksize, simt_stream_t stream);
+int simt_image_to_input(const unsigned char* rgb, float* x, int N, int H, int W, float mean0, float mean1, float mean2,
+                        int rgb_order, simt_stream_t stream);
+int simt_label_nearest(const unsigned char* src, long long* dst, int N, int H, int W, int Ho, int Wo, const int* ytab,
+                       const int* xtab, int flip_x, simt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

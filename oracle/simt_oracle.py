@@ -606,3 +606,82 @@ def v3_forward(st, x, layers=(3, 4, 6), openset=False, train=True, acts=None):
     if openset:
         y = torch.cat([y, F.conv2d(x, st["conv_1.weight"], st["conv_1.bias"])], 1)                        # :133-135
     return F.interpolate(y, size=(H, W), mode="bilinear")                                                 # :137
+
+
+# ------------------------------------------------------------------------------------------------------------
+# bf16 storage model of the GPU throughput path: the same network evaluated in float64 with a
+# round-to-bf16 at every point where the HIP path STORES a tensor as bf16 (conv operands and outputs, BN / ReLU
+# outputs); accumulation, BN statistics, head logits and losses stay wide.  It is what a bf16 run of the product is
+# checked against at full depth (tests/test_gpu_prod_shapes.py): the difference that is left is accumulation order
+# plus the occasional 1-ulp bf16 rounding flip, instead of the ~1e-2 of bf16 itself.  Gradients flow straight
+# through the roundings.  Test infrastructure, like the rest of this file.
+# ------------------------------------------------------------------------------------------------------------
+class _RoundBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def q16(t):
+    return _RoundBF16.apply(t)
+
+
+def _bn_fold(st, prefix):
+    scale = st[prefix + ".weight"].float() / torch.sqrt(st[prefix + ".running_var"].float() + BN_EPS)     # fp32 like simt_bn_fold
+    shift = st[prefix + ".bias"].float() - st[prefix + ".running_mean"].float() * scale
+    return scale.double(), shift.double()
+
+
+def bf16_model_forward(st, x, train, openset, layers=LAYERS, heads=("layer5", "layer6")):
+    """deeplab_multi_forward as the bf16 HIP plans store it (engine.py TrunkPlan: train = batch-statistics BN applied by
+    simt_bn_apply to the stored bf16 conv output; eval = BN scale folded into the bf16 weights, shift in the epilogue)."""
+    d = torch.float64
+    x = q16(x.to(d))                                                    # stem im2col matrix is bf16
+
+    def conv(xx, wname, fold=None, **kw):
+        w = st[wname].to(d)
+        if fold is not None:
+            sc, sh = _bn_fold(st, fold)
+            y = F.conv2d(xx, q16(w * sc.view(-1, 1, 1, 1)), **kw) + sh.view(1, -1, 1, 1)
+            return y                                                    # caller applies residual / ReLU, then rounds
+        return q16(F.conv2d(xx, q16(w), **kw))
+
+    def bn(prefix, y):
+        return F.batch_norm(y, None, None, st[prefix + ".weight"].to(d), st[prefix + ".bias"].to(d), training=True, eps=BN_EPS)
+
+    if train:
+        a = q16(F.relu(bn("bn1", conv(x, "conv1.weight", stride=2, padding=3))))
+    else:
+        a = q16(F.relu(conv(x, "conv1.weight", fold="bn1", stride=2, padding=3)))
+    a = F.max_pool2d(a, 3, 2, 1, ceil_mode=True)
+    feats = {}
+    for name, inpl, planes, stride, dil, down in block_specs(layers):
+        if train:
+            a1 = q16(F.relu(bn(f"{name}.bn1", conv(a, f"{name}.conv1.weight", stride=stride))))
+            a2 = q16(F.relu(bn(f"{name}.bn2", conv(a1, f"{name}.conv2.weight", padding=dil, dilation=dil))))
+            out = bn(f"{name}.bn3", conv(a2, f"{name}.conv3.weight"))
+            sc = bn(f"{name}.downsample.1", conv(a, f"{name}.downsample.0.weight", stride=stride)) if down else a
+            a = q16(F.relu(out + sc))
+        else:
+            a1 = q16(F.relu(conv(a, f"{name}.conv1.weight", fold=f"{name}.bn1", stride=stride)))
+            a2 = q16(F.relu(conv(a1, f"{name}.conv2.weight", fold=f"{name}.bn2", padding=dil, dilation=dil)))
+            sc = q16(conv(a, f"{name}.downsample.0.weight", fold=f"{name}.downsample.1", stride=stride)) if down else a
+            a = q16(F.relu(conv(a2, f"{name}.conv3.weight", fold=f"{name}.bn3") + sc))
+        feats[int(name[5])] = a
+
+    def aspp(hname, f):
+        out = None
+        for i, dl in ((0, 6), (1, 12)):
+            y = F.conv2d(f, q16(st[f"{hname}.conv2d_list.{i}.weight"].to(d)), st[f"{hname}.conv2d_list.{i}.bias"].to(d),
+                         padding=dl, dilation=dl)
+            out = y if out is None else out + y
+        return out                                                      # logits stay fp32 on the device: no rounding
+    x1, x2 = aspp(heads[0], feats[3]), aspp(heads[1], feats[4])
+    if openset:
+        x1 = torch.cat([x1, aspp(heads[0] + "_1", feats[3])], 1)
+        x2 = torch.cat([x2, aspp(heads[1] + "_1", feats[4])], 1)
+    return x1, x2

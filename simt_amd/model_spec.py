@@ -76,6 +76,31 @@ def reference_init(shapes, seed=1234, device="cpu"):
     return {k: v.to(device) for k, v in st.items()}
 
 
+def trained_like_init(shapes, seed=1234, head_scale=8.0, device="cpu"):
+    """Deterministic weights that behave like a released checkpoint instead of a fresh constructor: non-trivial BatchNorm affine and
+    running statistics (so that the frozen model's folding and the trainable model's frozen affine matter) and classifier weights
+    scaled up until the frozen model's posteriors spread over the whole (0, 1) range -- some pixels above --Threshold-high, some
+    below --Threshold-low (with the constructor init every posterior is ~1/19 and every pixel is an "open candidate").  One
+    generator per key, so the values do not depend on dict order.  Used by bench.py's second pass and by tools for dry runs."""
+    import zlib
+    st = {}
+    for k, shp in shapes.items():
+        g = torch.Generator().manual_seed((seed ^ zlib.crc32(k.encode())) & 0x7FFFFFFF)
+        if k.endswith("num_batches_tracked"):
+            st[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith("running_mean"):
+            st[k] = torch.randn(shp, generator=g) * 0.05
+        elif k.endswith("running_var"):
+            st[k] = torch.rand(shp, generator=g) * 0.5 + 0.75
+        elif ".bn" in k or k.startswith("bn1") or "downsample.1" in k:
+            st[k] = torch.rand(shp, generator=g) * 0.6 + 0.7 if k.endswith("weight") else torch.randn(shp, generator=g) * 0.1
+        elif k.endswith("bias"):
+            st[k] = torch.randn(shp, generator=g) * 0.01
+        else:
+            st[k] = torch.randn(shp, generator=g) * 0.01 * (head_scale if "conv2d_list" in k else 1.0)
+    return {k: v.to(device) for k, v in st.items()}
+
+
 def load_class_dist(name="bapa", path=None):
     """ClassDist/ClassDist_<name>.npy: float64 [19] class prior of the black-box model's pseudo labels
     (model/deeplab_multi.py:255 reads ../ClassDist/ClassDist_bapa.npy relative to cwd)."""
@@ -114,3 +139,18 @@ def synthetic_batch(B, H, W, class_dist, seed=1234, block=16, device="cpu"):
     lab = torch.where(ign, torch.full_like(lab, 255), lab)
     lab = lab.repeat_interleave(block, 1).repeat_interleave(block, 2)[:, :H, :W].contiguous()
     return img.to(device), lab.long().to(device)
+
+
+def synthetic_batch_u8(B, H, W, class_dist, seed=1234, block=16):
+    """The same synthetic batch as `synthetic_batch`, in the form a decoder hands over: (rgb uint8 [B,H,W,3], label uint8 [B,H,W]) on
+    the host.  simt_amd.data.pipeline.InputPrep turns it into synthetic_batch's tensors on the device (BGR - mean, CHW, int64)."""
+    g = torch.Generator().manual_seed(seed)
+    bgr = torch.randint(0, 256, (B, 3, H, W), generator=g)
+    hb, wb = (H + block - 1) // block, (W + block - 1) // block
+    p = torch.as_tensor(np.asarray(class_dist), dtype=torch.float64)
+    lab = torch.multinomial(p / p.sum(), B * hb * wb, replacement=True, generator=g).view(B, hb, wb)
+    ign = torch.rand(B, hb, wb, generator=g) < 0.1
+    lab = torch.where(ign, torch.full_like(lab, 255), lab)
+    lab = lab.repeat_interleave(block, 1).repeat_interleave(block, 2)[:, :H, :W].contiguous()
+    rgb = bgr.flip(1).permute(0, 2, 3, 1).contiguous().to(torch.uint8)
+    return rgb, lab.to(torch.uint8)

@@ -148,9 +148,12 @@ class SimTTrainer:
         if self.pg is not None:
             from .dp import BucketReducer, make_buckets
             sizes = {n: k for n, (_o, k) in self.plan.grad_offsets.items()}
-            # with skip_unapplied_grads the tail of the flat buffer (layer2, layer1, stem: never written, never applied) is not exchanged
-            order = [n for n in self.plan.grad_order if self.plan.grad_ready.get(n, 0) > 0]
-            assert order == self.plan.grad_order[:len(order)]
+            # Only gradients the optimiser APPLIES cross xGMI: layer3, layer4 and the heads = the head of the flat buffer
+            # (174 of 180 MB).  conv1 / layer1 / layer2 gradients are computed like the reference computes them (unless
+            # skip_unapplied_grads) but the SimT stage's SGD never lists them (model/deeplab_multi.py:194-237): they stay rank-local.
+            applied = set(self.sgd_names)
+            order = [n for n in self.plan.grad_order if n in applied and self.plan.grad_ready.get(n, 0) > 0]
+            assert order == self.plan.grad_order[:len(order)], "applied gradients must form a prefix of the flat buffer"
             end = sum(sizes[n] for n in order)
             buckets = make_buckets(order, sizes, self.plan.grad_ready, bucket_elems=8 << 20)
             self.reducer = BucketReducer(self.plan.flat_grad[:end], buckets, group=self.pg, extra=[self._ntm_grad_flat])

@@ -1,0 +1,43 @@
+"""bench.py as the driver runs it: `--gpus N` must produce an N-rank job and ONE JSON line with n_gpus == N carrying the
+roofline object.  With >= 2 GPUs the ranks talk RCCL; on a 1-GPU box the same launcher path is exercised with two ranks sharing
+the device over gloo (SIMT_DIST_BACKEND=gloo: functional check of spawn + DP step + max-over-ranks timing, not a measurement)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, args):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(extra_env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus2_spawns_two_ranks(dev):
+    small = ["--steps", "2", "--warmup", "1", "--batch", "1", "--size", "129", "129", "--no-cpu-baseline", "--no-extra-passes"]
+    if torch.cuda.device_count() >= 2:
+        line = _run({}, ["--gpus", "2"] + small)
+        assert "RCCL" in line["config"]["workload"]
+    else:
+        line = _run({"SIMT_DIST_BACKEND": "gloo"}, ["--gpus", "2"] + small)
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def test_bench_single_gpu_line_has_every_contract_field(dev):
+    line = _run({}, ["--steps", "3", "--warmup", "1", "--batch", "1", "--size", "257", "257", "--cpu-iters", "1"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "h2d_inclusive", "trained_like_pass", "ms_per_step_median"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["roofline"]["bound"] == "mfma" and line["cpu_baseline"]["kind"] == "port"
+    assert 0 <= line["trained_like_pass"]["pixels_with_confidence_label"] <= line["trained_like_pass"]["pixels"]

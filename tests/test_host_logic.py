@@ -95,3 +95,22 @@ def test_lr_poly_matches_golden():
     e = np.load(os.path.join(ROOT, "tests", "golden", "g10_lr_poly.npz"))
     for i, lr in zip(e["it"], e["lr"]):
         assert lr_poly(6e-4, int(i), 250000, 0.9) == lr
+
+
+def test_bench_gpus_flag_spawns_n_ranks_and_fails_loudly_without_gpu():
+    """`python bench.py --gpus 2` (no torch.distributed environment) must become a 2-rank torch.distributed.run job by itself -- the
+    driver's `--gpus N` is not advisory -- and, on a box without a GPU, every rank must refuse to run (no CPU fallback)."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    err = p.stderr + p.stdout
+    assert err.count("bench.py needs a GPU") >= 2, err[-2000:]                # both ranks got as far as the GPU check
+
+
+def test_bench_rejects_world_size_mismatch():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stderr + p.stdout)
