@@ -43,9 +43,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE config 2: 4)")
-    ap.add_argument("--size", type=int, nargs=2, default=[768, 768], metavar=("H", "W"))
-    ap.add_argument("--open-classes", type=int, default=3)
+    ap.add_argument("--model", default="v2", choices=["v2", "v3", "vgg"],
+                    help="v2: DeepLabv2-R101 (BASELINE configs[1]/[2], the headline); v3: DeepLabv3 + SimT K=6 at 512x1024 (configs[3]); "
+                         "vgg: DeepLab-VGG16 + SimT K=3, batch 8 at 512x512 (configs[4])")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: 4; vgg: 8)")
+    ap.add_argument("--size", type=int, nargs=2, default=None, metavar=("H", "W"), help="default 768 768; v3: 512 1024; vgg: 512 512")
+    ap.add_argument("--open-classes", type=int, default=None, help="default 3; v3: 6")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -55,7 +58,12 @@ def parse():
                          "NOT the headline configuration: the default computes everything the reference's iteration computes")
     ap.add_argument("--shapes", action="store_true", help="print a per-shape conv timing table to stderr")
     ap.add_argument("--cpu-iters", type=int, default=3, help="timed CPU-baseline iterations per point (after one warm-up)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    dflt = {"v2": (4, [768, 768], 3), "v3": (4, [512, 1024], 6), "vgg": (8, [512, 512], 3)}[a.model]
+    a.batch = a.batch if a.batch is not None else dflt[0]
+    a.size = a.size if a.size is not None else dflt[1]
+    a.open_classes = a.open_classes if a.open_classes is not None else dflt[2]
+    return a
 
 
 def spawn_ranks(n):
@@ -138,11 +146,37 @@ def main():
     hp = Hyper(open_classes=K, lr=6e-4, lr_T=6e-3, skip_unapplied_grads=a.skip_unapplied_grads)       # sh_simt.sh:16
 
     def make_trainer(trained_like):
+        if a.model != "v2":
+            from simt_amd.step_single import SimTSingleTrainer
+            if a.model == "v3":
+                from simt_amd.engine_v3 import v3_state_shapes
+                st = ms.kaiming_init(v3_state_shapes(19, K, True), seed=1234)
+                fst = ms.kaiming_init(v3_state_shapes(19, 0, False), seed=1234)
+            else:
+                from simt_amd.engine_vgg import vgg_state_shapes
+                st = ms.kaiming_init(vgg_state_shapes(19 + K), seed=1234)
+                fst = ms.kaiming_init(vgg_state_shapes(19), seed=1234)
+            return SimTSingleTrainer(a.model, st, fst, ms.ntm_init(19, K, 2), hp, cd, a.batch, H, W, dtype=dtype, device=dev, process_group=pg)
         init = ms.trained_like_init if trained_like else ms.reference_init
         st = init(ms.state_shapes(19, K, True), seed=1234)
-        fst = init(ms.state_shapes(19, 0, False), seed=1234 if not trained_like else 4321)
-        return SimTTrainer(st, fst, ms.ntm_init(19, K, 1), ms.ntm_init(19, K, 2), hp, cd, a.batch, H, W, dtype=dtype, device=dev,
-                           process_group=pg)
+        fst = init(ms.state_shapes(19, 0, False), seed=1234)
+        t = SimTTrainer(st, fst, ms.ntm_init(19, K, 1), ms.ntm_init(19, K, 2), hp, cd, a.batch, H, W, dtype=dtype, device=dev,
+                        process_group=pg)
+        if trained_like:
+            # A checkpoint's running statistics describe its own activations.  Synthetic ones do not, and 101 layers of eval-mode BN
+            # with mismatched statistics collapse the frozen model's features (every posterior ~1/19).  Calibrate them: 40 train-mode
+            # forwards of the (identical) trainable trunk on a synthetic batch move its running statistics onto the batch statistics
+            # (momentum 0.1), then the frozen model takes them over and re-folds its BatchNorms.
+            img, _ = ms.synthetic_batch(a.batch, H, W, cd, seed=99, device=dev)
+            t.plan.x_in.copy_(img)
+            for _ in range(40):
+                t.plan.fwd_list.run()
+            for k, v in t.fixed_params.items():
+                if k.endswith("running_mean") or k.endswith("running_var"):
+                    v.copy_(t.params[k])
+            t.fixed.repack()
+            torch.cuda.synchronize()
+        return t
 
     def barrier():
         torch.cuda.synchronize()
@@ -191,9 +225,8 @@ def main():
         for _ in range(2):
             acc.clear()
             shp.clear()
-            tr.fixed.fwd_list.run_timed(acc, shp)
-            tr.plan.fwd_list.run_timed(acc, shp)
-            tr.plan.bwd_list.run_timed(acc, shp)
+            for lst in tr.timed_lists():
+                lst.run_timed(acc, shp)
         if a.shapes and rank == 0:
             for (tag, shape), v in sorted(shp.items(), key=lambda kv: -kv[1][0]):
                 print(f"{tag:28s} {shape:44s} n={v[3]:3d} total {v[0]:7.3f} ms  avg {v[0] / v[3] * 1e3:8.1f} us  "
@@ -220,7 +253,7 @@ def main():
                                 "n": v[3]} for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])[:16]}}
 
     extra = {}
-    if not a.no_extra_passes:
+    if not a.no_extra_passes and a.model == "v2":
         # ---- PCIe-inclusive: decoded uint8 frames in pinned host memory -> upload + device conversion every step, one batch ahead
         from simt_amd.data.pipeline import DevicePrefetcher, InputPrep
         rgb, lab8 = ms.synthetic_batch_u8(a.batch, H, W, cd, seed=1234 + rank)
@@ -254,17 +287,23 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(K, a.cpu_iters)
     if rank == 0:
-        flop_img = FLOP_PER_IMAGE_768 * (H * W) / (768.0 * 768.0)
+        if a.model == "v2":
+            flop_img = FLOP_PER_IMAGE_768 * (H * W) / (768.0 * 768.0)
+        else:                           # algorithmic conv FLOPs of the three launch lists (frozen forward, forward, backward) per image
+            flop_img = sum(it.flops for lst in tr.timed_lists() for it in lst.items if it.fn is not None) / a.batch
+        names = {"v2": ("DeepLabv2-R101+SimT", "DeepLabv2-ResNet101"), "v3": ("DeepLabv3-R50+SimT", "DeepLabv3 (torchvision-style ResNet-50 to layer3 + ASSP)"),
+                 "vgg": ("DeepLab-VGG16+SimT", "DeepLab-VGG16")}[a.model]
+        cfg = {"v2": "configs[1]" if world == 1 else "configs[2]", "v3": "configs[3]", "vgg": "configs[4]"}[a.model]
         mode = ("bf16 storage / fp32 accumulate = throughput mode (parity claims 'loss within 1e-4' are made by the fp32 mode of the same "
                 "kernels; bf16 is held to the float64 bf16-storage model, tests/test_gpu_prod_shapes.py)") if a.dtype == "bf16" else "fp32 parity mode"
-        line = {"metric": "training images/sec at 768x768, DeepLabv2-R101+SimT", "value": round(value, 3),
+        line = {"metric": f"training images/sec at {H}x{W}, {names[0]}", "value": round(value, 3),
                 "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
                 "ms_per_step_median": round(med, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-                "config": {"workload": f"DeepLabv2-ResNet101 + SimT(C=19,K={K}) full training iteration, batch={a.batch}/GPU, "
+                "config": {"workload": f"{names[1]} + SimT(C=19,K={K}) full training iteration, batch={a.batch}/GPU, "
                                        f"{H}x{W}, {a.dtype}, {world}xMI355X" + (" DP RCCL all-reduce" if world > 1 else "")
                                        + (" [backward stops at layer3: unapplied gradients skipped]" if a.skip_unapplied_grads else ""),
-                           "global_batch": a.batch * world, "baseline_config": "configs[1]" if world == 1 else "configs[2]",
+                           "global_batch": a.batch * world, "baseline_config": cfg,
                            "numerics": mode, "inputs": "resident in HBM (see h2d_inclusive for the PCIe-inclusive rate)",
                            "step_tflops_conv_algorithmic": round(value * flop_img / 1e12, 1),
                            "frac_of_conv_roofline": round(value * flop_img / 1e12 / (world * MFMA_PEAK_TFLOPS[a.dtype]), 4)},

@@ -187,6 +187,12 @@ typedef struct {
   float th_high, th_low, lambda_seg, lambda_place, gscale;
   int32_t mode;         /* 0: SimT loss block.  1: warm-up stage (tools/trainV1_warmup.py:217-224): CE of both heads against
                          * `label` (ignore 255); fixp/T1/T2 unused (may be NULL); hout[0],[1] = loss_seg1/2, hout[14] = total */
+  int32_t single;       /* 1: one-output model (model/deeplabv3.py, model/deeplab_vgg.py return ONE tensor): pred1 / T1 / dpred1_* are
+                         * unused (may be NULL) and every auxiliary-head term is dropped; pred2 / T2 / dpred2_* carry the model's head */
+  int32_t up_half_pixel; /* 0: interp_target = nn.Upsample(bilinear, align_corners=True) (tools/trainV2_simt.py:301);
+                          * 1: F.interpolate(bilinear), align_corners=False, the in-model upsample of model/deeplabv3.py:137 fused here */
+  int32_t fix_logits;   /* 1: fixp holds the frozen model's low-res LOGITS; posterior = softmax(upsample(logits)) -- what
+                         * trainV2_simt.py:354 computes for a model that upsamples inside.  0: fixp = low-res probabilities */
 } simt_head_desc;
 int simt_head_nblk(int B, int H, int W);
 int simt_head_part_floats(int Q, int C);
@@ -207,6 +213,7 @@ typedef struct {
   const float* class_dist; /* [C] */
   int32_t Q, C, steps, step0; /* step0 = Adam steps already taken on w */
   float lr, beta1, beta2, eps;
+  int32_t single;       /* 1: only NTM / W number 1 (index [1]) exist -- one-output models; index [0] pointers may be NULL */
 } simt_ntm_inner_desc;
 int simt_ntm_inner_loop(const simt_ntm_inner_desc* d, simt_stream_t stream);
 typedef struct {
@@ -218,6 +225,7 @@ typedef struct {
   float* lout;          /* [16]: total*gscale, loss_p1, loss_p2, loss_y1, loss_y2, Place, Convex, Volume, Anchor, vol_ok */
   int32_t Q, C;
   float lambda_seg, lambda_convex, lambda_volume, lambda_anchor, gscale;
+  int32_t single;       /* 1: Convex / Volume / Anchor / total over NTM [1] only, no lambda_seg terms */
 } simt_ntm_post_desc;
 int simt_ntm_post(const simt_ntm_post_desc* d, simt_stream_t stream);
 int simt_sig_ntm(const float* ntm, const float* class_dist, const float* dT, float* T_out, float* dN_out, int Q, int C,
@@ -262,7 +270,8 @@ int simt_confusion_hist(const int64_t* gt, const int32_t* pred, long P, int n, i
 int simt_upsample_nchw(const float* src, int B, int h, int w, int lds, int C, int H, int W, int align_corners, float* dst,
                        simt_stream_t stream);
 int simt_upsample_nchw_bwd(const float* ddst, int B, int h, int w, int lds, int C, int H, int W, int align_corners,
-                           void* dsrc, int dtype, simt_stream_t stream); /* dsrc [B][h][w][lds] in dtype, first C channels */
+                           void* dsrc, int dtype, float* tmp, simt_stream_t stream); /* dsrc [B][h][w][lds] in dtype, first C
+                           * channels; tmp: caller-owned scratch of B*C*H*w floats (the x-folded intermediate of the separable adjoint) */
 
 /* ---- input pipeline (dataset/cityscapes_dataset.py:101-120 after PNG decoding) -----------------------------------------
  * The reference resizes with Pillow on the CPU (Image.resize BICUBIC / NEAREST) and converts to float32 BGR - mean, CHW.

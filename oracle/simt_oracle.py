@@ -685,3 +685,121 @@ def bf16_model_forward(st, x, train, openset, layers=LAYERS, heads=("layer5", "l
         x1 = torch.cat([x1, aspp(heads[0] + "_1", feats[3])], 1)
         x2 = torch.cat([x2, aspp(heads[1] + "_1", feats[4])], 1)
     return x1, x2
+
+
+# ------------------------------------------------------------------------------------------------------------
+# SimT iteration over a ONE-OUTPUT model (BASELINE configs[3] DeepLabv3, configs[4] DeepLab-VGG16).
+# The reference has no script that trains these files; its only SimT loop is tools/trainV2_simt.py:308-436, written for the
+# two-output DeeplabMulti.  The iteration is defined here as THAT loop with every auxiliary-head object removed
+# (pred1, NTM1, NTM_W1, and the lambda_seg-weighted terms they feed): what is left is, term by term, the reference's code
+# applied to the model's single output.  `simt_losses_single` is tied to the golden-pinned two-head `simt_losses` by an
+# identity checked in tests/test_oracle_golden.py: with pred1 = pred2, T1 = T2, W1 = W2 and lambda_seg = 0,
+#   total_two_head = total_single + lambda_convex * convex + lambda_volume * volume + lambda_anchor * anchor.
+# ------------------------------------------------------------------------------------------------------------
+def simt_losses_single(pred_up, prob_up, label, T, W, hp):
+    """pred_up [B,Q,H,W]: the model's logits at label resolution (requires grad upstream); prob_up [B,C,H,W]: the frozen model's
+    posterior at label resolution (trainV2_simt.py:354: `interp_target(softmax(output))`)."""
+    c = hp.num_classes
+    m, a = prob_up.max(1)                                                     # :355-361
+    conf0 = torch.where(m > hp.th_high, a, torch.full_like(a, 255))
+    conf0 = torch.where(m < hp.th_low, torch.full_like(a, c), conf0)
+    labelC_flat = prob_up.permute(0, 2, 3, 1).reshape(-1, c)
+    anchor, idx, ex = anchor_loss(pred_up, T, labelC_flat)                    # :375-384 (one head)
+    pseudo = pred_up.detach().argmax(1)                                       # :387-393
+    repl = torch.where(pseudo >= c, pseudo, torch.full_like(pseudo, 255))
+    conf = torch.where(conf0 == c, repl, conf0)
+    loss_p = F.cross_entropy(pred_up, conf, ignore_index=255)                 # :395
+    place, known, unknown = placeholder_loss(pred_up, hp)                     # :399
+    loss_y = noisy_nll(pred_up, T, label)                                     # :405-409
+    convex = 0.0 - ((W @ T) ** 2).sum()                                       # :412-416
+    vol = torch.log(torch.sqrt(torch.abs(torch.linalg.det(T.t() @ T))))       # :417-419
+    if torch.isinf(vol) or torch.isnan(vol):
+        vol = 0.0                                                             # :420-421
+    total = place + loss_p + loss_y + hp.lambda_convex * convex + hp.lambda_volume * vol + hp.lambda_anchor * anchor
+    return {"total": total / hp.iter_size, "loss_p": loss_p, "loss_y": loss_y, "place": place, "convex": convex,
+            "volume": vol if torch.is_tensor(vol) else torch.tensor(vol), "anchor": anchor, "conf": conf, "anchor_idx": idx,
+            "exist": ex, "known": known, "unknown": unknown}
+
+
+def inner_w_loop_single(ntm, w, state, class_dist, hp, lr_T, steps=10):
+    """:326-339 with one NTM / W pair: L = ||W T||^2, Adam on W, the gradient leaks into ntm.grad (quirk 3)."""
+    for _ in range(steps):
+        T = sig_ntm_forward(ntm, class_dist, hp.num_classes)
+        Wm = sig_w_forward(w)
+        w.grad = None
+        ((Wm @ T) ** 2).sum().backward()
+        state["step"] += 1
+        with torch.no_grad():
+            adam_step_(w, w.grad, state["m"], state["v"], state["step"], lr_T)
+
+
+def v3_optim_names(shapes, openset):
+    """DeepLabv3.optim_parameters (model/deeplabv3.py:139-166): group 0 = parameters of self.resnet whose name RELATIVE TO self.resnet
+    contains 'resnet_50.layer3' (the walk over every sub-module only matches at the top one, so each tensor is listed once; layer4 /
+    fc never run), group 1 (10x) = assp + conv (+ conv_1)."""
+    g0 = [k for k in shapes if k.startswith("resnet.resnet_50.layer3.") and (k.endswith(".weight") or k.endswith(".bias"))]
+    g1 = [k for k in shapes if (k.startswith("assp.") or k.startswith("conv.") or (openset and k.startswith("conv_1.")))
+          and (k.endswith(".weight") or k.endswith(".bias"))]
+    return g0, g1
+
+
+class OracleSingleTrainer:
+    """One SimT iteration over a one-output model, CPU.  model = "v3" (oracle.v3_forward: upsamples inside, align_corners=False) or
+    "vgg" (oracle.vgg_forward: low-res output, interp_target outside).  Mirrors OracleTrainer."""
+
+    def __init__(self, model, st, fixed_st, ntm, hp, class_dist, arch, dtype=torch.float32):
+        self.model, self.hp, self.cd, self.arch, self.dtype = model, hp, class_dist, arch, dtype
+        cv = lambda d: {k: (v.to(dtype) if v.dtype != torch.long else v) for k, v in d.items()}
+        st, self.fixed = cv(st), {k: v.clone() for k, v in cv(fixed_st).items()}
+        stat = lambda k: k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked")
+        self.st = {k: (v.clone().requires_grad_(True) if not stat(k) else v.clone()) for k, v in st.items()}
+        self.ntm = ntm.to(dtype).clone().requires_grad_(True)
+        q = ntm.shape[0]
+        self.w = w_init(hp.num_classes, q - hp.num_classes).to(dtype).requires_grad_(True)
+        self.wstate = {"step": 0, "m": torch.zeros(q, q, dtype=dtype), "v": torch.zeros(q, q, dtype=dtype)}
+        self.tstate = {"step": 0, "m": torch.zeros_like(self.ntm), "v": torch.zeros_like(self.ntm)}
+        shapes = {k: tuple(v.shape) for k, v in st.items()}
+        if model == "v3":
+            g0, g1 = v3_optim_names(shapes, True)
+            self.groups = [{"names": g0, "lr_mult": 1.0}, {"names": g1, "lr_mult": 10.0}]
+        else:                                             # DeeplabVGG.optim_parameters = self.parameters(): one group (deeplab_vgg.py:53-54)
+            self.groups = [{"names": [k for k in shapes if k.endswith(".weight") or k.endswith(".bias")], "lr_mult": 1.0}]
+        self.bufs, self.first = {}, True
+
+    def forward(self, st, image, train):
+        if self.model == "v3":
+            return v3_forward(st, image, layers=self.arch["layers"], openset="conv_1.weight" in st, train=train)
+        return vgg_forward(st, image, self.arch["layers"])
+
+    def step(self, image, label, it):
+        hp = self.hp
+        lr, lr_T = lr_poly(hp.lr, it, hp.num_steps, hp.power), lr_poly(hp.lr_T, it, hp.num_steps, hp.power)
+        for v in self.st.values():
+            if v.dtype != torch.long:
+                v.grad = None
+        self.ntm.grad = None
+        inner_w_loop_single(self.ntm, self.w, self.wstate, self.cd, hp, lr_T)
+        image = image.to(self.dtype)
+        size = tuple(label.shape[1:])
+        T = sig_ntm_forward(self.ntm, self.cd, hp.num_classes)
+        with torch.no_grad():
+            prob = upsample(torch.softmax(self.forward(self.fixed, image, False), 1), size)       # :352-354 (identity for v3)
+        pred = upsample(self.forward(self.st, image, True), size)                                 # :370-372 (identity for v3)
+        out = simt_losses_single(pred, prob, label, T, sig_w_forward(self.w), hp)
+        out["total"].backward()
+        with torch.no_grad():
+            for g in self.groups:
+                ps, gs, bs, ms = [], [], [], []
+                for n in g["names"]:
+                    p = self.st[n]
+                    if p.grad is None:
+                        continue
+                    if n not in self.bufs:
+                        self.bufs[n] = torch.zeros_like(p)
+                    ps.append(p); gs.append(p.grad); bs.append(self.bufs[n]); ms.append(1)
+                sgd_step_(ps, gs, bs, ms, lr * g["lr_mult"], hp.weight_decay, hp.momentum, self.first)
+            self.first = False
+            s = self.tstate
+            s["step"] += 1
+            adam_step_(self.ntm, self.ntm.grad, s["m"], s["v"], s["step"], lr_T)
+        return out

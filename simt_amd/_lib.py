@@ -48,21 +48,22 @@ class HeadDesc(C.Structure):
                 ("dpred1_t", c_p), ("dpred2_t", c_p),
                 ("B", i32), ("h", i32), ("w", i32), ("H", i32), ("W", i32), ("C", i32), ("Q", i32), ("ldp", i32),
                 ("ldf", i32), ("QP", i32), ("ld_f32", i32), ("ld_t", i32), ("grad_dtype", i32),
-                ("th_high", f32), ("th_low", f32), ("lambda_seg", f32), ("lambda_place", f32), ("gscale", f32), ("mode", i32)]
+                ("th_high", f32), ("th_low", f32), ("lambda_seg", f32), ("lambda_place", f32), ("gscale", f32), ("mode", i32),
+                ("single", i32), ("up_half_pixel", i32), ("fix_logits", i32)]
 
 
 class NtmInnerDesc(C.Structure):
     _fields_ = [("ntm", c_p * 2), ("w", c_p * 2), ("ntm_grad", c_p * 2), ("w_m", c_p * 2), ("w_v", c_p * 2),
                 ("T_out", c_p * 2), ("class_dist", c_p),
                 ("Q", i32), ("C", i32), ("steps", i32), ("step0", i32),
-                ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32)]
+                ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("single", i32)]
 
 
 class NtmPostDesc(C.Structure):
     _fields_ = [("ntm", c_p * 2), ("w", c_p * 2), ("ntm_grad", c_p * 2), ("class_dist", c_p), ("hout", c_p),
                 ("lout", c_p), ("Q", i32), ("C", i32),
                 ("lambda_seg", f32), ("lambda_convex", f32), ("lambda_volume", f32), ("lambda_anchor", f32),
-                ("gscale", f32)]
+                ("gscale", f32), ("single", i32)]
 
 
 class TapDesc(C.Structure):
@@ -123,7 +124,7 @@ SIGNATURES = {
     "simt_upsample_sum_argmax": (_I, [c_p, _I, _I, _I, c_p, _I, _I, _I, _I, _I, _I, _I, c_p, c_p]),
     "simt_confusion_hist": (_I, [c_p, c_p, _L, _I, c_p, c_p]),
     "simt_upsample_nchw": (_I, [c_p, _I, _I, _I, _I, _I, _I, _I, _I, c_p, c_p]),
-    "simt_upsample_nchw_bwd": (_I, [c_p, _I, _I, _I, _I, _I, _I, _I, _I, c_p, _I, c_p]),
+    "simt_upsample_nchw_bwd": (_I, [c_p, _I, _I, _I, _I, _I, _I, _I, _I, c_p, _I, c_p, c_p]),
     "simt_loss_ws_bytes": (_I, []),
     "simt_ce2d_fwd": (_I, [c_p, c_p, c_p, _I, _I, _I, _I, _I, _I, c_p, c_p, c_p]),
     "simt_ce2d_bwd": (_I, [c_p, c_p, c_p, _I, _I, _I, _I, _I, _I, c_p, c_p, c_p, c_p]),

@@ -210,20 +210,14 @@ extern "C" int simt_upsample_nchw(const float* src, int B, int h, int w, int lds
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
-// scratch for the separable adjoint: [B][C][H][w] fp32, grown on demand (hipMalloc outside any capture: first call)
-static float* g_upbwd_tmp = nullptr;
-static size_t g_upbwd_cap = 0;
+// tmp: caller-owned scratch of B*C*H*w floats for the separable adjoint (allocated with the plan's other buffers: no allocation on
+// the launch path, nothing shared between plans / streams / devices)
 extern "C" int simt_upsample_nchw_bwd(const float* ddst, int B, int h, int w, int lds, int C, int H, int W, int align_corners,
-                                      void* dsrc, int dtype, simt_stream_t stream) {
-  SIMT_CHECK(ddst && dsrc && C <= lds);
+                                      void* dsrc, int dtype, float* tmp, simt_stream_t stream) {
+  SIMT_CHECK(ddst && dsrc && tmp && C <= lds);
   UpArgs a; a.src = nullptr; a.dst = nullptr;
   fill_up(a, B, h, w, lds, C, H, W, align_corners);
-  const size_t need = (size_t)B * C * H * w * sizeof(float);
-  if (need > g_upbwd_cap) {
-    if (g_upbwd_tmp) (void)hipFree(g_upbwd_tmp);
-    if (hipMalloc((void**)&g_upbwd_tmp, need) != hipSuccess) { g_upbwd_tmp = nullptr; g_upbwd_cap = 0; SIMT_CHECK(!"hipMalloc of the upsample scratch failed"); }
-    g_upbwd_cap = need;
-  }
+  float* g_upbwd_tmp = tmp;
   long t1 = (long)B * C * H * w, g1 = (t1 + 255) / 256;
   if (g1 > 256 * 32) g1 = 256 * 32;
   hipLaunchKernelGGL(upsample_bwd_x_kernel, dim3((unsigned)g1), dim3(256), 0, (hipStream_t)stream, ddst, g_upbwd_tmp, a);

@@ -24,8 +24,27 @@
 
 struct HeadGeom {
   int B, h, w, H, W, C, Q, ldp, ldf;
-  float sy, sx;  // (h-1)/(H-1), (w-1)/(W-1) computed in float like ATen area_pixel_compute_scale
+  float sy, sx;  // align_corners=True: (h-1)/(H-1), (w-1)/(W-1); half-pixel: h/H, w/W -- in float like ATen area_pixel_compute_scale
+  int half;      // 0: interp_target of trainV2_simt.py:301 (align_corners=True);  1: F.interpolate(bilinear) default of
+                 // model/deeplabv3.py:137 (align_corners=False: src = (dst + 0.5) * scale - 0.5, clamped at 0)
+  int fix_logits;  // 1: fixp holds the frozen model's LOGITS and the posterior is softmax(upsample(logits)) (a model that upsamples
+                   // inside, deeplabv3.py:137 + trainV2_simt.py:354);  0: fixp holds low-res probabilities, upsampled (:354)
+  int single;      // 1: one-output model (DeepLabv3 / DeepLab-VGG): there is no auxiliary head, every head-1 term is dropped
 };
+
+// source coordinate of destination index d (ATen area_pixel_compute_source_index)
+__device__ __forceinline__ float src_coord(int half, float scale, int d) {
+  return half ? fmaxf(((float)d + 0.5f) * scale - 0.5f, 0.f) : scale * (float)d;
+}
+// destination indices [lo, hi] that can touch source index l (superset; weights are re-derived per element)
+__device__ __forceinline__ void dst_range(int l, int out, float scale, int& lo, int& hi) {
+  if (scale > 0.f) {
+    const float r = 1.f / scale;
+    lo = (int)floorf(((float)l - 1.f) * r) - 2;
+    hi = (int)ceilf(((float)l + 2.f) * r) + 2;
+  } else { lo = 0; hi = out - 1; }
+  lo = max(lo, 0); hi = min(hi, out - 1);
+}
 
 struct Taps {
   int o00, o01, o10, o11;  // pixel indices (b*h + iy)*w + ix
@@ -34,7 +53,7 @@ struct Taps {
 
 __device__ __forceinline__ Taps make_taps(const HeadGeom& g, int b, int y, int x) {
   Taps t;
-  float fy = g.sy * (float)y, fx = g.sx * (float)x;
+  float fy = src_coord(g.half, g.sy, y), fx = src_coord(g.half, g.sx, x);
   int iy0 = (int)fy, ix0 = (int)fx;
   if (iy0 > g.h - 1) iy0 = g.h - 1;
   if (ix0 > g.w - 1) ix0 = g.w - 1;
@@ -93,6 +112,24 @@ __device__ __forceinline__ void interp_argmax(const float* src, int ld, int n, c
       if (j4 * 4 + 3 < n && v3 > fm) { fm = v3; fa = j4 * 4 + 3; }
     }
   }
+}
+
+// frozen model's posterior at one pixel -> (max probability, its first arg-max).  fix_logits: softmax AFTER the interpolation.
+template <int NMAX>
+__device__ __forceinline__ void fixed_posterior(const HeadGeom& g, const float* fixp, const Taps& t, float& fm, int& fa) {
+  if (!g.fix_logits) { interp_argmax<NMAX>(fixp, g.ldf, g.C, t, fm, fa); return; }
+  float v[NMAX];
+  interp_vec<NMAX>(fixp, g.ldf, g.C, t, v);
+  float mx = v[0];
+  fa = 0;
+#pragma unroll
+  for (int j = 1; j < NMAX; ++j)
+    if (j < g.C && v[j] > mx) { mx = v[j]; fa = j; }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NMAX; ++j)
+    if (j < g.C) sum += expf(v[j] - mx);
+  fm = 1.0f / sum;                      // = exp(mx - mx) / sum, the value torch.softmax(...).max() returns
 }
 
 struct HeadEval {
@@ -254,14 +291,19 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
     // ---- fixed-model posterior -> confidence label (reference :354-361)
     float fm = 0.f;
     int fa = 0;
-    if (a.mode == 0) interp_argmax<QM>(a.fixp, g.ldf, C, tp, fm, fa);
+    if (a.mode == 0) fixed_posterior<QM>(g, a.fixp, tp, fm, fa);
     asm volatile("" ::: "memory");   // keep the next gathers from being hoisted above (register pressure)
     int conf = (fm > a.th_high) ? fa : 255;
     if (fm < a.th_low) conf = C;
 
     float v2[QM], v1[QM];
     interp_vec<QM>(a.pred2, g.ldp, Q, tp, v2);
-    interp_vec<QM>(a.pred1, g.ldp, Q, tp, v1);
+    if (g.single) {
+#pragma unroll
+      for (int j = 0; j < QM; ++j) v1[j] = v2[j];      // no auxiliary head: its slots mirror the main head and are ignored downstream
+    } else {
+      interp_vec<QM>(a.pred1, g.ldp, Q, tp, v1);
+    }
     HeadEval e2, e1;
     eval_head<QM>(v2, Q, C, a.th_high, e2);
     eval_head<QM>(v1, Q, C, a.th_high, e1);
@@ -480,8 +522,18 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(HeadArgs a, int nblk
     if (b >= g.B) { b = 0; y = 0; x = 0; }
     Taps tp = make_taps(g, b, y, x);
     const float* f = a.fixp;
-    o[16 + i] = lerp4(tp, f[(long)tp.o00 * g.ldf + c], f[(long)tp.o01 * g.ldf + c], f[(long)tp.o10 * g.ldf + c],
-                      f[(long)tp.o11 * g.ldf + c]);
+    const float vc = lerp4(tp, f[(long)tp.o00 * g.ldf + c], f[(long)tp.o01 * g.ldf + c], f[(long)tp.o10 * g.ldf + c],
+                           f[(long)tp.o11 * g.ldf + c]);
+    if (!g.fix_logits) { o[16 + i] = vc; continue; }
+    float mx = -INFINITY;                 // softmax of the interpolated logits at the anchor pixel (same order as fixed_posterior)
+    for (int cc = 0; cc < C; ++cc)
+      mx = fmaxf(mx, lerp4(tp, f[(long)tp.o00 * g.ldf + cc], f[(long)tp.o01 * g.ldf + cc], f[(long)tp.o10 * g.ldf + cc],
+                           f[(long)tp.o11 * g.ldf + cc]));
+    float sum = 0.f;
+    for (int cc = 0; cc < C; ++cc)
+      sum += expf(lerp4(tp, f[(long)tp.o00 * g.ldf + cc], f[(long)tp.o01 * g.ldf + cc], f[(long)tp.o10 * g.ldf + cc],
+                        f[(long)tp.o11 * g.ldf + cc]) - mx);
+    o[16 + i] = expf(vc - mx) / sum;
   }
 }
 
@@ -518,7 +570,7 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass2_kernel(Hea
     {
       Taps tp = make_taps(g, b, y, live ? x : 0);
       {
-        const float fx = g.sx * (float)x;
+        const float fx = src_coord(g.half, g.sx, x);
         int i0 = (int)fx;
         if (i0 > g.w - 1) i0 = g.w - 1;
         sI0[tid] = live ? i0 : -100;
@@ -526,13 +578,18 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass2_kernel(Hea
       }
       float fm = 0.f;
       int fa = 0;
-      if (a.mode == 0) interp_argmax<QM>(a.fixp, g.ldf, C, tp, fm, fa);
+      if (a.mode == 0) fixed_posterior<QM>(g, a.fixp, tp, fm, fa);
       asm volatile("" ::: "memory");
       int conf = (fm > a.th_high) ? fa : 255;
       if (fm < a.th_low) conf = C;
       float v2[QM], v1[QM];
       interp_vec<QM>(a.pred2, g.ldp, Q, tp, v2);
-      interp_vec<QM>(a.pred1, g.ldp, Q, tp, v1);
+      if (g.single) {
+#pragma unroll
+        for (int j = 0; j < QM; ++j) v1[j] = v2[j];
+      } else {
+        interp_vec<QM>(a.pred1, g.ldp, Q, tp, v1);
+      }
       HeadEval e2, e1;
       eval_head<QM>(v2, Q, C, a.th_high, e2);
       eval_head<QM>(v1, Q, C, a.th_high, e1);
@@ -589,8 +646,8 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass2_kernel(Hea
     // x-reduction: out[hd][xl][j] += sum_x wgt(x, xl) * G[hd][x][j]  -- only the low-res columns this 256-pixel chunk
     // can touch; the tap (i0, l1) of every pixel was computed once by its thread above
     const int xend = min(x0 + 256, g.W);
-    const int xl_lo = max(0, (int)(g.sx * (float)x0) - 1);
-    const int xl_hi = min(g.w - 1, (int)(g.sx * (float)(xend - 1)) + 2);
+    const int xl_lo = max(0, (int)src_coord(g.half, g.sx, x0) - 1);
+    const int xl_hi = min(g.w - 1, (int)src_coord(g.half, g.sx, xend - 1) + 2);
     const int nxl = xl_hi - xl_lo + 1;
     for (int idx = tid; idx < 2 * nxl * Q; idx += 256) {
       int hd = idx / (nxl * Q);
@@ -598,12 +655,7 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass2_kernel(Hea
       int xr = r / Q, j = r - xr * Q;
       int xl = xl_lo + xr;
       int lo, hi;
-      if (g.sx > 0.f) {
-        lo = (int)floorf((float)(xl - 1) / g.sx) - 1;
-        hi = (int)ceilf((float)(xl + 1) / g.sx) + 1;
-      } else {
-        lo = 0; hi = g.W - 1;
-      }
+      dst_range(xl, g.W, g.sx, lo, hi);
       lo = max(lo, x0);
       hi = min(hi, xend - 1);
       float s = 0.f;
@@ -640,18 +692,12 @@ __global__ void head_yreduce_kernel(const float* g1, float* d32_1, float* d32_2,
   int yl = (int)(t % g.h); t /= g.h;
   int b = (int)(t % g.B);
   int hd = (int)(t / g.B);
+  if (g.single && hd == 0) return;
   int lo, hi;
-  if (g.sy > 0.f) {
-    lo = (int)floorf((float)(yl - 1) / g.sy) - 1;
-    hi = (int)ceilf((float)(yl + 1) / g.sy) + 1;
-  } else {
-    lo = 0; hi = g.H - 1;
-  }
-  lo = max(lo, 0);
-  hi = min(hi, g.H - 1);
+  dst_range(yl, g.H, g.sy, lo, hi);
   float s = 0.f;
   for (int yy = lo; yy <= hi; ++yy) {
-    float fy = g.sy * (float)yy;
+    float fy = src_coord(g.half, g.sy, yy);
     int i0 = (int)fy;
     if (i0 > g.h - 1) i0 = g.h - 1;
     int i1 = i0 + (i0 < g.h - 1 ? 1 : 0);
@@ -676,17 +722,24 @@ static size_t pass2_lds(int Q, int C, int w) {
 }
 
 static int fill_args(const simt_head_desc* d, HeadArgs& a) {
-  SIMT_CHECK(d && d->pred1 && d->pred2 && d->label && d->part && d->keys && d->hout);
-  SIMT_CHECK(d->mode == 1 || (d->fixp && d->T1 && d->T2));
+  SIMT_CHECK(d && d->pred2 && d->label && d->part && d->keys && d->hout);
+  SIMT_CHECK(d->single ? (d->mode == 0) : (d->pred1 != nullptr));
+  SIMT_CHECK(d->mode == 1 || (d->fixp && d->T2 && (d->single || d->T1)));
   SIMT_CHECK(d->Q <= QMAX && d->C < d->Q + 1 && d->C >= 1 && d->Q <= 64);
   SIMT_CHECK(d->ldp % 4 == 0 && d->ldf % 4 == 0 && d->ldp >= ((d->Q + 3) / 4) * 4 && d->ldf >= ((d->C + 3) / 4) * 4);
   SIMT_CHECK((long)d->B * d->H * d->W < 0xFFFFFFFFl);
   a.g.B = d->B; a.g.h = d->h; a.g.w = d->w; a.g.H = d->H; a.g.W = d->W; a.g.C = d->C; a.g.Q = d->Q;
   a.g.ldp = d->ldp; a.g.ldf = d->ldf;
-  a.g.sy = d->H > 1 ? (float)(d->h - 1) / (float)(d->H - 1) : 0.f;
-  a.g.sx = d->W > 1 ? (float)(d->w - 1) / (float)(d->W - 1) : 0.f;
-  a.pred1 = d->pred1; a.pred2 = d->pred2; a.fixp = d->fixp; a.label = (const long long*)d->label;
-  a.T1 = d->T1; a.T2 = d->T2;
+  a.g.half = d->up_half_pixel ? 1 : 0; a.g.fix_logits = d->fix_logits ? 1 : 0; a.g.single = d->single ? 1 : 0;
+  if (a.g.half) {
+    a.g.sy = (float)d->h / (float)d->H;
+    a.g.sx = (float)d->w / (float)d->W;
+  } else {
+    a.g.sy = d->H > 1 ? (float)(d->h - 1) / (float)(d->H - 1) : 0.f;
+    a.g.sx = d->W > 1 ? (float)(d->w - 1) / (float)(d->W - 1) : 0.f;
+  }
+  a.pred1 = d->single ? d->pred2 : d->pred1; a.pred2 = d->pred2; a.fixp = d->fixp; a.label = (const long long*)d->label;
+  a.T1 = d->single ? d->T2 : d->T1; a.T2 = d->T2;
   a.th_high = d->th_high; a.th_low = d->th_low; a.lambda_seg = d->lambda_seg; a.lambda_place = d->lambda_place;
   a.part = d->part; a.keys = (unsigned long long*)d->keys; a.hout = d->hout; a.g1 = d->g1; a.QP = d->QP;
   a.gscale = d->gscale;

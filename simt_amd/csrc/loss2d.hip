@@ -21,13 +21,18 @@ struct Ce2dArgs {
   int C, ignore_label, is_softmax;
 };
 
-__device__ __forceinline__ bool ce_valid(long long t, int ignore, int C) { return t >= 0 && t != ignore; }
+// A target in [C, inf) that is not the ignore label is an ERROR in the reference (torch's nll_loss raises "Target t is out of
+// bounds").  It must never index pred / weight: the pixel is skipped by the gradient and POISONS the loss with NaN (ce_oob),
+// so the mistake is as loud as the reference's exception without a host sync in the hot path.
+__device__ __forceinline__ bool ce_valid(long long t, int ignore, int C) { return t >= 0 && t != ignore && t < C; }
+__device__ __forceinline__ bool ce_oob(long long t, int ignore, int C) { return t >= C && t != ignore; }
 
 __global__ __launch_bounds__(256) void ce2d_fwd_kernel(Ce2dArgs a) {
   __shared__ double red[2][256];
   double num = 0.0, den = 0.0;
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < a.P; p += (long)gridDim.x * 256) {
     long long t = a.target[p];
+    if (ce_oob(t, a.ignore_label, a.C)) num = NAN;
     if (!ce_valid(t, a.ignore_label, a.C)) continue;
     long b = p / a.HW, r = p - b * a.HW;
     const float* col = a.pred + b * a.C * a.HW + r;

@@ -22,6 +22,7 @@ struct NtmInnerArgs {
   const float* class_dist;
   int Q, C, steps, step0;
   float lr, beta1, beta2, eps;
+  int k0;      // first NTM index this launch handles (1 for one-output models)
 };
 
 // T = rowL1normalize( sigmoid(N) * cd + [I;0] ), also returns sigmoid and the row sums (for the backward)
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void ntm_inner_kernel(NtmInnerArgs a) {
   __shared__ float N[NQ * NC], T[NQ * NC], sig[NQ * NC], WT[NQ * NC], dT[NQ * NC], gN[NQ * NC];
   __shared__ float wraw[NQ * NQ], sm[NQ * NQ], Wm[NQ * NQ], dW[NQ * NQ], am[NQ * NQ], av[NQ * NQ];
   __shared__ float rs[NQ], dot[NQ], cd[NC];
-  const int k = blockIdx.x, tid = threadIdx.x, Q = a.Q, C = a.C;
+  const int k = blockIdx.x + a.k0, tid = threadIdx.x, Q = a.Q, C = a.C;
   for (int i = tid; i < Q * C; i += 256) { N[i] = a.ntm[k][i]; gN[i] = 0.f; }
   for (int i = tid; i < Q * Q; i += 256) { wraw[i] = a.w[k][i]; am[i] = a.w_m[k][i]; av[i] = a.w_v[k][i]; }
   if (tid < C) cd[tid] = a.class_dist[tid];
@@ -147,14 +148,17 @@ __global__ __launch_bounds__(256) void ntm_inner_kernel(NtmInnerArgs a) {
 extern "C" int simt_ntm_inner_loop(const simt_ntm_inner_desc* d, simt_stream_t stream) {
   SIMT_CHECK(d && d->Q <= NQ && d->C <= NC && d->C <= d->Q && d->class_dist);
   NtmInnerArgs a;
+  a.k0 = d->single ? 1 : 0;
   for (int k = 0; k < 2; ++k) {
+    a.ntm[k] = nullptr; a.w[k] = nullptr; a.ntm_grad[k] = nullptr; a.w_m[k] = nullptr; a.w_v[k] = nullptr; a.T_out[k] = nullptr;
+    if (k < a.k0) continue;
     SIMT_CHECK(d->ntm[k] && d->w[k] && d->ntm_grad[k] && d->w_m[k] && d->w_v[k] && d->T_out[k]);
     a.ntm[k] = d->ntm[k]; a.w[k] = d->w[k]; a.ntm_grad[k] = d->ntm_grad[k]; a.w_m[k] = d->w_m[k]; a.w_v[k] = d->w_v[k];
     a.T_out[k] = d->T_out[k];
   }
   a.class_dist = d->class_dist; a.Q = d->Q; a.C = d->C; a.steps = d->steps; a.step0 = d->step0;
   a.lr = d->lr; a.beta1 = d->beta1; a.beta2 = d->beta2; a.eps = d->eps;
-  hipLaunchKernelGGL(ntm_inner_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(ntm_inner_kernel, dim3(2 - a.k0), dim3(256), 0, (hipStream_t)stream, a);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
@@ -171,6 +175,7 @@ struct NtmPostArgs {
   float* lout;          // [16] scalars
   int Q, C, QMAXH;
   float lambda_seg, lambda_convex, lambda_volume, lambda_anchor, gscale;
+  int k0;      // 1: one-output model, only NTM [1]
 };
 
 __global__ __launch_bounds__(256) void ntm_post_kernel(NtmPostArgs a) {
@@ -187,8 +192,9 @@ __global__ __launch_bounds__(256) void ntm_post_kernel(NtmPostArgs a) {
   __shared__ int s_piv;
   const int tid = threadIdx.x, Q = a.Q, C = a.C, QC = Q * C;
   if (tid < C) cd[tid] = a.class_dist[tid];
+  if (tid == 0) { s_convex[0] = 0.f; s_vol[0] = 0.f; s_anchor[0] = 0.f; }
   __syncthreads();
-  for (int k = 0; k < 2; ++k) {
+  for (int k = a.k0; k < 2; ++k) {
     for (int i = tid; i < QC; i += 256) N[i] = a.ntm[k][i];
     for (int i = tid; i < Q * Q; i += 256) wraw[i] = a.w[k][i];
     __syncthreads();
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256) void ntm_post_kernel(NtmPostArgs a) {
   if (!vol_ok) vol = 0.f;
   const float convex = s_convex[0] + s_convex[1];
   const float anchor = s_anchor[0] + s_anchor[1];
-  for (int k = 0; k < 2; ++k) {
+  for (int k = a.k0; k < 2; ++k) {
     const float wy = (k == 0) ? a.lambda_seg : 1.f;
     const float* A = a.hout + 16 + k * QC;
     const float* ex = a.hout + 16 + 2 * QC + k * a.QMAXH;
@@ -325,11 +331,12 @@ __global__ __launch_bounds__(256) void ntm_post_kernel(NtmPostArgs a) {
   }
   if (tid == 0) {
     const float* o = a.hout;
-    float place = a.lambda_seg * o[2] + o[3];
-    float target = o[1] + o[5] + a.lambda_seg * o[0] + a.lambda_seg * o[4];
+    const float lseg = a.k0 ? 0.f : a.lambda_seg;          // one-output model: no auxiliary-head terms
+    float place = lseg * o[2] + o[3];
+    float target = o[1] + o[5] + lseg * o[0] + lseg * o[4];
     float total = place + target + a.lambda_convex * convex + a.lambda_volume * vol + a.lambda_anchor * anchor;
     float* l = a.lout;
-    l[0] = total * a.gscale; l[1] = o[0]; l[2] = o[1]; l[3] = o[4]; l[4] = o[5]; l[5] = place; l[6] = convex; l[7] = vol;
+    l[0] = total * a.gscale; l[1] = a.k0 ? 0.f : o[0]; l[2] = o[1]; l[3] = a.k0 ? 0.f : o[4]; l[4] = o[5]; l[5] = place; l[6] = convex; l[7] = vol;
     l[8] = anchor; l[9] = vol_ok ? 1.f : 0.f; l[10] = s_vol[0]; l[11] = s_vol[1];
   }
 }
@@ -337,7 +344,10 @@ __global__ __launch_bounds__(256) void ntm_post_kernel(NtmPostArgs a) {
 extern "C" int simt_ntm_post(const simt_ntm_post_desc* d, simt_stream_t stream) {
   SIMT_CHECK(d && d->Q <= NQ && d->C <= NC && d->hout && d->lout && d->class_dist);
   NtmPostArgs a;
+  a.k0 = d->single ? 1 : 0;
   for (int k = 0; k < 2; ++k) {
+    a.ntm[k] = nullptr; a.w[k] = nullptr; a.ntm_grad[k] = nullptr;
+    if (k < a.k0) continue;
     SIMT_CHECK(d->ntm[k] && d->w[k] && d->ntm_grad[k]);
     a.ntm[k] = d->ntm[k]; a.w[k] = d->w[k]; a.ntm_grad[k] = d->ntm_grad[k];
   }

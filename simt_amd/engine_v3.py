@@ -295,7 +295,9 @@ class V3Plan(TrunkPlan):
         ck = ops.round_up(Q, self.kq)
         dl = self.new(M, ck, zero=True)
         self.dlogits = {"x": dl}
-        b.add("simt_upsample_nchw_bwd", self.dout_full.data_ptr(), B, h, w, ck, Q, self.H, self.W, 0, dl.data_ptr(), ops.dt_code(dt))
+        self.up_tmp = self.new(B, Q, self.H, w, dtype=torch.float32)        # x-folded intermediate of the separable adjoint
+        b.add("simt_upsample_nchw_bwd", self.dout_full.data_ptr(), B, h, w, ck, Q, self.H, self.W, 0, dl.data_ptr(), ops.dt_code(dt),
+              self.up_tmp.data_ptr())
         b.wait(b.record(0), 1)
         row, parts = 0, []
         for prefix, cout in self.groups:

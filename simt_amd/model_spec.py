@@ -154,3 +154,20 @@ def synthetic_batch_u8(B, H, W, class_dist, seed=1234, block=16):
     lab = lab.repeat_interleave(block, 1).repeat_interleave(block, 2)[:, :H, :W].contiguous()
     rgb = bgr.flip(1).permute(0, 2, 3, 1).contiguous().to(torch.uint8)
     return rgb, lab.to(torch.uint8)
+
+
+def kaiming_init(shapes, seed=1234, device="cpu"):
+    """torchvision-style constructor init for the one-output models (model/deeplabv3.py wraps torchvision's resnet50, model/deeplab_vgg.py
+    its vgg16): conv weights ~ N(0, sqrt(2 / fan_out)), conv biases 0, BatchNorm weight 1 / bias 0 / running stats 0 / 1."""
+    g = torch.Generator().manual_seed(seed)
+    st = {}
+    for k, shp in shapes.items():
+        if k.endswith("num_batches_tracked"):
+            st[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith("running_var") or (k.endswith(".weight") and len(shp) == 1):
+            st[k] = torch.ones(shp)
+        elif len(shp) == 1:
+            st[k] = torch.zeros(shp)
+        else:
+            st[k] = torch.randn(shp, generator=g) * math.sqrt(2.0 / (shp[0] * shp[2] * shp[3]))
+    return {k: v.to(device) for k, v in st.items()}

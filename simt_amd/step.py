@@ -273,6 +273,10 @@ class SimTTrainer:
         self.it_done += 1
         return self.lout
 
+    def timed_lists(self):
+        """The launch lists of one iteration (frozen forward, trainable forward, backward) for per-kernel timing (bench.py)."""
+        return [self.fixed.fwd_list, self.plan.fwd_list, self.plan.bwd_list]
+
     def losses(self):
         """Host copy of the scalars of the last step (synchronises)."""
         v = self.lout.cpu().tolist()

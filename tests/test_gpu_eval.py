@@ -109,8 +109,9 @@ def test_upsample_nchw_forward_and_adjoint(dev, align, shape):
     (ref * up).sum().backward()
     for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
         dsrc = torch.zeros(B, h, w, lds, device=dev, dtype=dt)
+        tmp = torch.empty(B, C, H, w, device=dev)                     # caller-owned scratch of the separable adjoint
         L.call("simt_upsample_nchw_bwd", up.to(dev).data_ptr(), B, h, w, lds, C, H, W, align, dsrc.data_ptr(), ops.dt_code(dt),
-               ops.stream_ptr())
+               tmp.data_ptr(), ops.stream_ptr())
         got = dsrc[..., :C].float().cpu().permute(0, 3, 1, 2)
         assert (got - x.grad).abs().max().item() < tol * x.grad.abs().max().item()
         assert (dsrc[..., C:] == 0).all()

@@ -1,0 +1,233 @@
+"""SimT iteration over the ONE-OUTPUT models (BASELINE configs[3] DeepLabv3 + SimT K=6, configs[4] DeepLab-VGG16 + SimT K=3):
+`simt_amd.step_single.SimTSingleTrainer` through the C ABI against `oracle.simt_oracle.OracleSingleTrainer`.
+
+What is pinned and what is not: the loss body is the reference's (tools/trainV2_simt.py:351-424) with the auxiliary head
+removed -- `simt_losses_single` is tied to the golden-pinned two-head restatement by the identity test in tests/test_oracle_golden.py;
+the two TRUNKS are restatements of files that cannot be imported here (torchvision absent / Python-2 source): parity unpinned.
+
+  * head kernel in single-head mode, both upsample flavours (half-pixel + softmax-after-upsample = DeepLabv3; align_corners=True +
+    softmax-before = VGG): losses 1e-4, d/dlogits 1e-5, dNTM 2e-5, confidence-label count exact.
+  * DeepLab-VGG16 + SimT, fp32, THREE consecutive iterations: no BatchNorm -> well conditioned -> every loss 2e-4 of the fp32 oracle
+    at every iteration, sampled parameters 1e-5 after every step (a tight multi-step trajectory).
+  * DeepLabv3 + SimT (K=6), fp32: iteration-0 losses against the float64 oracle within 5x the fp32-CPU oracle's own distance + 1e-4
+    (train-mode BN: the conditioning argument of tests/test_gpu_trunk.py), parameters after the step likewise; two iterations run.
+  * bf16 (throughput mode): finite, within 0.1 * (1 + |ref|).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import simt_oracle as so
+from simt_amd import _lib as L
+from simt_amd import ops
+from simt_amd.engine_v3 import v3_state_shapes
+from simt_amd.engine_vgg import vgg_state_shapes
+from simt_amd.step import Hyper
+from simt_amd.step_single import SimTSingleTrainer
+
+pytestmark = pytest.mark.gpu
+CD = so.load_class_dist()
+KEYS = ["total", "loss_p", "loss_y", "place", "convex", "volume", "anchor"]
+
+
+def close(a, b, tol, what=""):
+    a, b = torch.as_tensor(np.asarray(a)).double(), torch.as_tensor(np.asarray(b)).double()
+    err = (a - b).abs().max().item()
+    assert err <= tol * (1 + b.abs().max().item()), f"{what}: err {err} (ref max {b.abs().max().item()})"
+
+
+def nhwc_pad(x, ld):
+    B, Cn, h, w = x.shape
+    out = torch.zeros(B * h * w, ld)
+    out[:, :Cn] = x.permute(0, 2, 3, 1).reshape(-1, Cn)
+    return out
+
+
+@pytest.mark.parametrize("flavour,K", [("v3", 6), ("vgg", 3), ("v3", 15)])
+def test_single_head_kernel_vs_oracle(dev, flavour, K):
+    Cn = 19
+    Q = Cn + K
+    g = torch.Generator().manual_seed(17 + K)
+    B, h, w, H, W = 2, 11, 19, 88 if flavour == "v3" else 81, 152 if flavour == "v3" else 145
+    pred = torch.randn(B, Q, h, w, generator=g) * 3
+    fix = torch.randn(B, Cn, h, w, generator=g) * 4
+    _, lab = so.synthetic_batch(B, H, W, CD.numpy(), seed=11, block=8)
+    ntm = so.ntm_init(Cn, K, 3)
+    hp = so.Hyper(num_classes=Cn, open_classes=K, lambda_convex=0.5, lambda_volume=0.1, lambda_anchor=0.5)
+    half = flavour == "v3"
+    # ---- device
+    st = ops.stream_ptr()
+    ldp = max(32, ops.round_up(Q, 8))
+    p_d, f_d = nhwc_pad(pred, ldp).to(dev), nhwc_pad(fix, 32).to(dev)
+    fixp = f_d
+    if not half:
+        fixp = torch.zeros_like(f_d)
+        ops.softmax_rows(f_d, 32, fixp, 32, B * h * w, Cn)
+    cd = CD.float().to(dev)
+    ntm_d, ngrad = ntm.clone().to(dev), torch.zeros(Q, Cn, device=dev)
+    wraw, wm, wv, T = so.w_init(Cn, K).to(dev), torch.zeros(Q, Q, device=dev), torch.zeros(Q, Q, device=dev), torch.zeros(Q, Cn, device=dev)
+    ni = L.NtmInnerDesc()
+    ni.ntm[1], ni.w[1], ni.ntm_grad[1], ni.w_m[1], ni.w_v[1], ni.T_out[1] = (t.data_ptr() for t in (ntm_d, wraw, ngrad, wm, wv, T))
+    ni.class_dist, ni.Q, ni.C, ni.steps, ni.step0, ni.single = cd.data_ptr(), Q, Cn, 10, 0, 1
+    ni.lr, ni.beta1, ni.beta2, ni.eps = 6e-3, 0.9, 0.999, 1e-8
+    L.call("simt_ntm_inner_loop", C.byref(ni), st)
+    lib = L.load()
+    part = torch.zeros(lib.simt_head_nblk(B, H, W), lib.simt_head_part_floats(Q, Cn), device=dev)
+    keys = torch.zeros(lib.simt_head_keys_count(), device=dev, dtype=torch.int64)
+    hout, lout = torch.zeros(lib.simt_head_hout_floats(Q, Cn), device=dev), torch.zeros(16, device=dev)
+    QP = ops.round_up(Q, 8)
+    g1 = torch.zeros(2, B, H, w, QP, device=dev)
+    dp = torch.zeros(B * h * w, ldp, device=dev)
+    lab_d = lab.to(dev)
+    hd = L.HeadDesc()
+    hd.pred1, hd.pred2, hd.fixp, hd.label, hd.T1, hd.T2 = None, p_d.data_ptr(), fixp.data_ptr(), lab_d.data_ptr(), None, T.data_ptr()
+    hd.part, hd.keys, hd.hout, hd.g1 = part.data_ptr(), keys.data_ptr(), hout.data_ptr(), g1.data_ptr()
+    hd.dpred1_f32, hd.dpred2_f32, hd.dpred1_t, hd.dpred2_t = None, dp.data_ptr(), None, None
+    hd.B, hd.h, hd.w, hd.H, hd.W, hd.C, hd.Q = B, h, w, H, W, Cn, Q
+    hd.ldp, hd.ldf, hd.QP, hd.ld_f32, hd.ld_t, hd.grad_dtype = ldp, 32, QP, ldp, 0, L.SIMT_F32
+    hd.th_high, hd.th_low, hd.lambda_seg, hd.lambda_place, hd.gscale = 0.8, 0.2, 0.0, 0.1, 1.0
+    hd.mode, hd.single, hd.up_half_pixel, hd.fix_logits = 0, 1, int(half), int(half)
+    L.call("simt_head_loss", C.byref(hd), st)
+    npd = L.NtmPostDesc()
+    npd.ntm[1], npd.w[1], npd.ntm_grad[1] = ntm_d.data_ptr(), wraw.data_ptr(), ngrad.data_ptr()
+    npd.class_dist, npd.hout, npd.lout, npd.Q, npd.C = cd.data_ptr(), hout.data_ptr(), lout.data_ptr(), Q, Cn
+    npd.lambda_seg, npd.lambda_convex, npd.lambda_volume, npd.lambda_anchor, npd.gscale, npd.single = 0.0, 0.5, 0.1, 0.5, 1.0, 1
+    L.call("simt_ntm_post", C.byref(npd), st)
+    L.call("simt_head_grad", C.byref(hd), st)
+    torch.cuda.synchronize()
+    # ---- oracle
+    n = ntm.clone().requires_grad_(True)
+    wr = so.w_init(Cn, K).requires_grad_(True)
+    so.inner_w_loop_single(n, wr, {"step": 0, "m": torch.zeros(Q, Q), "v": torch.zeros(Q, Q)}, CD, hp, 6e-3)
+    q = pred.clone().requires_grad_(True)
+    Tm = so.sig_ntm_forward(n, CD, Cn)
+    if half:
+        up = torch.nn.functional.interpolate(q, size=(H, W), mode="bilinear")
+        prob = torch.softmax(torch.nn.functional.interpolate(fix, size=(H, W), mode="bilinear"), 1)
+    else:
+        up, prob = so.upsample(q, (H, W)), so.upsample(torch.softmax(fix, 1), (H, W))
+    out = so.simt_losses_single(up, prob, lab, Tm, so.sig_w_forward(wr), hp)
+    out["total"].backward()
+    lo = lout.cpu()
+    for idx, key in [(0, "total"), (2, "loss_p"), (4, "loss_y"), (5, "place"), (6, "convex"), (7, "volume"), (8, "anchor")]:
+        close(lo[idx], out[key].detach(), 1e-4, key)
+    assert float(lo[1]) == 0.0 and float(lo[3]) == 0.0                       # no auxiliary head
+    assert int(hout[6].item()) == int((out["conf"] != 255).sum())
+    got = dp.cpu()[:, :Q].reshape(B, h, w, Q).permute(0, 3, 1, 2)
+    close(got, q.grad, 1e-5, "d/dlogits")
+    assert torch.all(dp.cpu()[:, Q:] == 0)
+    close(ngrad.cpu(), n.grad, 2e-5, "dNTM (leak + main)")
+    close(wraw.cpu(), wr.detach(), 1e-5, "W after 10 Adam steps")
+
+
+VGG_SMALL = [(0, 3, 32, 1, False), (2, 32, 32, 1, True), (5, 32, 64, 1, False), (7, 64, 64, 1, True), (10, 64, 64, 1, False),
+             (12, 64, 64, 1, False), (14, 64, 64, 1, True), (17, 64, 128, 1, False), (19, 128, 128, 1, False), (21, 128, 128, 1, False),
+             (23, 128, 128, 2, False), (25, 128, 128, 2, False), (27, 128, 128, 2, False), (29, 128, 256, 4, False),
+             (31, 256, 256, 4, False)]
+
+
+def _vgg_state(nc, layers, seed):
+    g = torch.Generator().manual_seed(seed)
+    st = {}
+    for k, shp in vgg_state_shapes(nc, layers).items():
+        if k.endswith("bias"):
+            st[k] = torch.randn(shp, generator=g) * 0.05
+        else:
+            st[k] = torch.randn(shp, generator=g) * (2.0 / (shp[1] * 9)) ** 0.5 * (3.0 if k.startswith("classifier") else 1.0)
+    return st
+
+
+def test_vgg_simt_three_iterations_fp32(dev):
+    K, Cn, B, H, W = 3, 19, 2, 96, 128
+    st, fst = _vgg_state(Cn + K, VGG_SMALL, 5), _vgg_state(Cn, VGG_SMALL, 6)
+    kw = dict(open_classes=K, lr=2.5e-4, lr_T=6e-3, lambda_convex=0.1, lambda_volume=1.0, lambda_anchor=1.0)
+    tr = SimTSingleTrainer("vgg", st, fst, so.ntm_init(Cn, K, 7), Hyper(**kw), CD.numpy(), B, H, W, dtype=torch.float32, device=dev,
+                           arch={"vgg_layers": VGG_SMALL})
+    assert len(tr.sgd_names) == 2 * 15 + 4                                     # every conv weight + bias, two live classifier branches
+    orc = so.OracleSingleTrainer("vgg", st, fst, so.ntm_init(Cn, K, 7), so.Hyper(**kw), CD, {"layers": VGG_SMALL})
+    names = ["features.0.weight", "features.14.bias", "features.29.weight", "classifier.conv2d_list.0.weight", "classifier.conv2d_list.1.bias"]
+    for it in range(3):
+        img, lab = so.synthetic_batch(B, H, W, CD.numpy(), seed=40 + it, block=8)
+        tr.step(img.to(dev), lab.to(dev), it)
+        out = orc.step(img, lab, it)
+        l = tr.losses()
+        for k in KEYS:
+            close(l[k], out[k].detach(), 2e-4, f"it {it} {k}")
+        assert int(tr.hout[6].item()) == int((out["conf"] != 255).sum())
+        for n in names:
+            close(tr.params[n].cpu(), orc.st[n].detach(), 1e-5, f"it {it} {n}")
+        close(tr.ntm.cpu(), orc.ntm.detach(), 2e-5, f"it {it} NTM")
+
+
+def _v3_state(shapes, seed):
+    from test_gpu_v3 import make_state
+    st = make_state(shapes, seed)
+    for k in ("conv.weight", "conv_1.weight"):
+        if k in st:
+            st[k] = st[k] * 4.0                  # confident classifiers: both thresholds of the frozen model are live
+    return st
+
+
+def test_v3_simt_iterations_fp32(dev):
+    K, Cn, B, H, W = 6, 19, 2, 96, 128
+    layers, width, ac = (1, 2, 2), 32, 32
+    st = _v3_state(v3_state_shapes(Cn, K, True, layers, width, ac), 3)
+    fst = _v3_state(v3_state_shapes(Cn, 0, False, layers, width, ac), 4)
+    kw = dict(open_classes=K, lr=2.5e-4, lr_T=6e-3, lambda_convex=0.1, lambda_volume=1.0, lambda_anchor=1.0)
+    arch = {"layers": layers, "width": width, "assp_ch": ac}
+    tr = SimTSingleTrainer("v3", st, fst, so.ntm_init(Cn, K, 9), Hyper(**kw), CD.numpy(), B, H, W, dtype=torch.float32, device=dev, arch=arch)
+    g0, g1 = tr.optim_groups()
+    assert g0 and all(n.startswith("resnet.resnet_50.layer3.") for n in g0) and any(n.endswith("bn1.weight") for n in g0)
+    assert "conv.weight" in g1 and "conv_1.bias" in g1 and "assp.bnf.bias" in g1
+    o32 = so.OracleSingleTrainer("v3", st, fst, so.ntm_init(Cn, K, 9), so.Hyper(**kw), CD, {"layers": layers})
+    o64 = so.OracleSingleTrainer("v3", st, fst, so.ntm_init(Cn, K, 9), so.Hyper(**kw), CD, {"layers": layers}, dtype=torch.float64)
+    names = ["resnet.resnet_50.layer3.0.conv1.weight", "resnet.resnet_50.layer3.1.bn2.weight", "assp.conv3.weight", "assp.bnf.bias", "conv.weight",
+             "conv_1.bias"]
+    for it in range(2):
+        img, lab = so.synthetic_batch(B, H, W, CD.numpy(), seed=60 + it, block=8)
+        tr.step(img.to(dev), lab.to(dev), it)
+        a, b = o32.step(img, lab, it), o64.step(img, lab, it)
+        l = tr.losses()
+        got = np.array([l[k] for k in KEYS])
+        r32 = np.array([float(a[k].detach()) for k in KEYS])
+        r64 = np.array([float(b[k].detach()) for k in KEYS])
+        print(f"it {it}: gpu {got}\n      f32 {r32}\n      f64 {r64}")
+        bound = 5 * np.abs(r32 - r64) + 1e-4 * (1 + np.abs(r64)) if it == 0 else 5 * np.abs(r32 - r64) + 2e-2 * (1 + np.abs(r64))
+        assert np.all(np.abs(got - r64) <= bound), f"it {it}"
+        np.testing.assert_allclose(got[4:6], r32[4:6], rtol=2e-5)                  # Convex, Volume: NTM algebra only
+        if it == 0:
+            assert int(tr.hout[6].item()) == int((b["conf"] != 255).sum())
+            for n in names:
+                p64 = o64.st[n].detach()
+                e_ref = (o32.st[n].detach().double() - p64).abs().max().item()
+                e_gpu = (tr.params[n].cpu().double() - p64).abs().max().item()
+                assert e_gpu <= 5 * e_ref + 1e-6, f"{n}: gpu-vs-f64 {e_gpu:.2e}, fp32-oracle-vs-f64 {e_ref:.2e}"
+
+
+@pytest.mark.parametrize("model", ["v3", "vgg"])
+def test_single_trainers_bf16_sanity(dev, model):
+    Cn, B, H, W = 19, 2, 96, 128
+    if model == "v3":
+        K, layers, width, ac = 6, (1, 2, 2), 64, 64
+        st = _v3_state(v3_state_shapes(Cn, K, True, layers, width, ac), 3)
+        fst = _v3_state(v3_state_shapes(Cn, 0, False, layers, width, ac), 4)
+        arch, oarch = {"layers": layers, "width": width, "assp_ch": ac}, {"layers": layers}
+    else:
+        K = 3
+        lay = [(i, ci if ci == 3 else max(ci, 64), max(co, 64), d, p) for (i, ci, co, d, p) in VGG_SMALL]
+        st, fst = _vgg_state(Cn + K, lay, 5), _vgg_state(Cn, lay, 6)
+        arch, oarch = {"vgg_layers": lay}, {"layers": lay}
+    kw = dict(open_classes=K, lr=2.5e-4, lr_T=6e-3)
+    tr = SimTSingleTrainer(model, st, fst, so.ntm_init(Cn, K, 9), Hyper(**kw), CD.numpy(), B, H, W, dtype=torch.bfloat16, device=dev, arch=arch)
+    orc = so.OracleSingleTrainer(model, st, fst, so.ntm_init(Cn, K, 9), so.Hyper(**kw), CD, oarch, dtype=torch.float64)
+    img, lab = so.synthetic_batch(B, H, W, CD.numpy(), seed=77, block=8)
+    tr.step(img.to(dev), lab.to(dev), 0)
+    out = orc.step(img, lab, 0)
+    l = tr.losses()
+    got, ref = np.array([l[k] for k in KEYS]), np.array([float(out[k].detach()) for k in KEYS])
+    print(model, "bf16", got, "f64", ref)
+    assert np.all(np.isfinite(got)) and np.all(np.abs(got - ref) <= 0.1 * (1 + np.abs(ref)))
+    for n in tr.sgd_names[:4]:
+        assert torch.isfinite(tr.params[n]).all()

@@ -290,3 +290,29 @@ def test_g12_gradient_accumulation_iter_size2():
         np.testing.assert_allclose(tr.ntm[0].detach().numpy(), d["ntm_after"][it][0], rtol=0, atol=1e-5 if it == 0 else 1e-4)
         np.testing.assert_allclose(tr.ntm[1].detach().numpy(), d["ntm_after"][it][1], rtol=0, atol=1e-5 if it == 0 else 1e-4)
     close(tr.w[0].detach(), d["w1"], 1e-4)
+
+
+@pytest.mark.parametrize("K", [3, 6, 15])
+def test_single_head_losses_tied_to_pinned_two_head_losses(K):
+    """The one-output SimT loss body (oracle.simt_losses_single: configs[3] / [4]) against the golden-pinned two-head restatement:
+    with pred1 = pred2, T1 = T2, W1 = W2 and lambda_seg = 0 the two-head total counts Convex / Volume / Anchor twice, so
+    total_two = total_single + lambda_convex * convex + lambda_volume * volume + lambda_anchor * anchor, and every shared term is equal."""
+    C = 19
+    Q = C + K
+    g = torch.Generator().manual_seed(K)
+    B, h, w, H, W = 2, 9, 9, 33, 33
+    cd = so.load_class_dist()
+    p = torch.randn(B, Q, h, w, generator=g) * 3
+    f = torch.randn(B, C, h, w, generator=g) * 4
+    _, lab = so.synthetic_batch(B, H, W, cd.numpy(), seed=3, block=8)
+    T = so.sig_ntm_forward(so.ntm_init(C, K, 5), cd, C).float()
+    Wm = so.sig_w_forward(so.w_init(C, K) + torch.randn(Q, Q, generator=g) * 0.1)
+    two = so.simt_losses(p, p, f, lab, T, T, Wm, Wm, so.Hyper(open_classes=K, lambda_seg=0.0), (H, W))
+    hp = so.Hyper(open_classes=K)
+    one = so.simt_losses_single(so.upsample(p, (H, W)), so.upsample(torch.softmax(f, 1), (H, W)), lab, T, Wm, hp)
+    rhs = one["total"] + hp.lambda_convex * one["convex"] + hp.lambda_volume * one["volume"] + hp.lambda_anchor * one["anchor"]
+    assert abs(float(two["total"]) - float(rhs)) < 1e-5 * (1 + abs(float(rhs)))
+    assert torch.equal(two["conf"], one["conf"]) and torch.equal(two["anchor_idx2"], one["anchor_idx"])
+    for a, b in (("loss_p2", "loss_p"), ("loss_y2", "loss_y")):
+        assert abs(float(two[a]) - float(one[b])) < 1e-6
+    assert abs(float(two["convex"]) - 2 * float(one["convex"])) < 1e-5 and abs(float(two["anchor"]) - 2 * float(one["anchor"])) < 1e-5
