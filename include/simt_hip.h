@@ -273,6 +273,13 @@ int simt_upsample_nchw_bwd(const float* ddst, int B, int h, int w, int lds, int 
                            void* dsrc, int dtype, float* tmp, simt_stream_t stream); /* dsrc [B][h][w][lds] in dtype, first C
                            * channels; tmp: caller-owned scratch of B*C*H*w floats (the x-folded intermediate of the separable adjoint) */
 
+/* ---- offline NTM utilities (tools/compute_ClassDistribution.py:49-51,66-86 `fast_hist(a, n)` = bincount of the pseudo labels;
+ * tools/compute_ConfusionMatrix.py:54-56,68-98 `fast_hist(a, b, n33, n19)` = bincount(n19 * a + b) after label_mapping) -------------
+ * hist[lut[a[p]] * nb + b[p]] += 1 over uint8 images (int64, accumulates across calls); a == NULL: one row (class distribution);
+ * lut: 256-entry label_mapping table or NULL (identity); entries with row >= na or b >= nb (255 = ignore) are skipped. */
+int simt_hist2d_u8(const unsigned char* a, const unsigned char* b, long P, int na, int nb, const unsigned char* lut, int64_t* hist,
+                   simt_stream_t stream);
+
 /* ---- input pipeline (dataset/cityscapes_dataset.py:101-120 after PNG decoding) -----------------------------------------
  * The reference resizes with Pillow on the CPU (Image.resize BICUBIC / NEAREST) and converts to float32 BGR - mean, CHW.
  * simt_resample_u8 applies ONE pass of Pillow's 8-bit separable resampler (Resample.c: 22-bit fixed-point coefficients,

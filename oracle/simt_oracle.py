@@ -636,56 +636,64 @@ def _bn_fold(st, prefix):
     return scale.double(), shift.double()
 
 
+def _q16_conv(st, xx, wname, fold=None, **kw):
+    d = torch.float64
+    w = st[wname].to(d)
+    if fold is not None:
+        sc, sh = _bn_fold(st, fold)
+        return F.conv2d(xx, q16(w * sc.view(-1, 1, 1, 1)), **kw) + sh.view(1, -1, 1, 1)      # caller applies residual / ReLU, then rounds
+    return q16(F.conv2d(xx, q16(w), **kw))
+
+
+def _q16_bn(st, prefix, y):
+    d = torch.float64
+    return F.batch_norm(y, None, None, st[prefix + ".weight"].to(d), st[prefix + ".bias"].to(d), training=True, eps=BN_EPS)
+
+
+def bf16_block_forward(st, name, a, stride, dil, down, train=True):
+    """One Bottleneck (model/deeplab_multi.py:81-101) as the bf16 plans store it -> (a1, a2, z); a: float64 tensor holding bf16 values."""
+    conv, bn = _q16_conv, _q16_bn
+    if train:
+        a1 = q16(F.relu(bn(st, f"{name}.bn1", conv(st, a, f"{name}.conv1.weight", stride=stride))))
+        a2 = q16(F.relu(bn(st, f"{name}.bn2", conv(st, a1, f"{name}.conv2.weight", padding=dil, dilation=dil))))
+        out = bn(st, f"{name}.bn3", conv(st, a2, f"{name}.conv3.weight"))
+        sc = bn(st, f"{name}.downsample.1", conv(st, a, f"{name}.downsample.0.weight", stride=stride)) if down else a
+        return a1, a2, q16(F.relu(out + sc))
+    a1 = q16(F.relu(conv(st, a, f"{name}.conv1.weight", fold=f"{name}.bn1", stride=stride)))
+    a2 = q16(F.relu(conv(st, a1, f"{name}.conv2.weight", fold=f"{name}.bn2", padding=dil, dilation=dil)))
+    sc = q16(conv(st, a, f"{name}.downsample.0.weight", fold=f"{name}.downsample.1", stride=stride)) if down else a
+    return a1, a2, q16(F.relu(conv(st, a2, f"{name}.conv3.weight", fold=f"{name}.bn3") + sc))
+
+
+def bf16_aspp(st, hname, f):
+    """Classifier_Module on a bf16 feature map: bf16 weights, fp32 logits (no rounding of the output)."""
+    d = torch.float64
+    out = None
+    for i, dl in ((0, 6), (1, 12)):
+        y = F.conv2d(f, q16(st[f"{hname}.conv2d_list.{i}.weight"].to(d)), st[f"{hname}.conv2d_list.{i}.bias"].to(d), padding=dl, dilation=dl)
+        out = y if out is None else out + y
+    return out
+
+
 def bf16_model_forward(st, x, train, openset, layers=LAYERS, heads=("layer5", "layer6")):
     """deeplab_multi_forward as the bf16 HIP plans store it (engine.py TrunkPlan: train = batch-statistics BN applied by
     simt_bn_apply to the stored bf16 conv output; eval = BN scale folded into the bf16 weights, shift in the epilogue)."""
     d = torch.float64
     x = q16(x.to(d))                                                    # stem im2col matrix is bf16
-
-    def conv(xx, wname, fold=None, **kw):
-        w = st[wname].to(d)
-        if fold is not None:
-            sc, sh = _bn_fold(st, fold)
-            y = F.conv2d(xx, q16(w * sc.view(-1, 1, 1, 1)), **kw) + sh.view(1, -1, 1, 1)
-            return y                                                    # caller applies residual / ReLU, then rounds
-        return q16(F.conv2d(xx, q16(w), **kw))
-
-    def bn(prefix, y):
-        return F.batch_norm(y, None, None, st[prefix + ".weight"].to(d), st[prefix + ".bias"].to(d), training=True, eps=BN_EPS)
-
     if train:
-        a = q16(F.relu(bn("bn1", conv(x, "conv1.weight", stride=2, padding=3))))
+        a = q16(F.relu(_q16_bn(st, "bn1", _q16_conv(st, x, "conv1.weight", stride=2, padding=3))))
     else:
-        a = q16(F.relu(conv(x, "conv1.weight", fold="bn1", stride=2, padding=3)))
+        a = q16(F.relu(_q16_conv(st, x, "conv1.weight", fold="bn1", stride=2, padding=3)))
     a = F.max_pool2d(a, 3, 2, 1, ceil_mode=True)
     feats = {}
     for name, inpl, planes, stride, dil, down in block_specs(layers):
-        if train:
-            a1 = q16(F.relu(bn(f"{name}.bn1", conv(a, f"{name}.conv1.weight", stride=stride))))
-            a2 = q16(F.relu(bn(f"{name}.bn2", conv(a1, f"{name}.conv2.weight", padding=dil, dilation=dil))))
-            out = bn(f"{name}.bn3", conv(a2, f"{name}.conv3.weight"))
-            sc = bn(f"{name}.downsample.1", conv(a, f"{name}.downsample.0.weight", stride=stride)) if down else a
-            a = q16(F.relu(out + sc))
-        else:
-            a1 = q16(F.relu(conv(a, f"{name}.conv1.weight", fold=f"{name}.bn1", stride=stride)))
-            a2 = q16(F.relu(conv(a1, f"{name}.conv2.weight", fold=f"{name}.bn2", padding=dil, dilation=dil)))
-            sc = q16(conv(a, f"{name}.downsample.0.weight", fold=f"{name}.downsample.1", stride=stride)) if down else a
-            a = q16(F.relu(conv(a2, f"{name}.conv3.weight", fold=f"{name}.bn3") + sc))
+        _, _, a = bf16_block_forward(st, name, a, stride, dil, down, train)
         feats[int(name[5])] = a
-
-    def aspp(hname, f):
-        out = None
-        for i, dl in ((0, 6), (1, 12)):
-            y = F.conv2d(f, q16(st[f"{hname}.conv2d_list.{i}.weight"].to(d)), st[f"{hname}.conv2d_list.{i}.bias"].to(d),
-                         padding=dl, dilation=dl)
-            out = y if out is None else out + y
-        return out                                                      # logits stay fp32 on the device: no rounding
-    x1, x2 = aspp(heads[0], feats[3]), aspp(heads[1], feats[4])
+    x1, x2 = bf16_aspp(st, heads[0], feats[3]), bf16_aspp(st, heads[1], feats[4])
     if openset:
-        x1 = torch.cat([x1, aspp(heads[0] + "_1", feats[3])], 1)
-        x2 = torch.cat([x2, aspp(heads[1] + "_1", feats[4])], 1)
+        x1 = torch.cat([x1, bf16_aspp(st, heads[0] + "_1", feats[3])], 1)
+        x2 = torch.cat([x2, bf16_aspp(st, heads[1] + "_1", feats[4])], 1)
     return x1, x2
-
 
 # ------------------------------------------------------------------------------------------------------------
 # SimT iteration over a ONE-OUTPUT model (BASELINE configs[3] DeepLabv3, configs[4] DeepLab-VGG16).
@@ -803,3 +811,34 @@ class OracleSingleTrainer:
             s["step"] += 1
             adam_step_(self.ntm, self.ntm.grad, s["m"], s["v"], s["step"], lr_T)
         return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# offline NTM utilities (tools/compute_ClassDistribution.py:49-63,66-94; tools/compute_ConfusionMatrix.py:54-66,68-98)
+# ------------------------------------------------------------------------------------------------------------
+def label_mapping(inp, mapping):
+    """output[input == src] = dst for every (src, dst) row, applied in order on a copy (evaluate_cityscapes.py:90-94 and both tools)."""
+    out = np.copy(inp)
+    for src, dst in mapping:
+        out[inp == src] = dst
+    return np.array(out, dtype=np.int64)
+
+
+def class_hist(pred, n):
+    """compute_ClassDistribution.py:49-51 `fast_hist(a, n)`: counts of the values in [0, n)."""
+    k = (pred >= 0) & (pred < n)
+    return np.bincount(pred[k], minlength=n)
+
+
+def class_distribution(preds, n=19):
+    """compute_CD + the normalisation of :88-92: sum of per-image histograms / (total + 10e-10) -> what ClassDist_*.npy hold."""
+    cm = np.zeros(n)
+    for p in preds:
+        cm += class_hist(np.asarray(p).flatten(), n)
+    return cm, cm / (np.sum(cm) + 10e-10)
+
+
+def rect_hist(gt, pred, n_rows, n_cols):
+    """compute_ConfusionMatrix.py:54-56 `fast_hist(a, b, n33, n19)`: rows = (mapped) ground-truth ids, columns = pseudo labels."""
+    k = (gt >= 0) & (gt < n_rows)
+    return np.bincount(n_cols * gt[k].astype(int) + pred[k], minlength=n_rows * n_cols).reshape(n_rows, n_cols)

@@ -129,6 +129,7 @@ SIGNATURES = {
     "simt_ce2d_fwd": (_I, [c_p, c_p, c_p, _I, _I, _I, _I, _I, _I, c_p, c_p, c_p]),
     "simt_ce2d_bwd": (_I, [c_p, c_p, c_p, _I, _I, _I, _I, _I, _I, c_p, c_p, c_p, c_p]),
     "simt_entropy2d": (_I, [c_p, _I, _I, _I, _I, c_p, c_p, c_p, c_p, c_p]),
+    "simt_hist2d_u8": (_I, [c_p, c_p, _L, _I, _I, c_p, c_p, c_p]),
     "simt_resample_u8": (_I, [c_p, c_p, _I, _I, _I, _I, _I, _I, c_p, c_p, _I, c_p]),
     "simt_image_to_input": (_I, [c_p, c_p, _I, _I, _I, f32, f32, f32, _I, c_p]),
     "simt_label_nearest": (_I, [c_p, c_p, _I, _I, _I, _I, _I, c_p, c_p, _I, c_p]),

@@ -231,3 +231,38 @@ extern "C" int simt_upsample_nchw_bwd(const float* ddst, int B, int h, int w, in
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
+
+// ---- offline NTM utilities (tools/compute_ClassDistribution.py:49-51,66-86; tools/compute_ConfusionMatrix.py:54-56,68-98) ----------
+// hist[na_idx * nb + b] += 1 over uint8 label images: a = row class (optional 256-entry LUT = label_mapping; NULL a -> row 0, i.e. the
+// 1-D class histogram of compute_CD), b = column class.  Entries with a (after the LUT) >= na or b >= nb are skipped: 255 = ignore.
+// Integer atomics -> exact and order independent; LDS histogram per block (na * nb <= 2048), one global atomic per non-zero bin.
+__global__ __launch_bounds__(256) void hist2d_u8_kernel(const unsigned char* __restrict__ a, const unsigned char* __restrict__ b, long P,
+                                                        int na, int nb, const unsigned char* __restrict__ lut,
+                                                        unsigned long long* __restrict__ hist) {
+  __shared__ unsigned int sh[2048];
+  __shared__ unsigned char sl[256];
+  const int nn = na * nb;
+  for (int i = threadIdx.x; i < nn; i += 256) sh[i] = 0u;
+  sl[threadIdx.x] = lut ? lut[threadIdx.x] : (unsigned char)threadIdx.x;
+  __syncthreads();
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+    const int r = a ? (int)sl[a[p]] : 0;
+    const int c = (int)b[p];
+    if (r < na && c < nb) atomicAdd(&sh[r * nb + c], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nn; i += 256)
+    if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
+}
+
+extern "C" int simt_hist2d_u8(const unsigned char* a, const unsigned char* b, long P, int na, int nb, const unsigned char* lut,
+                              int64_t* hist, simt_stream_t stream) {
+  SIMT_CHECK(b && hist && P >= 0 && na >= 1 && nb >= 1 && na * nb <= 2048 && (a || na == 1));
+  if (P == 0) return SIMT_OK;
+  long grid = (P + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(hist2d_u8_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, b, P, na, nb, lut,
+                     (unsigned long long*)hist);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}

@@ -273,6 +273,15 @@ class SimTTrainer:
         self.it_done += 1
         return self.lout
 
+    def state_dict(self):
+        """Host copy of the trainable model's state (the reference's `model.state_dict()` of :449,461): every key, NCHW fp32, with
+        `num_batches_tracked` = number of train-mode forwards so far (nn.BatchNorm2d bumps it once per forward)."""
+        sd = {}
+        for k, v in self.params.items():
+            sd[k] = (v.detach().cpu() if not k.endswith("num_batches_tracked") else
+                     torch.tensor(int(v.item()) + self.it_done * self.hp.iter_size, dtype=torch.long))
+        return sd
+
     def timed_lists(self):
         """The launch lists of one iteration (frozen forward, trainable forward, backward) for per-kernel timing (bench.py)."""
         return [self.fixed.fwd_list, self.plan.fwd_list, self.plan.bwd_list]
@@ -373,6 +382,13 @@ class WarmupTrainer:
         self.plan.repack()
         self.it_done += 1
         return self.hout
+
+    def state_dict(self):
+        sd = {}
+        for k, v in self.params.items():
+            sd[k] = (v.detach().cpu() if not k.endswith("num_batches_tracked") else
+                     torch.tensor(int(v.item()) + self.it_done * self.hp.iter_size, dtype=torch.long))
+        return sd
 
     def losses(self):
         v = self.hout[:16].cpu().tolist()

@@ -48,6 +48,21 @@ class Evaluator:
         self.pred = torch.zeros(batch, self.H, self.W, device=self.dev, dtype=torch.int32)
         self.hist = torch.zeros(num_classes * num_classes, device=self.dev, dtype=torch.int64)
 
+    def load(self, state):
+        """Refresh the weights from a (training) state dict and re-fold / re-pack both plans: the in-loop evaluation of
+        tools/trainV2_simt.py:452-456 reuses one Evaluator for the whole run."""
+        for plan in self.plans:
+            for k, v in plan.p.items():
+                if k in state and v.dtype != torch.long:
+                    v.copy_(state[k])
+        seen = set()
+        for plan in self.plans:
+            if id(plan.p) in seen:
+                pass
+            seen.add(id(plan.p))
+            plan.repack()
+        self.hist.zero_()
+
     def predict(self, *images):
         """images: one [B,3,h,w] fp32 tensor per scale.  Returns the arg-max label map [B,H,W] int32 (device)."""
         outs = []
@@ -70,3 +85,65 @@ class Evaluator:
         hist = self.hist.cpu().numpy().reshape(self.C, self.C).astype(np.float64)
         ius = per_class_iu(hist)
         return round(float(np.nanmean(ius)) * 100, 2), ius
+
+
+def evaluate_simt(state, data_dir, data_list, gt_dir, devkit_dir="../dataset/cityscapes_list", *, num_classes=19, open_classes=0, set_name="val",
+                  device="cuda:0", dtype=torch.bfloat16, evaluator=None, rank=0, world=1, process_group=None, verbose=True, workers=4):
+    """File-based evaluation loop of the reference (evaluate_cityscapes.py:96-162): every validation frame at crop sizes (1024, 512) and
+    (1280, 640) -> logits[:, :num_classes] of the main head, upsampled to 1024 x 2048, summed, arg-maxed -> fast_hist against the
+    ground-truth label ids mapped with info.json's label2train -> mIoU (round(nanmean * 100, 2)).
+    Host: file lists, PNG decoding (threads), the label LUT.  Device: both resizes (Pillow-exact), BGR - mean, both forwards, the fused
+    upsample + sum + arg-max, the histogram.  Data parallel: ranks take strided shards of the list and the histogram is all-reduced."""
+    import json
+    from concurrent.futures import ThreadPoolExecutor
+    from os.path import join
+
+    from simt_amd.data.pipeline import IMG_MEAN, InputPrep
+    from simt_amd.dataset.cityscapes_dataset import cityscapesDataSet
+    from simt_amd.tools.ntm_stats import mapping_lut
+    dev = torch.device(device)
+    with open(join(devkit_dir, "info.json"), "r") as fp:
+        info = json.load(fp)
+    name_classes = info.get("label", [str(i) for i in range(num_classes)])
+    lut = mapping_lut(np.array(info["label2train"]))
+    ds = cityscapesDataSet(data_dir, data_list, crop_size=(1024, 512), mean=IMG_MEAN, scale=False, mirror=False, set=set_name)
+    ev = evaluator or Evaluator(state, num_classes=num_classes, open_classes=open_classes, dtype=dtype, device=dev)
+    if evaluator is not None:
+        ev.load(state)
+    from PIL import Image
+
+    def fetch(i):
+        rgb, _, name = ds.decode(i)
+        gt_path = "%s/%s" % (gt_dir, name.split("leftImg8bit")[0] + "gtFine_labelIds.png")
+        return rgb, lut[np.array(Image.open(gt_path))], name
+    idx = list(range(rank, len(ds), world))
+    preps = {}
+    xa = xb = None
+    with ThreadPoolExecutor(max(1, workers)) as pool:
+        for rgb, label, name in pool.map(fetch, idx):
+            key = rgb.shape[:2]
+            if key not in preps:
+                preps[key] = (InputPrep(1, key, (1024, 512), dev, with_label=False), InputPrep(1, key, (1280, 640), dev, with_label=False))
+                xa, xb = torch.empty(1, 3, 512, 1024, device=dev), torch.empty(1, 3, 640, 1280, device=dev)
+            if label.size != ev.H * ev.W:
+                print("Skipping: len(gt) = {:d}, len(pred) = {:d}, {:s}".format(label.size, ev.H * ev.W, name))
+                continue
+            rgb_d = torch.from_numpy(rgb[None]).to(dev)
+            preps[key][0].run(rgb_d, xa)
+            preps[key][1].run(rgb_d, xb)
+            ev.add(xa, xb, torch.from_numpy(label[None].astype(np.int64)))
+    if process_group is not None and world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(ev.hist, group=process_group)
+    miou, ius = ev.result()
+    if verbose and rank == 0:
+        for ind_class in range(num_classes):
+            print("===>" + str(name_classes[ind_class]) + ":\t" + str(round(ius[ind_class] * 100, 2)))
+        print("===> mIoU: " + str(miou))
+    return miou
+
+
+def evaluate_warmup(state, *args, **kw):
+    """evaluate_cityscapes.py:165-225: the same loop for a warm-up (no open-set heads) checkpoint."""
+    kw["open_classes"] = 0
+    return evaluate_simt(state, *args, **kw)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Warm-up stage on MI355X: the reference's tools/trainV1_warmup.py (plain CE on both heads, SGD over the whole net)
 driven by `WarmupTrainer` (simt_amd/step.py).  Same flag names as the reference for everything that matters
-(trainV1_warmup.py:60-150); data: synthetic Cityscapes-shaped batches unless a loader is plugged into `batches()`.
+(trainV1_warmup.py:60-150); data: `cityscapesPseudo` through the device input pipeline (simt_amd/data/pipeline.py) or, with
+--synthetic, Cityscapes-shaped synthetic batches.  --restore-from must exist and match (the reference's `k[6:]` prefix strip of :177
+is honoured) unless --from-scratch is given.
 
     python -m simt_amd.tools.trainV1_warmup --learning-rate 2.5e-4 --input-size-target 1024,512 --num-steps-stop 40000
 """
@@ -14,7 +16,7 @@ import torch
 
 from simt_amd import model_spec as ms
 from simt_amd.step import Hyper, WarmupTrainer, lr_poly
-from simt_amd.tools.trainV2_simt import restore
+from simt_amd.tools.trainV2_simt import batches, restore
 
 
 def get_arguments(argv=None):
@@ -37,6 +39,12 @@ def get_arguments(argv=None):
     p.add_argument("--gpu", type=int, default=0)
     p.add_argument("--compute-dtype", choices=["bf16", "f32"], default="bf16")
     p.add_argument("--print-every", type=int, default=100)
+    p.add_argument("--data-dir-target", type=str, default="")
+    p.add_argument("--data-list-target", type=str, default="../dataset/cityscapes_list/pseudo_bapa.lst")
+    p.add_argument("--num-workers", type=int, default=4)
+    p.add_argument("--random-mirror", action="store_true")
+    p.add_argument("--synthetic", action="store_true", help="synthetic Cityscapes-shaped batches")
+    p.add_argument("--from-scratch", action="store_true", help="allow training from the constructor init (no --restore-from)")
     return p.parse_args(argv)
 
 
@@ -56,7 +64,8 @@ def main(argv=None):
         pg = dist.group.WORLD
     w, h = map(int, args.input_size_target.split(","))
     state = ms.reference_init(ms.state_shapes(args.num_classes, 0, False), seed=args.random_seed)
-    n = restore(state, args.restore_from)
+    # trainV1_warmup.py:177: keys of the pretrained checkpoint carry a 6-character prefix (`k[6:]`); shapes are filtered
+    n = restore(state, args.restore_from, strip_prefix=6, required=not getattr(args, "from_scratch", False))
     hp = Hyper(num_classes=args.num_classes, open_classes=0, lambda_seg=args.lambda_seg, lr=args.learning_rate, iter_size=args.iter_size,
                momentum=args.momentum, weight_decay=args.weight_decay, power=args.power, num_steps=args.num_steps)
     dtype = torch.bfloat16 if args.compute_dtype == "bf16" else torch.float32
@@ -65,10 +74,10 @@ def main(argv=None):
     if rank == 0:
         print(f"restored {n} tensors; {world} GPU(s), batch {args.batch_size}/GPU, {h}x{w}, {args.compute_dtype}")
         os.makedirs(args.snapshot_dir, exist_ok=True)
+    data = batches(args, args.batch_size, h, w, cd, rank, world, dev)
     t0 = time.time()
     for i_iter in range(args.num_steps):
-        mb = [ms.synthetic_batch(args.batch_size, h, w, cd, seed=args.random_seed + 1000 * rank + i_iter * args.iter_size + j, device=dev)
-              for j in range(args.iter_size)]                         # gradient accumulation: iter_size micro-batches per step
+        mb = [next(data) for _ in range(args.iter_size)]             # gradient accumulation: iter_size micro-batches per step
         img, lab = ([m[0] for m in mb], [m[1] for m in mb]) if args.iter_size > 1 else mb[0]
         tr.step(img, lab, i_iter)
         if i_iter % args.print_every == 0 and rank == 0:
@@ -78,8 +87,7 @@ def main(argv=None):
                 args.batch_size * world * (i_iter + 1) / max(time.time() - t0, 1e-9)))
         if i_iter >= args.num_steps_stop - 1:
             if rank == 0:
-                torch.save({k: v.detach().cpu() for k, v in tr.params.items()},
-                           osp.join(args.snapshot_dir, "GTA5_" + str(args.num_steps_stop) + ".pth"))
+                torch.save(tr.state_dict(), osp.join(args.snapshot_dir, "GTA5_" + str(args.num_steps_stop) + ".pth"))
             break
     if world > 1:
         import torch.distributed as dist

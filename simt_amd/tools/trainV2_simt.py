@@ -7,9 +7,13 @@ data, LR schedule, printing every 100 iterations (:438-441), snapshots (:447-450
     python -m simt_amd.tools.trainV2_simt --open-classes 15 --learning-rate 6e-4 --learning-rate-T 6e-3 ...
     torchrun --standalone --local-addr 127.0.0.1 --nproc-per-node 8 -m simt_amd.tools.trainV2_simt ...   (data parallel)
 
-Data: `--synthetic` (default when --data-dir-target does not exist) feeds Cityscapes-shaped synthetic batches
-(SURVEY 8d); a real `cityscapesPseudo`-style loader is the "next" row 3 of SURVEY 8f and plugs in at `batches()`.
-Additions over the reference (all optional): --synthetic, --compute-dtype, --print-every.
+Data: `cityscapesPseudo(--data-dir-target, --data-list-target)` through `GpuLoader` (decode on host threads, Pillow-exact resize +
+BGR-mean on the GPU, pinned double-buffered uploads; simt_amd/data/pipeline.py), shuffled, --random-mirror as the reference writes
+it; `--synthetic` feeds Cityscapes-shaped synthetic batches instead.  Pointing --data-dir-target at a missing directory
+without --synthetic is an error (a run that silently trains on noise would still write checkpoints that look like results).
+Every --save-pred-every iterations: evaluate_simt on the validation set (--data-dir-val ...) and the best-mIoU snapshot rotation of
+trainV2_simt.py:452-464.  Additions over the reference (all optional): --synthetic, --compute-dtype, --print-every, --data-dir-val,
+--data-list-val, --gt-dir-val, --devkit-dir.
 """
 import argparse
 import os
@@ -67,27 +71,52 @@ def get_arguments(argv=None):
     p.add_argument("--synthetic", action="store_true", help="synthetic Cityscapes-shaped batches")
     p.add_argument("--compute-dtype", choices=["bf16", "f32"], default="bf16")
     p.add_argument("--print-every", type=int, default=100)
+    p.add_argument("--data-dir-val", type=str, default="", help="Cityscapes root for the in-loop evaluation (evaluate_cityscapes.py:26)")
+    p.add_argument("--data-list-val", type=str, default="../dataset/cityscapes_list/val.txt")
+    p.add_argument("--gt-dir-val", type=str, default="", help="directory of *_gtFine_labelIds.png (evaluate_cityscapes.py:140)")
+    p.add_argument("--devkit-dir", type=str, default="../dataset/cityscapes_list")
+    p.add_argument("--from-scratch", action="store_true", help="allow training from the constructor init (no --restore-from)")
     return p.parse_args(argv)
 
 
-def restore(state, path, not_restore_last=False):
-    """Filter-by-key load of an AdaptSegNet-style checkpoint into a fresh state (trainV2_simt.py:248-255)."""
+def restore(state, path, not_restore_last=False, strip_prefix=0, required=False):
+    """Filter-by-key load of an AdaptSegNet-style checkpoint into a fresh state (trainV2_simt.py:248-255).  strip_prefix=6: the warm-up
+    stage's `k[6:]` (trainV1_warmup.py:177, checkpoints saved from a wrapped module) -- a key is accepted with or without the prefix.
+    required: a missing file or zero matching tensors is an error (the reference crashes in torch.load; silently training from the
+    constructor init would still produce checkpoints that look like results)."""
     if not path or not osp.exists(path):
+        if required:
+            raise FileNotFoundError(f"--restore-from {path!r} does not exist (pass --from-scratch to train from the constructor init)")
         return 0
     saved = torch.load(path, map_location="cpu")
     n = 0
     for k, v in saved.items():
-        if k in state and (not not_restore_last or not k.startswith(("layer5", "layer6"))) and state[k].shape == v.shape:
-            state[k] = v.clone()
-            n += 1
+        for cand in ((k, k[strip_prefix:]) if strip_prefix else (k,)):
+            if cand in state and (not not_restore_last or not cand.startswith(("layer5", "layer6"))) and state[cand].shape == v.shape:
+                state[cand] = v.clone()
+                n += 1
+                break
+    if required and n == 0:
+        raise RuntimeError(f"--restore-from {path!r}: no tensor matched the model's keys / shapes")
     return n
 
 
-def batches(args, B, H, W, cd, rank, dev):
-    it = 0
-    while True:
-        yield ms.synthetic_batch(B, H, W, cd, seed=args.random_seed + 1000 * rank + it, device=dev)
-        it += 1
+def batches(args, B, H, W, cd, rank, world, dev):
+    """-> iterator of (image f32 [B,3,H,W], label i64 [B,H,W]) resident on the device."""
+    if args.synthetic:
+        def synth():
+            it = 0
+            while True:                                     # one global sequence of seeds, dealt round-robin to the ranks
+                yield ms.synthetic_batch(B, H, W, cd, seed=args.random_seed + it * world + rank, device=dev)
+                it += 1
+        return synth()
+    if not args.data_dir_target or not osp.isdir(args.data_dir_target):
+        raise SystemExit(f"--data-dir-target {args.data_dir_target!r} is not a directory; pass --synthetic for synthetic batches")
+    from simt_amd.data.pipeline import IMG_MEAN, GpuLoader
+    from simt_amd.dataset.cityscapes_dataset import cityscapesPseudo
+    ds = cityscapesPseudo(args.data_dir_target, args.data_list_target, crop_size=(W, H), scale=False, mirror=args.random_mirror, mean=IMG_MEAN)
+    loader = GpuLoader(ds, B, shuffle=True, num_workers=args.num_workers, device=dev, seed=args.random_seed, rank=rank, world=world)
+    return ((img, lab) for (img, lab, _sizes, _names) in loader)
 
 
 def main(argv=None):
@@ -108,8 +137,8 @@ def main(argv=None):
     C, K = args.num_classes, args.open_classes
     state = ms.reference_init(ms.state_shapes(C, K, True), seed=args.random_seed)
     fixed = ms.reference_init(ms.state_shapes(C, 0, False), seed=args.random_seed)
-    n1 = restore(state, args.restore_from, args.not_restore_last)
-    n2 = restore(fixed, args.restore_from)
+    n1 = restore(state, args.restore_from, args.not_restore_last, required=not (args.synthetic or args.from_scratch))
+    n2 = restore(fixed, args.restore_from, required=not (args.synthetic or args.from_scratch))
     cd = ms.load_class_dist("bapa")
     hp = Hyper(num_classes=C, open_classes=K, th_high=args.Threshold_high, th_low=args.Threshold_low,
                lambda_seg=args.lambda_seg, lambda_place=args.lambda_Place, lambda_convex=args.lambda_Convex,
@@ -123,7 +152,8 @@ def main(argv=None):
         print(f"restored {n1}/{n2} tensors from {args.restore_from}; {world} GPU(s), batch {args.batch_size}/GPU, "
               f"{h}x{w}, {args.compute_dtype}, K={K}")
         os.makedirs(args.snapshot_dir, exist_ok=True)
-    data = batches(args, args.batch_size, h, w, cd, rank, dev)
+    data = batches(args, args.batch_size, h, w, cd, rank, world, dev)
+    evaluator, best_mIoU, best_iter = None, 0, 0
     t0 = time.time()
     for i_iter in range(args.num_steps):
         mb = [next(data) for _ in range(args.iter_size)]           # gradient accumulation: iter_size micro-batches per step
@@ -132,16 +162,33 @@ def main(argv=None):
         if i_iter % args.print_every == 0 and rank == 0:
             l = tr.losses()
             print("iter = {0:8d}/{1:8d}, loss_seg_p = {2:.3f} loss_seg_y = {3:.3f} Convex = {4:.3f} Volume = {5:.3f} "
-                  "Anchor = {6:.3f} Place = {7:.3f}  lr = {8:.2e}  ({9:.1f} img/s)".format(
-                      i_iter, args.num_steps, l["loss_p2"], l["loss_y2"], l["convex"], l["volume"], l["anchor"], l["place"],
-                      lr_poly(args.learning_rate, i_iter, args.num_steps, args.power),
-                      args.batch_size * world * (i_iter + 1) / max(time.time() - t0, 1e-9)))
-        if i_iter >= args.num_steps_stop - 1 or (i_iter % args.save_pred_every == 0 and i_iter != 0):
+                  "Anchor = {6:.3f} Place_loss = {7:.3f}  lr = {8:.2e}  ({9:.1f} img/s)".format(
+                      i_iter, args.num_steps, l["loss_p1"] + l["loss_p2"], l["loss_y1"] + l["loss_y2"], l["convex"], l["volume"],
+                      l["anchor"], l["place"], lr_poly(args.learning_rate, i_iter, args.num_steps, args.power),
+                      args.batch_size * world * (i_iter + 1) / max(time.time() - t0, 1e-9)))               # :438-441 (p1+p2, y1+y2)
+        if i_iter >= args.num_steps_stop - 1:
             if rank == 0:
-                sd = {k: v.detach().cpu() for k, v in tr.params.items()}
-                torch.save(sd, osp.join(args.snapshot_dir, f"SimT_{i_iter}.pth"))
-            if i_iter >= args.num_steps_stop - 1:
-                break
+                print("save model ...")
+                torch.save(tr.state_dict(), osp.join(args.snapshot_dir, "GTA5_" + str(args.num_steps_stop) + ".pth"))   # :447-450
+            break
+        if i_iter % args.save_pred_every == 0 and i_iter != 0 and args.data_dir_val:
+            # :452-464: evaluate, keep only the best-mIoU snapshot
+            from simt_amd.tools.evaluate_cityscapes import Evaluator, evaluate_simt
+            if evaluator is None:
+                evaluator = Evaluator(tr.params, num_classes=C, open_classes=K, dtype=dtype, device=dev)
+            if rank == 0:
+                print(time.strftime("%Y-%m-%d %H:%M:%S"), "  Begin evaluation on iter {0:8d}/{1:8d}  ".format(i_iter, args.num_steps))
+            mIoU = evaluate_simt(tr.params, args.data_dir_val, args.data_list_val, args.gt_dir_val, args.devkit_dir, num_classes=C,
+                                 open_classes=K, device=dev, dtype=dtype, evaluator=evaluator, rank=rank, world=world, process_group=pg)
+            if rank == 0:
+                print("Finish Evaluation: " + time.asctime(time.localtime(time.time())))
+                if mIoU > best_mIoU:
+                    old_file = osp.join(args.snapshot_dir, "GTA5_iter" + str(best_iter) + "_mIoU" + str(best_mIoU) + ".pth")
+                    if os.path.exists(old_file):
+                        os.remove(old_file)
+                    print("Saving model with mIoU: ", mIoU)
+                    torch.save(tr.state_dict(), osp.join(args.snapshot_dir, "GTA5_iter" + str(i_iter) + "_mIoU" + str(mIoU) + ".pth"))
+                    best_mIoU, best_iter = mIoU, i_iter
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -62,22 +62,25 @@ def test_metric_helpers_match_reference_golden():
     assert round(float(np.nanmean(per_class_iu(h))) * 100, 2) == float(d["miou"])
 
 
-def test_evaluator_end_to_end_small(dev):
-    """Two eval plans (two input scales) + fused predict + histogram vs the oracle on the CPU, fp32, small trunk."""
+@pytest.mark.parametrize("K", [3, 0])
+def test_evaluator_end_to_end_small(dev, K):
+    """Two eval plans (two input scales) + fused predict + histogram vs the oracle on the CPU, fp32, small trunk.
+    K = 3: evaluate_simt (open-set heads present, logits[:, :19] scored, evaluate_cityscapes.py:96-162); K = 0: evaluate_warmup
+    (:165-225, a warm-up checkpoint without open-set heads)."""
     layers = (1, 1, 2, 1)
-    st = so.recipe_state(so.state_shapes(19, 3, True, layers=layers), seed=31, head_scale=8.0)
+    st = so.recipe_state(so.state_shapes(19, K, K > 0, layers=layers), seed=31, head_scale=8.0)
     g = torch.Generator().manual_seed(9)
     B, (H, W) = 1, (64, 96)
     s1, s2 = (33, 49), (41, 61)
     img1 = torch.randn(B, 3, *s1, generator=g) * 50
     img2 = F.interpolate(img1, size=s2, mode="bilinear", align_corners=True)
     gt = torch.randint(0, 19, (B, H, W), generator=g)
-    ev = Evaluator(st, num_classes=19, open_classes=3, batch=B, label_hw=(H, W), scales=(s1, s2), dtype=torch.float32,
+    ev = Evaluator(st, num_classes=19, open_classes=K, batch=B, label_hw=(H, W), scales=(s1, s2), dtype=torch.float32,
                    device=dev, layers=layers)
     ev.add(img1, img2, gt)
     miou, ius = ev.result()
-    _, o1 = so.deeplab_multi_forward(st, img1, False, True, layers=layers)
-    _, o2 = so.deeplab_multi_forward(st, img2, False, True, layers=layers)
+    _, o1 = so.deeplab_multi_forward(st, img1, False, K > 0, layers=layers)
+    _, o2 = so.deeplab_multi_forward(st, img2, False, K > 0, layers=layers)
     out = (F.interpolate(o1[:, :19], size=(H, W), mode="bilinear", align_corners=True).numpy() +
            F.interpolate(o2[:, :19], size=(H, W), mode="bilinear", align_corners=True).numpy())
     pred = np.argmax(out.transpose(0, 2, 3, 1), axis=3)
@@ -115,3 +118,34 @@ def test_upsample_nchw_forward_and_adjoint(dev, align, shape):
         got = dsrc[..., :C].float().cpu().permute(0, 3, 1, 2)
         assert (got - x.grad).abs().max().item() < tol * x.grad.abs().max().item()
         assert (dsrc[..., C:] == 0).all()
+
+
+def test_upsample_sum_argmax_at_cityscapes_resolution(dev):
+    """The evaluation kernel at the reference's geometry: logits 65 x 129 (1024 x 512 input) + 81 x 161 (1280 x 640) -> 1024 x 2048
+    labels, against torch CPU; mismatches only where the two largest summed logits are closer than 1e-5 (FMA contraction)."""
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 8)))
+    g = torch.Generator().manual_seed(12)
+    B, C, H, W = 1, 19, 1024, 2048
+    la = torch.randn(B, C, 65, 129, generator=g) * 3
+    lb = torch.randn(B, C, 81, 161, generator=g) * 3
+    ref_sum = (F.interpolate(la, size=(H, W), mode="bilinear", align_corners=True).numpy() +
+               F.interpolate(lb, size=(H, W), mode="bilinear", align_corners=True).numpy())
+    ref = np.argmax(ref_sum.transpose(0, 2, 3, 1), axis=3)
+
+    def nhwc(t, ld=32):
+        o = torch.zeros(t.shape[0], t.shape[2], t.shape[3], ld)
+        o[..., :t.shape[1]] = t.permute(0, 2, 3, 1)
+        return o.to(dev)
+    a_d, b_d = nhwc(la), nhwc(lb)
+    pred = torch.full((B, H, W), -1, device=dev, dtype=torch.int32)
+    L.call("simt_upsample_sum_argmax", ops._p(a_d), 65, 129, 32, ops._p(b_d), 81, 161, 32, B, H, W, C, ops._p(pred), ops.stream_ptr())
+    got = pred.cpu().numpy()
+    srt = np.sort(ref_sum, axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    diff = got != ref
+    assert diff.sum() <= 20 and np.all(margin[diff] < 1e-5), f"{diff.sum()} mismatches of {got.size}, margins {margin[diff][:5]}"
+    gt = torch.randint(0, C, (B, H, W), generator=g)
+    gt[torch.rand(B, H, W, generator=g) < 0.1] = 255
+    hist = torch.zeros(C * C, device=dev, dtype=torch.int64)
+    L.call("simt_confusion_hist", ops._p(gt.to(dev)), ops._p(pred), gt.numel(), C, ops._p(hist), ops.stream_ptr())
+    assert np.array_equal(hist.cpu().numpy().reshape(C, C), fast_hist(gt.numpy().flatten(), got.flatten().astype(np.int64), C))

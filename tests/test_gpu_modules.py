@@ -166,3 +166,21 @@ def test_res_deeplab_single_head_module(dev):
     for i in range(4):                                   # all four branches are live in deeplab.py
         assert rel(m.layer5.conv2d_list[i].weight.grad, stg[f"layer5.conv2d_list.{i}.weight"].grad) < 1e-3
         assert rel(m.layer5.conv2d_list[i].bias.grad, stg[f"layer5.conv2d_list.{i}.bias"].grad) < 1e-4
+
+
+def test_cross_entropy_out_of_range_label_is_loud(dev):
+    """A target in [C, 254] is an error in the reference (torch raises "Target ... is out of bounds"); here it must neither index out
+    of bounds nor pass silently: the loss comes back NaN and the gradient stays finite (csrc/loss2d.hip ce_oob)."""
+    from simt_amd.utils.loss import CrossEntropy2d
+    g = torch.Generator().manual_seed(1)
+    pred = torch.randn(2, 19, 9, 11, generator=g).to(dev).requires_grad_(True)
+    tgt = torch.randint(0, 19, (2, 9, 11), generator=g)
+    tgt[0, 0, 0] = 255
+    ok = CrossEntropy2d()(pred, tgt.to(dev))
+    assert torch.isfinite(ok)
+    tgt[1, 3, 3] = 20
+    bad = CrossEntropy2d()(pred, tgt.to(dev))
+    assert torch.isnan(bad)
+    pred.grad = None
+    ok.backward()
+    assert torch.isfinite(pred.grad).all()

@@ -317,11 +317,19 @@ def _nchw(t, Cn):
     return t[..., :Cn].permute(0, 3, 1, 2).double().cpu()
 
 
+def _feat(t, B, h, w):
+    """[B*h*w, C] device buffer -> float64 NCHW on the host."""
+    return t.view(B, h, w, -1).permute(0, 3, 1, 2).double().cpu()
+
+
 def test_full_depth_r101_bf16_forward_b4_768(dev):
-    """BASELINE configs[1] exactly (B=4, 768x768, bf16, 23-block layer3): the frozen (BN-folded) forward and the train-mode forward
-    of the production plans vs the float64 bf16-storage model.  Eval is well conditioned: 1e-2 of max|logit| (measured 4-7e-3: 1-ulp
-    bf16 rounding flips of fp32- vs float64-accumulated sums through 101 layers; the arg-max of the logits differs on < 0.2 % of the
-    positions).  Train mode back-propagates nothing here, but batch-statistic BN amplifies those flips: 2e-2."""
+    """BASELINE configs[1] exactly (B=4, 768x768, bf16, 33 bottlenecks): the production plans against the float64 bf16-storage model.
+      * frozen (BN-folded) forward, END TO END: well conditioned, 1e-2 of max|logit| (measured 4-7e-3: 1-ulp bf16 rounding flips of
+        fp32- vs float64-accumulated sums through 101 layers), arg-max differs on < 0.2 % of the positions;
+      * train-mode forward, EVERY BLOCK fed with the GPU's own block input (the conditioning argument of tests/test_gpu_trunk.py: an
+        untrained 101-layer net with batch-statistic BN is a chaotic map -- a 1-ulp bf16 flip moves the END-TO-END logits by tens of
+        per cent in ANY implementation, two float64 runs with different thread counts included -- so end-to-end agreement is not a
+        meaningful bar in bf16; per block it is): a1, a2, z within 2e-2 of max|ref|, the heads' logits from the GPU's own features 1e-2."""
     K, B, H, W = 3, B4, 768, 768
     _threads()
     st = so.recipe_state(so.state_shapes(19, K, True), seed=1234, head_scale=8.0)
@@ -345,47 +353,100 @@ def test_full_depth_r101_bf16_forward_b4_768(dev):
     assert "conv_igemm2_kernel<256, 5, 3, 0, 0>" in tags and "conv_igemm2_kernel<128, 4, 2, 0, 0>" in tags
     out = tr.forward(img.to(dev))
     torch.cuda.synchronize()
-    t1, t2 = _nchw(out["x1"], 22), _nchw(out["x2"], 22)
-    del tr
+    worst = 0.0
     with torch.no_grad():
-        m1, m2 = so.bf16_model_forward(st, img, True, True)
-    r1, r2 = _rel(t1, m1), _rel(t2, m2)
-    print(f"train bf16 vs storage model: x1 {r1:.2e} x2 {r2:.2e}")
-    assert r1 < 2e-2 and r2 < 2e-2
+        for rec in tr.block_io:
+            x = _feat(rec["x"], B, rec["Hi"], rec["Wi"])
+            a1, a2, z = so.bf16_block_forward(st, rec["name"], x, rec["stride"], rec["dil"], rec["down"], True)
+            for key, ref in (("a1", a1), ("a2", a2), ("z", z)):
+                e = _rel(_feat(rec[key], B, rec["Ho"], rec["Wo"]), ref)
+                worst = max(worst, e)
+                assert e < 2e-2, f"{rec['name']} {key}: {e:.2e}"
+        for hd in tr.heads:
+            f = _feat(hd.feat, B, hd.h, hd.w)
+            ref = torch.cat([so.bf16_aspp(st, pref, f) for pref, _c in hd.groups], 1)
+            e = _rel(_nchw(out[hd.name], 22), ref)
+            assert e < 1e-2, f"head {hd.name}: {e:.2e}"
+    print(f"train-mode bf16, 33 blocks at B=4 768x768: worst block-level error {worst:.2e}")
 
 
-def test_full_depth_r101_bf16_train_step_b1_768(dev):
-    """Full-depth bf16 forward + BACKWARD (dgrad, wgrad2 at production split, fused BN-backward reduce, bit masks) at 1 x 768 x 768
-    against autograd through the float64 bf16-storage model (roundings passed straight through).  The backward's own bf16 storage
-    (dY tensors) is not modelled, so gradients are held to relative-L2 / cosine bounds: every one of the 120 tensors cos > 0.99,
-    median relative L2 < 3e-2."""
-    K, B, H, W = 3, 1, 768, 768
-    _threads()
+def _bwd_setup(dev, B, fuse, monkeypatch, seed=99):
+    monkeypatch.setenv("SIMT_BN_FUSE", "1" if fuse else "0")
+    K, H, W = 3, 768, 768
     st = so.recipe_state(so.state_shapes(19, K, True), seed=1234, head_scale=8.0)
-    img, _ = so.synthetic_batch(B, H, W, CD.numpy(), seed=99)
+    img, _ = so.synthetic_batch(B, H, W, CD.numpy(), seed=seed)
     p = {k: v.clone().to(dev) for k, v in st.items()}
     tr = TrunkPlan(p, B, H, W, multi_heads(19, K, True), dtype=BF, train=True)
-    out = tr.forward(img.to(dev))
+    tr.forward(img.to(dev))
+    return st, tr
+
+
+def test_full_depth_r101_bf16_backward_blocks_b1_768(dev, monkeypatch):
+    """Full-depth bf16 BACKWARD, block by block (dgrad <256,*,3> / <128,4,2>, conv_wgrad2 + slab reduce, BatchNorm backward with bit masks)
+    at 1 x 768 x 768: every Bottleneck's backward launches are replayed on a seeded dz and compared with autograd through the float64
+    bf16-storage model of that block evaluated on the GPU's own block input (roundings passed straight through; the backward's own bf16
+    storage of dY is not modelled): input gradient and all 3-4 weight gradients cos > 0.999 and relative L2 < 3e-2.  The fused
+    BatchNorm-backward reduce is switched off here (its partial sums come from the PREVIOUS block's launches, which a per-block replay
+    does not run); test_full_depth_bf16_backward_fused_equals_unfused_b4 covers it in situ."""
+    from simt_amd.engine import LaunchList
+    _threads()
+    B = 1
+    st, tr = _bwd_setup(dev, B, False, monkeypatch)
     g = torch.Generator().manual_seed(8)
-    h, w = tr.heads[0].h, tr.heads[0].w
-    ups = [(torch.randn(B, 22, h, w, generator=g) / (h * w)).to(BF).float() for _ in range(2)]
-    for name, up in zip(("x1", "x2"), ups):
-        dl = tr.dlogits[name]
-        dl.zero_()
-        dl[:, :22] = up.permute(0, 2, 3, 1).reshape(-1, 22).to(dev, BF)
-    grads = tr.backward()
-    torch.cuda.synchronize()
-    names = sorted(grads.keys())
-    stg = {k: (v.double().requires_grad_(True) if k in grads else v) for k, v in st.items()}
-    m1, m2 = so.bf16_model_forward(stg, img, True, True)
-    ((m1 * ups[0].double()).sum() + (m2 * ups[1].double()).sum()).backward()
-    assert _rel(_nchw(out["x1"], 22), m1.detach()) < 2e-2 and _rel(_nchw(out["x2"], 22), m2.detach()) < 2e-2
-    cos, l2 = [], []
-    for n in names:
-        a, b = grads[n].double().cpu().flatten(), stg[n].grad.flatten()
-        cos.append(F.cosine_similarity(a, b, dim=0).item())
-        l2.append(((a - b).norm() / b.norm()).item())
-    worst = int(np.argmin(cos))
-    print(f"bf16 full-depth gradients: cos min {min(cos):.4f} ({names[worst]}) median {np.median(cos):.5f}; "
-          f"rel-L2 median {np.median(l2):.3e} max {max(l2):.3e}")
-    assert min(cos) > 0.99 and np.median(l2) < 3e-2
+    worst_cos, worst_l2 = 1.0, 0.0
+    for rec in tr.block_io:
+        name = rec["name"]
+        x = _feat(rec["x"], B, rec["Hi"], rec["Wi"]).requires_grad_(True)
+        sd = {k: (v.double().requires_grad_(True) if ("conv" in k or "downsample.0" in k) else v) for k, v in st.items() if k.startswith(name + ".")}
+        _, _, z = so.bf16_block_forward(sd, name, x, rec["stride"], rec["dil"], rec["down"], True)
+        dz = (torch.randn(z.shape, generator=g) / z.shape[1] ** 0.5).to(BF).double()
+        z.backward(dz)
+        start, end, dzb, dxb = tr.bwd_marks[name]
+        dzb.copy_(dz.permute(0, 2, 3, 1).reshape(dzb.shape).to(dev, BF))
+        sub = LaunchList()
+        sub.items = tr.bwd_list.items[start:end]
+        sub.run()
+        torch.cuda.synchronize()
+        pairs = [(f"{name} dx", _feat(dxb, B, rec["Hi"], rec["Wi"]), x.grad)]
+        pairs += [(k, tr.grads[k].double().cpu(), v.grad) for k, v in sd.items() if v.dtype == torch.float64 and v.requires_grad]
+        for what, got, ref in pairs:
+            c = F.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
+            l2 = ((got - ref).norm() / ref.norm()).item()
+            worst_cos, worst_l2 = min(worst_cos, c), max(worst_l2, l2)
+            assert c > 0.999 and l2 < 3e-2, f"{what}: cos {c:.5f} rel-L2 {l2:.2e}"
+    print(f"bf16 block-level backward, 33 blocks: worst cos {worst_cos:.5f}, worst rel-L2 {worst_l2:.2e}")
+
+
+def test_full_depth_bf16_backward_fused_equals_unfused_b4(dev, monkeypatch):
+    """The production backward (B=4, 768x768, bf16) with the BatchNorm-backward reduce FUSED into the dgrad epilogues (default;
+    simt_conv_desc.bnr_*) against the same backward with the separate reduce kernel: same forward, same upstream gradient.  The two
+    differ only in the summation order of S1 / S2, so all 120 gradient tensors agree to 2e-3 relative L2 (no chaos: the backward is
+    linear given the stored activations and masks)."""
+    B = B4
+    g = torch.Generator().manual_seed(8)
+    res = []
+    ups = None
+    for fuse in (True, False):
+        st, tr = _bwd_setup(dev, B, fuse, monkeypatch, seed=1234)
+        n_fused = sum(1 for it in tr.bwd_list.items if it.fn is not None and it.tag.startswith("conv_igemm2") and it.keep is not None and it.keep.bnr_mode)
+        assert (n_fused > 60) == fuse, n_fused
+        h, w = tr.heads[0].h, tr.heads[0].w
+        if ups is None:
+            ups = [(torch.randn(B, 22, h, w, generator=g) / (h * w)).to(BF) for _ in range(2)]
+        for nm, up in zip(("x1", "x2"), ups):
+            dl = tr.dlogits[nm]
+            dl.zero_()
+            dl[:, :22] = up.permute(0, 2, 3, 1).reshape(-1, 22).to(dev)
+        grads = tr.backward()
+        torch.cuda.synchronize()
+        res.append({k: v.double().cpu() for k, v in grads.items()})
+        del tr
+        torch.cuda.empty_cache()
+    worst = 0.0
+    for k in res[0]:
+        a, b = res[0][k], res[1][k]
+        assert torch.isfinite(a).all() and b.norm() > 0
+        l2 = ((a - b).norm() / b.norm()).item()
+        worst = max(worst, l2)
+        assert l2 < 2e-3, f"{k}: fused vs unfused rel-L2 {l2:.2e}"
+    print(f"fused vs unfused BN-backward reduce, 120 gradients at B=4 768x768: worst rel-L2 {worst:.2e}")

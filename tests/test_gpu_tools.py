@@ -1,0 +1,69 @@
+"""The outer loop of the reference's SimT stage (tools/trainV2_simt.py:232-464) as `simt_amd.tools.trainV2_simt.main` runs it on the
+GPU: real files through the device input pipeline (cityscapesPseudo -> GpuLoader), the periodic evaluate_simt on a validation list
+with the best-mIoU snapshot rotation (:452-464), the final `GTA5_<num_steps_stop>.pth` (:447-450) with the reference's 656 state-dict
+keys, and the loud failures (missing data directory / checkpoint) that replace the reference's crashes."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_dataset(tmp_path, Image):
+    rng = np.random.default_rng(0)
+    for d in ("train_img", "train_lab", "val/frankfurt", "gt/frankfurt", "kit", "snap"):
+        (tmp_path / d).mkdir(parents=True)
+    lines = []
+    for i in range(4):
+        Image.fromarray(rng.integers(0, 256, (96, 192, 3), dtype=np.uint8)).save(tmp_path / "train_img" / f"t{i}.png")
+        lab = rng.integers(0, 19, (96, 192), dtype=np.uint8)
+        lab[rng.random(lab.shape) < 0.1] = 255
+        Image.fromarray(lab).save(tmp_path / "train_lab" / f"t{i}.png")
+        lines.append(f"train_img/t{i}.png train_lab/t{i}.png")
+    (tmp_path / "pseudo.lst").write_text("\n".join(lines) + "\n")
+    vals = []
+    for i in range(2):
+        name = f"frankfurt/frankfurt_00000{i}_leftImg8bit.png"
+        Image.fromarray(rng.integers(0, 256, (1024, 2048, 3), dtype=np.uint8)).save(tmp_path / "val" / name)
+        Image.fromarray(rng.integers(0, 34, (1024, 2048), dtype=np.uint8)).save(
+            tmp_path / "gt" / f"frankfurt/frankfurt_00000{i}_gtFine_labelIds.png")
+        vals.append(name)
+    (tmp_path / "kit" / "val.txt").write_text("\n".join(vals) + "\n")
+    l2t = [[i, i if i < 19 else 255] for i in range(34)] + [[-1, 255]]
+    json.dump({"classes": 19, "label": [f"c{i}" for i in range(19)], "label2train": l2t}, open(tmp_path / "kit" / "info.json", "w"))
+
+
+def test_train_tool_real_files_eval_and_snapshots(dev, tmp_path, capsys):
+    Image = pytest.importorskip("PIL.Image")
+    from simt_amd.tools import trainV2_simt as tool
+    _make_dataset(tmp_path, Image)
+    snap = str(tmp_path / "snap")
+    argv = ["--data-dir-target", str(tmp_path), "--data-list-target", str(tmp_path / "pseudo.lst"), "--input-size-target", "129,65",
+            "--batch-size", "2", "--num-steps", "50", "--num-steps-stop", "5", "--save-pred-every", "2", "--print-every", "1",
+            "--open-classes", "3", "--learning-rate", "6e-4", "--learning-rate-T", "6e-3", "--from-scratch", "--restore-from", "",
+            "--snapshot-dir", snap, "--data-dir-val", str(tmp_path), "--data-list-val", str(tmp_path / "kit" / "val.txt"),
+            "--gt-dir-val", str(tmp_path / "gt"), "--devkit-dir", str(tmp_path / "kit"), "--num-workers", "2", "--random-mirror"]
+    tool.main(argv)
+    out = capsys.readouterr().out
+    assert out.count("Begin evaluation") == 2 and out.count("===> mIoU:") == 2            # iterations 2 and 4
+    assert "iter =        4/" in out and "Place_loss" in out and "save model" in out
+    final = os.path.join(snap, "GTA5_5.pth")
+    assert os.path.exists(final)
+    sd = torch.load(final)
+    assert len(sd) == 656 and int(sd["bn1.num_batches_tracked"]) == 5 and sd["conv1.weight"].shape == (64, 3, 7, 7)
+    best = glob.glob(os.path.join(snap, "GTA5_iter*_mIoU*.pth"))
+    assert len(best) == 1                                                                  # the previous best was removed (:458-460)
+    assert all(torch.isfinite(v).all() for k, v in sd.items() if v.dtype.is_floating_point)
+
+
+def test_train_tool_refuses_missing_data_and_checkpoint(dev, tmp_path):
+    from simt_amd.tools import trainV2_simt as tool
+    base = ["--input-size-target", "129,65", "--batch-size", "1", "--num-steps-stop", "1", "--snapshot-dir", str(tmp_path / "s")]
+    with pytest.raises(FileNotFoundError):
+        tool.main(base + ["--synthetic" if False else "--data-dir-target", str(tmp_path / "nope"), "--restore-from", str(tmp_path / "no.pth")])
+    with pytest.raises(SystemExit):
+        tool.main(base + ["--data-dir-target", str(tmp_path / "nope"), "--from-scratch"])

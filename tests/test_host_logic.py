@@ -114,3 +114,25 @@ def test_bench_rejects_world_size_mismatch():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stderr + p.stdout)
+
+
+def test_restore_prefix_required_and_not_restore_last(tmp_path):
+    """Checkpoint restore of the tools: key filter + shape filter (trainV2_simt.py:248-255), the warm-up stage's 6-character prefix
+    strip (trainV1_warmup.py:177), --not-restore-last, and loud failure on a missing file / zero matches."""
+    from simt_amd.tools.trainV2_simt import restore
+    state = {"conv1.weight": torch.zeros(4, 3), "layer5.conv2d_list.0.weight": torch.zeros(2, 2), "bn1.bias": torch.zeros(4)}
+    ck = {"Scale.conv1.weight": torch.ones(4, 3), "Scale.layer5.conv2d_list.0.weight": torch.ones(2, 2), "Scale.bn1.bias": torch.ones(5),
+          "Scale.fc.weight": torch.ones(3)}
+    path = str(tmp_path / "ck.pth")
+    torch.save(ck, path)
+    st = dict(state)
+    assert restore(st, path) == 0                                            # verbatim keys: nothing matches
+    with pytest.raises(RuntimeError):
+        restore(dict(state), path, required=True)
+    st = dict(state)
+    assert restore(st, path, strip_prefix=6) == 2 and st["conv1.weight"].sum() == 12 and st["bn1.bias"].sum() == 0     # shape-filtered
+    st = dict(state)
+    assert restore(st, path, strip_prefix=6, not_restore_last=True) == 1 and st["layer5.conv2d_list.0.weight"].sum() == 0
+    with pytest.raises(FileNotFoundError):
+        restore(dict(state), str(tmp_path / "missing.pth"), required=True)
+    assert restore(dict(state), str(tmp_path / "missing.pth")) == 0

@@ -62,3 +62,16 @@ def test_dataset_lists_and_decode(tmp_path):
     assert rgb.shape == (20, 40, 3) and rgb.dtype == np.uint8 and lab.shape == (20, 40) and name == "a1_label"
     dv = cityscapesDataSet(str(tmp_path), str(tmp_path / "val.txt"), crop_size=(16, 8), mean=pr.IMG_MEAN, set="val")
     assert len(dv) == 3 and dv.decode(2)[1] is None and dv.decode(2)[2] == "a2.png"
+
+
+def test_ntm_stats_oracle_matches_reference_golden():
+    """oracle.class_distribution / rect_hist / label_mapping (tools/compute_ClassDistribution.py, compute_ConfusionMatrix.py) against
+    the outputs of the reference's own functions (tests/golden/g14_hist.npz)."""
+    from oracle import simt_oracle as so
+    d = np.load(os.path.join(G, "g14_hist.npz"))
+    c, nrm = so.class_distribution(list(d["cd_preds"]))
+    assert np.array_equal(c, d["cd_counts"]) and np.array_equal(nrm, d["cd_norm"])
+    M = np.zeros((34, 19))
+    for g_, p in zip(d["cm_gts"], d["cm_preds"]):
+        M += so.rect_hist(so.label_mapping(g_, d["cm_mapping"]).flatten(), p.flatten(), 34, 19)
+    assert np.array_equal(M, d["cm_counts"])
