@@ -65,9 +65,8 @@ typedef struct {
   int32_t bnr_mode, bnr_ld;
 } simt_conv_desc;
 int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);
-/* which kernel instantiation simt_conv_fprop runs for d: returns 0 (conv_igemm_kernel), 2 (conv_igemm2_kernel<bn,tm,nst>)
- * or 3 (conv1x1_nloop_kernel<tm>: resident pixel panel, loop over the column tiles; tm = Cin / 64; experimental, only
- * with the environment variable SIMT_CONV_NLOOP=1) */
+/* which kernel instantiation simt_conv_fprop runs for d (profiling / reporting / tests that must hit a given instantiation):
+ * returns 0 (conv_igemm_kernel, fp32 parity + narrow outputs) or 2 (conv_igemm2_kernel<bn, tm, nst>, the bf16 throughput kernel) */
 int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int* nst);
 /* number of pixel tiles (= statistics / bnr_part slots) the launch for d uses; 0 if d does not run on the bf16 v2 kernel */
 int simt_conv_mtiles(const simt_conv_desc* d);

@@ -5,6 +5,8 @@ cd "$(dirname "$0")"
 OUT=../libsimt_hip.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
+# ABLATION=1: also compile the timing-ablation / loader-wave experiment instantiations (outputs meaningless; never shipped)
+if [ "${ABLATION:-0}" = "1" ]; then FLAGS="$FLAGS -DSIMT_ABLATION"; fi
 mkdir -p ../_build
 objs=()
 pids=()

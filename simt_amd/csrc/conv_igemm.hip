@@ -279,14 +279,6 @@ static int launch_conv(const ConvKArgs& k, hipStream_t st) {
 }
 
 int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream);  // conv_igemm2.hip
-bool simt_conv_nloop_eligible(const simt_conv_desc* d);                       // conv1x1_nloop.hip
-int simt_conv_fprop_bf16_nloop(const simt_conv_desc* d, simt_stream_t stream);
-// Experimental (conv1x1_nloop.hip): correct, but at 49 us not faster than the tiled kernel's 42-49 us on the 256 -> 1024 shape
-// (its register-direct stores reach ~2.1 TB/s against ~3.2 TB/s for the LDS-transposed row stores): opt-in only.
-static bool nloop_enabled() {
-  const char* e = getenv("SIMT_CONV_NLOOP");
-  return e && e[0] == '1';
-}
 
 extern "C" int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream) {
   SIMT_CHECK(d && d->x && d->w && d->y);
@@ -300,7 +292,6 @@ extern "C" int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream) {
   SIMT_CHECK(d->Nstore % 8 == 0 && d->Nstore <= d->Npad && d->Nstore <= d->ldy);
   SIMT_CHECK(d->ldy % 8 == 0 && (!d->res || d->ldr % 8 == 0) && (!d->mask || d->ldm % 8 == 0));
   SIMT_CHECK(!(d->dtype_in == SIMT_F32 && d->dtype_out == SIMT_BF16));
-  if (v2 && nloop_enabled() && simt_conv_nloop_eligible(d)) return simt_conv_fprop_bf16_nloop(d, stream);
   if (v2) return simt_conv_fprop_bf16_v2(d, stream);
   SIMT_CHECK(!d->bnr_mode);   // the fused BN-backward reduce exists in the bf16 v2 kernel only
   ConvKArgs k;

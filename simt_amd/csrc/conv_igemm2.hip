@@ -357,6 +357,18 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
       }
     return;
   }
+  // Stream the tile out as whole rows (16 B per lane, 512-B rows) with bias / residual / ReLU applied on the way, and
+  // accumulate the BatchNorm statistics (sum, sum of squares of the STORED bf16 values of the valid rows) per lane.
+  constexpr int VPR = BN / 8;        // 16-B vectors per row
+  constexpr int RPP = NT / VPR;      // rows per pass (= number of row groups)
+  constexpr int NIT = (BM + RPP - 1) / RPP;   // rows per thread
+  const int vcol = (tid % VPR) * 8;
+  const int rg = tid / VPR;
+  const int n = n0 + vcol;
+  // Operands the epilogue reads from global memory (residual, its bit mask, the saved activation of the fused BatchNorm-backward
+  // reduce, the VGG ReLU mask): ALL rows of this thread are requested here, right after the accumulators left for LDS (their
+  // registers are free), so the HBM latency is paid once per workgroup (one row ahead, as in round 1, exposed it once per row: 4-10
+  // dependent round trips per workgroup, the largest part of the short-K kernels' time).
   __syncthreads();
   char* sC = smem;                                   // [BM][CP] bytes, bf16
 #pragma unroll
@@ -370,14 +382,27 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
       pk.y = (uint32_t)f2bf(acc[j][i][2]) | ((uint32_t)f2bf(acc[j][i][3]) << 16);
       *(uint2*)(sC + r * CP + c * 2) = pk;
     }
+  struct Aux { uint4 res, by; unsigned rbits, ybits; };   // by: saved activation (bnr) or ReLU mask operand (VGG): exclusive
+  const bool aux = (a.res || a.bnr_mode || a.mask) && n < a.Nstore;
+  Aux q[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    q[it].res = q[it].by = make_uint4(0u, 0u, 0u, 0u);
+    q[it].rbits = q[it].ybits = 0xffu;
+    const int m = m0 + rg + it * RPP;
+    if (aux && rg + it * RPP < BM && m < m_end) {
+      if (a.res) {
+        q[it].res = *(const uint4*)(a.res + (long)m * a.ldr + n);
+        if (a.res_bits) q[it].rbits = a.res_bits[((long)m * a.ldr + n) >> 3];
+      }
+      if (a.bnr_mode) {
+        q[it].by = *(const uint4*)(a.bnr_y + (long)m * a.bnr_ld + n);
+        if (a.bnr_mode == 3) q[it].ybits = a.bnr_bits[((long)m * a.bnr_ld + n) >> 3];
+      }
+      if (a.mask) q[it].by = *(const uint4*)(a.mask + (long)m * a.ldm + n);
+    }
+  }
   __syncthreads();
-  // Stream the tile out as whole rows (16 B per lane, 512-B rows) with bias / residual / ReLU applied on the way, and
-  // accumulate the BatchNorm statistics (sum, sum of squares of the STORED bf16 values of the valid rows) per lane.
-  constexpr int VPR = BN / 8;        // 16-B vectors per row
-  constexpr int RPP = NT / VPR;      // rows per pass (= number of row groups)
-  const int vcol = (tid % VPR) * 8;
-  const int rg = tid / VPR;
-  const int n = n0 + vcol;
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -392,40 +417,18 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
       load8(a.bnr_rstd + n, brs);
       if (a.bnr_mode == 2) { load8(a.bnr_scale + n, bsc); load8(a.bnr_shift + n, bsh); }
     }
-    // Operands the epilogue reads from global memory (residual, its bit mask, the saved activation of the fused BatchNorm-backward
-    // reduce, the VGG ReLU mask) are fetched ONE ROW AHEAD: their HBM latency overlaps the previous row's arithmetic and stores.
-    struct Aux { uint4 res, by, mk; unsigned rbits, ybits; };
-    auto fetch = [&](int m) {
-      Aux x;
-      x.res = x.by = x.mk = make_uint4(0u, 0u, 0u, 0u);
-      x.rbits = x.ybits = 0xffu;
-      if (a.res) {
-        x.res = *(const uint4*)(a.res + (long)m * a.ldr + n);
-        if (a.res_bits) x.rbits = a.res_bits[((long)m * a.ldr + n) >> 3];
-      }
-      if (a.bnr_mode) {
-        x.by = *(const uint4*)(a.bnr_y + (long)m * a.bnr_ld + n);
-        if (a.bnr_mode == 3) x.ybits = a.bnr_bits[((long)m * a.bnr_ld + n) >> 3];
-      }
-      if (a.mask) x.mk = *(const uint4*)(a.mask + (long)m * a.ldm + n);
-      return x;
+    auto unpack = [](const uint4& qq, float* v) {
+      v[0] = __uint_as_float(qq.x << 16); v[1] = __uint_as_float(qq.x & 0xffff0000u);
+      v[2] = __uint_as_float(qq.y << 16); v[3] = __uint_as_float(qq.y & 0xffff0000u);
+      v[4] = __uint_as_float(qq.z << 16); v[5] = __uint_as_float(qq.z & 0xffff0000u);
+      v[6] = __uint_as_float(qq.w << 16); v[7] = __uint_as_float(qq.w & 0xffff0000u);
     };
-    auto unpack = [](const uint4& q, float* v) {
-      v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
-      v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
-      v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xffff0000u);
-      v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xffff0000u);
-    };
-    const bool aux = a.res || a.bnr_mode || a.mask;
-    Aux nxt;
-    nxt.res = nxt.by = nxt.mk = make_uint4(0u, 0u, 0u, 0u);
-    nxt.rbits = nxt.ybits = 0xffu;
-    if (aux && rg < BM && m0 + rg < m_end) nxt = fetch(m0 + rg);
-    for (int r = rg; r < BM; r += RPP) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int r = rg + it * RPP;
       const int m = m0 + r;
-      if (m >= m_end) break;
-      const Aux cur = nxt;
-      if (aux && r + RPP < BM && m + RPP < m_end) nxt = fetch(m + RPP);
+      if (r >= BM || m >= m_end) break;
+      const Aux cur = q[it];
       const uint2 lo = *(const uint2*)(sC + r * CP + vcol * 2);
       const uint2 hi = *(const uint2*)(sC + r * CP + vcol * 2 + 8);
       const uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
         }
         if (a.mask) {
           float mv[8];
-          unpack(cur.mk, mv);
+          unpack(cur.by, mv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
         }
@@ -535,28 +538,27 @@ static int launch_conv2m(const Conv2KArgs& k, hipStream_t st) {
   return SIMT_OK;
 }
 
+// The product library instantiates the kernel once per tile shape (MODE 0, LW 0).  The timing-ablation builds (MODE 1 / 2 / 11-13:
+// loads only, MFMA only, priority variants -- their OUTPUTS ARE MEANINGLESS) and the loader-wave experiments (LW 4 / 8) exist only
+// in a library compiled with -DSIMT_ABLATION (csrc/build.sh ABLATION=1), where SIMT_CONV2_MODE / SIMT_CONV2_LW select them.
+#ifdef SIMT_ABLATION
 #include <stdlib.h>
-static int conv2_loader_waves() {          // SIMT_CONV2_LW=1 selects the wave-specialised build (experiment, see the kernel's LW note)
-  static int lw = -1;
-  if (lw < 0) { const char* e = getenv("SIMT_CONV2_LW"); lw = e ? atoi(e) : 0; }
-  return lw;     // 0 (default), 4 or 8 loader waves
-}
+static int conv2_env(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+#endif
 template <int BN, int TM, int NST = 3>
 static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("SIMT_CONV2_MODE");
-    mode = e ? atoi(e) : 0;
-  }
+#ifdef SIMT_ABLATION
+  static const int mode = conv2_env("SIMT_CONV2_MODE"), lw = conv2_env("SIMT_CONV2_LW");
   if (mode == 1) return launch_conv2m<BN, TM, NST, 1>(k, st);
   if (mode == 2) return launch_conv2m<BN, TM, NST, 2>(k, st);
   if (mode == 11) return launch_conv2m<BN, TM, NST, 11>(k, st);
   if (mode == 12) return launch_conv2m<BN, TM, NST, 12>(k, st);
   if (mode == 13) return launch_conv2m<BN, TM, NST, 13>(k, st);
   if constexpr (NST == 3) {
-    if (conv2_loader_waves() == 4) return launch_conv2m<BN, TM, NST, 0, 4>(k, st);
-    if (conv2_loader_waves() == 8) return launch_conv2m<BN, TM, NST, 0, 8>(k, st);
+    if (lw == 4) return launch_conv2m<BN, TM, NST, 0, 4>(k, st);
+    if (lw == 8) return launch_conv2m<BN, TM, NST, 0, 8>(k, st);
   }
+#endif
   return launch_conv2m<BN, TM, NST, 0>(k, st);
 }
 
@@ -574,7 +576,6 @@ static void pick_rows(int M, int ntn, bool allow160, int* rows, int* tm) {
   }
 }
 
-bool simt_conv_nloop_eligible(const simt_conv_desc* d);   // conv1x1_nloop.hip
 struct Conv2Variant { int tile_n, tm, nst, rows, ntiles_n; };
 static Conv2Variant pick_variant(const simt_conv_desc* d) {
   Conv2Variant v;
@@ -599,20 +600,14 @@ extern "C" int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int*
   const bool v2 = d->dtype_in == SIMT_BF16 && d->tile_n >= 64 &&
                   (d->dtype_out == SIMT_BF16 || (!d->bias && !d->res && !d->relu && !d->stats && !d->mask && d->tile_n == 256));
   if (!v2) { *bn = d->tile_n; *tm = 0; *nst = 2; return 0; }
-  {
-    const char* e = getenv("SIMT_CONV_NLOOP");
-    if (e && e[0] == '1' && simt_conv_nloop_eligible(d)) { *bn = 128; *tm = d->Cin / 64; *nst = 3; return 3; }   // conv1x1_nloop_kernel<K/64>
-  }
   const Conv2Variant v = pick_variant(d);
   *bn = v.tile_n; *tm = v.tm; *nst = v.nst;
   return 2;
 }
 
-int simt_conv_nloop_mtiles(const simt_conv_desc* d);      // conv1x1_nloop.hip
 extern "C" int simt_conv_mtiles(const simt_conv_desc* d) {
   int bn, tm, nst;
   const int gen = simt_conv_variant(d, &bn, &tm, &nst);
-  if (gen == 3) return simt_conv_nloop_mtiles(d);
   if (gen != 2) return 0;
   const Conv2Variant v = pick_variant(d);
   const int M = d->B * d->Ho * d->Wo;

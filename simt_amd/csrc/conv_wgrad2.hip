@@ -225,18 +225,24 @@ int simt_conv_wgrad_bf16_v2(const simt_wgrad_desc* d, simt_stream_t stream) {
   k.rcpHoWo = 1.0f / (float)(d->Ho * d->Wo);
   for (int i = 0; i < SIMT_MAX_TAPS; ++i) { k.tdy[i] = d->dy_[i]; k.tdx[i] = d->dx_[i]; }
   const int lds = 3 * 3 * 64 * 256;
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("SIMT_WGRAD2_MODE");
-    mode = e ? atoi(e) : 0;
+  static bool attr_set = false;
+  if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
   }
   const int grid = k.cotiles * k.ktiles * k.nsplit;
-  if (mode == 1) hipLaunchKernelGGL(conv_wgrad2_kernel<1>, dim3(grid), dim3(512), lds, (hipStream_t)stream, k);
-  else if (mode == 2) hipLaunchKernelGGL(conv_wgrad2_kernel<2>, dim3(grid), dim3(512), lds, (hipStream_t)stream, k);
-  else hipLaunchKernelGGL(conv_wgrad2_kernel<0>, dim3(grid), dim3(512), lds, (hipStream_t)stream, k);
+#ifdef SIMT_ABLATION     // timing ablations (loads only / MFMA only: MEANINGLESS outputs), never in the product library
+  static const int mode = getenv("SIMT_WGRAD2_MODE") ? atoi(getenv("SIMT_WGRAD2_MODE")) : 0;
+  if (mode == 1 || mode == 2) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (mode == 1) hipLaunchKernelGGL(conv_wgrad2_kernel<1>, dim3(grid), dim3(512), lds, (hipStream_t)stream, k);
+    else hipLaunchKernelGGL(conv_wgrad2_kernel<2>, dim3(grid), dim3(512), lds, (hipStream_t)stream, k);
+    SIMT_LAUNCH_CHECK();
+    return SIMT_OK;
+  }
+#endif
+  hipLaunchKernelGGL(conv_wgrad2_kernel<0>, dim3(grid), dim3(512), lds, (hipStream_t)stream, k);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }

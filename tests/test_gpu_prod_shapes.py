@@ -418,15 +418,17 @@ def test_full_depth_r101_bf16_backward_blocks_b1_768(dev, monkeypatch):
 
 
 def test_full_depth_bf16_backward_fused_equals_unfused_b4(dev, monkeypatch):
-    """The production backward (B=4, 768x768, bf16) with the BatchNorm-backward reduce FUSED into the dgrad epilogues (default;
-    simt_conv_desc.bnr_*) against the same backward with the separate reduce kernel: same forward, same upstream gradient.  The two
-    differ only in the summation order of S1 / S2, so all 120 gradient tensors agree to 2e-3 relative L2 (no chaos: the backward is
-    linear given the stored activations and masks)."""
+    """The production backward (B=4, 768x768, bf16, two-stream schedule) with the BatchNorm-backward reduce FUSED into the dgrad
+    epilogues (default; simt_conv_desc.bnr_*) against the same backward with the separate reduce kernel: same forward, same upstream
+    gradient.  (1) The fused backward is run twice on fresh plans: all 120 gradient tensors BIT-IDENTICAL (fixed-order reductions, no
+    float atomics, stream hand-offs by events).  (2) Fused vs unfused differ in the summation order of S1 / S2 only; the ~1e-6 this
+    moves dY by flips a few bf16 roundings per stored tensor, which the following layers carry along: relative L2 < 1e-2 per tensor,
+    median < 2e-3."""
     B = B4
     g = torch.Generator().manual_seed(8)
     res = []
     ups = None
-    for fuse in (True, False):
+    for fuse in (True, True, False):
         st, tr = _bwd_setup(dev, B, fuse, monkeypatch, seed=1234)
         n_fused = sum(1 for it in tr.bwd_list.items if it.fn is not None and it.tag.startswith("conv_igemm2") and it.keep is not None and it.keep.bnr_mode)
         assert (n_fused > 60) == fuse, n_fused
@@ -439,14 +441,16 @@ def test_full_depth_bf16_backward_fused_equals_unfused_b4(dev, monkeypatch):
             dl[:, :22] = up.permute(0, 2, 3, 1).reshape(-1, 22).to(dev)
         grads = tr.backward()
         torch.cuda.synchronize()
-        res.append({k: v.double().cpu() for k, v in grads.items()})
+        res.append({k: v.clone() for k, v in grads.items()})
         del tr
         torch.cuda.empty_cache()
-    worst = 0.0
+    diff = [k for k in res[0] if not torch.equal(res[0][k], res[1][k])]
+    assert not diff, f"{len(diff)} gradient tensors differ between two runs of the same backward: {diff[:5]}"
+    l2 = {}
     for k in res[0]:
-        a, b = res[0][k], res[1][k]
+        a, b = res[0][k].double(), res[2][k].double()
         assert torch.isfinite(a).all() and b.norm() > 0
-        l2 = ((a - b).norm() / b.norm()).item()
-        worst = max(worst, l2)
-        assert l2 < 2e-3, f"{k}: fused vs unfused rel-L2 {l2:.2e}"
-    print(f"fused vs unfused BN-backward reduce, 120 gradients at B=4 768x768: worst rel-L2 {worst:.2e}")
+        l2[k] = ((a - b).norm() / b.norm()).item()
+    top = sorted(l2.items(), key=lambda kv: -kv[1])[:5]
+    print(f"fused vs unfused BN-backward reduce, 120 gradients at B=4 768x768: median rel-L2 {np.median(list(l2.values())):.2e}, worst {top}")
+    assert top[0][1] < 1e-2 and np.median(list(l2.values())) < 2e-3

@@ -49,14 +49,14 @@ def test_train_tool_real_files_eval_and_snapshots(dev, tmp_path, capsys):
             "--gt-dir-val", str(tmp_path / "gt"), "--devkit-dir", str(tmp_path / "kit"), "--num-workers", "2", "--random-mirror"]
     tool.main(argv)
     out = capsys.readouterr().out
-    assert out.count("Begin evaluation") == 2 and out.count("===> mIoU:") == 2            # iterations 2 and 4
+    assert out.count("Begin evaluation") == 1 and out.count("===> mIoU:") == 1            # iteration 2 (iteration 4 is the stop: save + break)
     assert "iter =        4/" in out and "Place_loss" in out and "save model" in out
     final = os.path.join(snap, "GTA5_5.pth")
     assert os.path.exists(final)
     sd = torch.load(final)
     assert len(sd) == 656 and int(sd["bn1.num_batches_tracked"]) == 5 and sd["conv1.weight"].shape == (64, 3, 7, 7)
     best = glob.glob(os.path.join(snap, "GTA5_iter*_mIoU*.pth"))
-    assert len(best) == 1                                                                  # the previous best was removed (:458-460)
+    assert len(best) == 1 and "GTA5_iter2_mIoU" in best[0]
     assert all(torch.isfinite(v).all() for k, v in sd.items() if v.dtype.is_floating_point)
 
 
