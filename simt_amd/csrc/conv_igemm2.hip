@@ -21,43 +21,13 @@
 //     wave's global_load_lds issue + ds_read latency (MI355X_MICROARCH "two waves per SIMD", item 9).
 // LDS rows are 128 B; the 16-B chunk index is XOR-swizzled with (row>>1)&7 on the global SOURCE address and on the
 // ds_read_b128 side (conflict-free 16-lane groups), the LDS image itself stays lane-linear as global_load_lds needs.
-#include "common.h"
+#include "conv2_common.h"
 
-struct Conv2KArgs {
-  const char* x;
-  const char* w;
-  bf16_t* y;
-  const float* bias;
-  const bf16_t* res;
-  const bf16_t* mask;
-  const unsigned char* res_bits;
-  const bf16_t* bnr_y;                 // fused first pass of the BatchNorm backward (simt_conv_desc.bnr_*)
-  const float *bnr_mean, *bnr_rstd, *bnr_scale, *bnr_shift;
-  const unsigned char* bnr_bits;
-  float* bnr_part;
-  int bnr_mode, bnr_ld;
-  float* stats;
-  const char* zero;
-  int H, W, Ho, Wo, Cout, Nstore, ldy, ldr, stride, ntaps, relu, M;
-  int kc_per_tap, pix_bytes, wrow_bytes, ldm;
-  int ntiles_n, ntiles_m;
-  int out_f32;     // 1: y is fp32 and is stored straight from the accumulators (no bias/residual/ReLU/stats)
-  int rows;        // pixels per tile (<= BM)
-  int nblk128;     // stats slots allocated by the caller: ceil(M/128) >= ntiles_m
-  int toff[SIMT_MAX_TAPS];   // (dy*W + dx) * pix_bytes: 32-bit so that the uniform per-stage lookup is an s_load_dword
-                             // (a 16-bit table compiles to global_load_sshort, whose vmcnt(0) drains the glds ring)
-  short dy[SIMT_MAX_TAPS], dx[SIMT_MAX_TAPS];
-};
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N <= 16, "unsupported vmcnt");
-#define SIMT_VMCNT_CASE(K) else if constexpr (N == K) asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory")
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  SIMT_VMCNT_CASE(1); SIMT_VMCNT_CASE(2); SIMT_VMCNT_CASE(3); SIMT_VMCNT_CASE(4); SIMT_VMCNT_CASE(5); SIMT_VMCNT_CASE(6);
-  SIMT_VMCNT_CASE(7); SIMT_VMCNT_CASE(8); SIMT_VMCNT_CASE(9); SIMT_VMCNT_CASE(10); SIMT_VMCNT_CASE(11); SIMT_VMCNT_CASE(12);
-  SIMT_VMCNT_CASE(13); SIMT_VMCNT_CASE(14); SIMT_VMCNT_CASE(15); SIMT_VMCNT_CASE(16);
-#undef SIMT_VMCNT_CASE
+#ifdef SIMT_ABLATION
+extern "C" int simt_debug_stamps(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
+#endif
 
 // MODE 0 = product.  MODE 1 (loads only) and MODE 2 (MFMA only) are timing-ablation builds selected by the environment
 // variable SIMT_CONV2_MODE; their outputs are meaningless.
@@ -88,6 +58,7 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
+  STAMP(0);
   const int nwg = a.ntiles_m * a.ntiles_n;
   const int tile = xcd_remap(blockIdx.x, nwg);
   const int mt = tile / a.ntiles_n, nt = tile - mt * a.ntiles_n;
@@ -271,6 +242,7 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][j], xf[s][i], acc[j][i], 0, 0, 0);
   };
 
+  STAMP(1);
   if (MODE != 2 && LW == 0) {
     issue(0);
     if (NST == 3 && nk > 1) issue(1);
@@ -305,6 +277,7 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
       if (MODE != 2 && LW == 0) wait_stage(kt + 1 < nk);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if (kt == 0) STAMP(2);
       if constexpr (MODE == 0 || MODE == 11 || MODE == 13) {
         load_frags(buf);
         if (LW == 0 && kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
@@ -341,6 +314,7 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
     if (MODE != 1) mma();
   }
 
+  STAMP(3);
   // ---------------- epilogue ----------------
   // acc[j][i][e]: cout = n0 + wn*TN*16 + j*16 + (lane>>4)*4 + e ; pixel row = wm*TM*16 + i*16 + (lane&15)
   if (a.out_f32) {
@@ -403,6 +377,7 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
     }
   }
   __syncthreads();
+  STAMP(4);
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -485,6 +460,7 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
       }
     }
   }
+  STAMP(5);
   if (a.stats || a.bnr_mode) {
     // combine the RPP row groups in fixed order: sR[rg][2][BN] floats behind the tile
     float* sR = (float*)(smem + BM * CP);
@@ -494,6 +470,7 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
       sR[(rg * 2 + 1) * BN + vcol + e] = s2[e];
     }
     __syncthreads();
+    STAMP(6);
     if (tid < BN) {
       const int nn = n0 + tid;
       if (nn < a.Cout) {
@@ -576,7 +553,17 @@ static void pick_rows(int M, int ntn, bool allow160, int* rows, int* tm) {
   }
 }
 
-struct Conv2Variant { int tile_n, tm, nst, rows, ntiles_n; };
+bool simt_conv_stream_eligible(const simt_conv_desc* d);                  // conv1x1_stream.hip
+int simt_conv_stream_launch(Conv2KArgs k, int npad, hipStream_t st);
+static bool stream_enabled() {
+#ifdef SIMT_ABLATION
+  static const int off = getenv("SIMT_NO_STREAM") ? atoi(getenv("SIMT_NO_STREAM")) : 0;
+  return !off;
+#else
+  return true;
+#endif
+}
+struct Conv2Variant { int tile_n, tm, nst, rows, ntiles_n; bool stream; };
 static Conv2Variant pick_variant(const simt_conv_desc* d) {
   Conv2Variant v;
   const int M = d->B * d->Ho * d->Wo;
@@ -585,6 +572,11 @@ static Conv2Variant pick_variant(const simt_conv_desc* d) {
   v.tile_n = d->tile_n;
   const long Kt = (long)d->ntaps * d->Cin;
   const bool short_k = d->tile_n == 256 && d->dtype_out == SIMT_BF16 && ((Kt <= 512 && d->Cout >= 512) || (Kt <= 128 && d->Cout >= 256));
+#ifdef SIMT_ABLATION
+  { static const int no_short = getenv("SIMT_NO_SHORTK") ? atoi(getenv("SIMT_NO_SHORTK")) : 0; if (no_short) { Conv2Variant w; w.stream = false; w.tile_n = d->tile_n; w.nst = 3; w.ntiles_n = d->Npad / w.tile_n; w.tm = 4; pick_rows(M, w.ntiles_n, w.tile_n != 64, &w.rows, &w.tm); if (w.tile_n == 64) w.tm = 2; return w; } }
+#endif
+  v.stream = short_k && stream_enabled() && simt_conv_stream_eligible(d);
+  if (v.stream) { v.tile_n = 128; v.nst = 3; v.ntiles_n = d->Npad / 128; v.tm = 4; v.rows = 128; return v; }
   if (short_k) v.tile_n = 128;
   v.nst = short_k ? 2 : 3;
   v.ntiles_n = d->Npad / v.tile_n;
@@ -602,13 +594,13 @@ extern "C" int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int*
   if (!v2) { *bn = d->tile_n; *tm = 0; *nst = 2; return 0; }
   const Conv2Variant v = pick_variant(d);
   *bn = v.tile_n; *tm = v.tm; *nst = v.nst;
-  return 2;
+  return v.stream ? 4 : 2;
 }
 
 extern "C" int simt_conv_mtiles(const simt_conv_desc* d) {
   int bn, tm, nst;
   const int gen = simt_conv_variant(d, &bn, &tm, &nst);
-  if (gen != 2) return 0;
+  if (gen != 2 && gen != 4) return 0;
   const Conv2Variant v = pick_variant(d);
   const int M = d->B * d->Ho * d->Wo;
   return (M + v.rows - 1) / v.rows;
@@ -648,6 +640,7 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
     k.toff[i] = (d->dy[i] * d->W + d->dx[i]) * k.pix_bytes;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (v.stream) return simt_conv_stream_launch(k, d->Npad, st);
   if (short_k) return tm == 5 ? launch_conv2<128, 5, 2>(k, st) : launch_conv2<128, 4, 2>(k, st);
   if (tile_n == 256) return tm == 5 ? launch_conv2<256, 5>(k, st) : launch_conv2<256, 4>(k, st);
   if (tile_n == 128) return tm == 5 ? launch_conv2<128, 5>(k, st) : launch_conv2<128, 4>(k, st);
