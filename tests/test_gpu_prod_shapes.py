@@ -421,24 +421,78 @@ def test_full_depth_r101_bf16_backward_blocks_b1_768(dev, monkeypatch):
     print(f"bf16 block-level backward, 33 blocks: worst cos {worst_cos:.5f}, worst rel-L2 {worst_l2:.2e}")
 
 
-def test_full_depth_bf16_backward_fused_equals_unfused_b4(dev, monkeypatch):
-    """The production backward (B=4, 768x768, bf16, two-stream schedule) with the BatchNorm-backward reduce FUSED into the dgrad
-    epilogues (default; simt_conv_desc.bnr_*) against the same backward with the separate reduce kernel: same forward, same upstream
-    gradient.  (1) The fused backward is run twice on fresh plans: all 120 gradient tensors BIT-IDENTICAL (fixed-order reductions, no
-    float atomics, stream hand-offs by events).  (2) Fused vs unfused differ in the summation order of S1 / S2 only; the ~1e-6 this
-    moves dY by flips a few bf16 roundings per stored tensor, which the following layers carry along: relative L2 < 1e-2 per tensor,
-    median < 2e-3."""
-    B = B4
+def _dcopy(ptr, n, dtype, dev):
+    """Device pointer -> fresh tensor (hipMemcpy device-to-device through torch's own runtime)."""
+    import ctypes
+    t = torch.empty(n, dtype=dtype, device=dev)
+    hip = ctypes.CDLL("libamdhip64.so")
+    rc = hip.hipMemcpy(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(n * t.element_size()), 3)
+    assert rc == 0
+    return t
+
+
+def test_full_depth_bf16_backward_fused_bn_reduce_in_situ_b4(dev, monkeypatch):
+    """The production backward (B=4, 768x768, bf16) with the BatchNorm-backward reduce FUSED into the dgrad epilogues (default;
+    simt_conv_desc.bnr_*), checked IN SITU: the backward is replayed launch by launch, and at each of the ~94 simt_bn_bwd launches
+    that consume partial sums written by a conv epilogue the same launch is repeated with its own reduce pass over the same dz / y /
+    masks: S1, S2 agree to 1e-5 of max|S| and dy to 1e-4 relative L2 (measured 1e-7 / 5e-6: summation order only).
+    A whole-network fused-vs-unfused comparison is NOT a meaningful bar: those 5e-6 flip single bf16 roundings of the stored dY
+    tensors, and 100 layers of batch-statistic BatchNorm backward amplify them to percents (measured up to 2.5e-2 relative L2 on single
+    tensors) -- the same conditioning argument as for the forward."""
+    monkeypatch.setenv("SIMT_SINGLE_STREAM", "1")
+    import simt_amd.engine as eng
+    eng._SIDE_STREAMS.clear()
+    st, tr = _bwd_setup(dev, B4, True, monkeypatch, seed=1234)
     g = torch.Generator().manual_seed(8)
-    res = []
-    ups = None
-    for fuse in (True, True, False):
-        st, tr = _bwd_setup(dev, B, fuse, monkeypatch, seed=1234)
-        n_fused = sum(1 for it in tr.bwd_list.items if it.fn is not None and it.tag.startswith("conv_igemm2") and it.keep is not None and it.keep.bnr_mode)
-        assert (n_fused > 60) == fuse, n_fused
+    h, w = tr.heads[0].h, tr.heads[0].w
+    for nm in ("x1", "x2"):
+        up = (torch.randn(B4, 22, h, w, generator=g) / (h * w)).to(BF)
+        dl = tr.dlogits[nm]
+        dl.zero_()
+        dl[:, :22] = up.permute(0, 2, 3, 1).reshape(-1, 22).to(dev)
+    lib = L.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    seen, worst_dy, worst_s = 0, 0.0, 0.0
+    for it in tr.bwd_list.items:
+        if it.fn is None:
+            continue
+        assert it.fn(*it.args, stream) == 0
+        if it.tag != "simt_bn_bwd" or it.keep.reduce_done_nblk == 0:
+            continue
+        d = it.keep
+        M, Cn, nf = d.M, d.C, d.reduce_done_nblk
+        torch.cuda.synchronize()
+        dy_f = _dcopy(d.dy, M * Cn, BF, dev)
+        s_f = _dcopy(d.part, nf * 3 * Cn, torch.float32, dev).view(nf, 3, Cn).double().sum(0)
+        d.reduce_done_nblk = 0
+        assert it.fn(*it.args, stream) == 0
+        torch.cuda.synchronize()
+        d.reduce_done_nblk = nf
+        dy_u = _dcopy(d.dy, M * Cn, BF, dev)
+        nb = lib.simt_bn_bwd_nblk(M, Cn)
+        s_u = _dcopy(d.part, nb * 3 * Cn, torch.float32, dev).view(nb, 3, Cn).double().sum(0)
+        l2 = ((dy_f.double() - dy_u.double()).norm() / dy_u.double().norm()).item()
+        es = max(((s_f[k] - s_u[k]).abs().max() / s_u[k].abs().max()).item() for k in (0, 1))
+        worst_dy, worst_s, seen = max(worst_dy, l2), max(worst_s, es), seen + 1
+        assert l2 < 1e-4 and es < 1e-5, f"bn_bwd M={M} C={Cn} mask_mode={d.mask_mode}: dy rel-L2 {l2:.2e}, S rel {es:.2e}"
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")           # continue the chain on the production (fused) result
+        hip.hipMemcpy(ctypes.c_void_p(d.dy), ctypes.c_void_p(dy_f.data_ptr()), ctypes.c_size_t(M * Cn * 2), 3)
+    print(f"fused BN-backward reduce in situ: {seen} launches, worst dy rel-L2 {worst_dy:.2e}, worst S rel {worst_s:.2e}")
+    assert seen > 60
+    eng._SIDE_STREAMS.clear()
+
+
+def test_full_depth_bf16_backward_is_bitwise_reproducible_b4(dev, monkeypatch):
+    """Two fresh plans, same inputs, the production two-stream schedule at B=4 768x768 bf16: all 120 gradient tensors BIT-IDENTICAL
+    (fixed-order reductions, no float atomics, stream hand-offs by events)."""
+    g = torch.Generator().manual_seed(8)
+    res, ups = [], None
+    for _ in range(2):
+        st, tr = _bwd_setup(dev, B4, True, monkeypatch, seed=1234)
         h, w = tr.heads[0].h, tr.heads[0].w
         if ups is None:
-            ups = [(torch.randn(B, 22, h, w, generator=g) / (h * w)).to(BF) for _ in range(2)]
+            ups = [(torch.randn(B4, 22, h, w, generator=g) / (h * w)).to(BF) for _ in range(2)]
         for nm, up in zip(("x1", "x2"), ups):
             dl = tr.dlogits[nm]
             dl.zero_()
@@ -450,11 +504,4 @@ def test_full_depth_bf16_backward_fused_equals_unfused_b4(dev, monkeypatch):
         torch.cuda.empty_cache()
     diff = [k for k in res[0] if not torch.equal(res[0][k], res[1][k])]
     assert not diff, f"{len(diff)} gradient tensors differ between two runs of the same backward: {diff[:5]}"
-    l2 = {}
-    for k in res[0]:
-        a, b = res[0][k].double(), res[2][k].double()
-        assert torch.isfinite(a).all() and b.norm() > 0
-        l2[k] = ((a - b).norm() / b.norm()).item()
-    top = sorted(l2.items(), key=lambda kv: -kv[1])[:5]
-    print(f"fused vs unfused BN-backward reduce, 120 gradients at B=4 768x768: median rel-L2 {np.median(list(l2.values())):.2e}, worst {top}")
-    assert top[0][1] < 1e-2 and np.median(list(l2.values())) < 2e-3
+    assert all(torch.isfinite(v).all() for v in res[0].values())
