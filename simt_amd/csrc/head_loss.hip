@@ -540,8 +540,11 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(HeadArgs a, int nblk
 // --------------------------------------------------------------------------------------------------------
 // pass 2: gradient w.r.t. the upsampled logits, reduced along x inside the block.  One block per (b, y) row.
 // --------------------------------------------------------------------------------------------------------
+// launch bounds: 2 waves per SIMD for every QM.  With 3 (170 VGPRs) the QM = 24 build spilled 272 B per lane to scratch -- the
+// 256 MB of HBM traffic per launch that round 1's PMC pass showed against ~30 MB algorithmic; without the spill 1 016 -> 826 us on
+// cold operands at 4 x 768 x 768 (pass 1 is the other way round: 630 us with its 104-byte spill at 3 waves, 802 us without at 2).
 template <int QM>
-__global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass2_kernel(HeadArgs a) {
+__global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
   const HeadGeom g = a.g;
   const int Q = g.Q, C = g.C, QC = Q * C, QP = a.QP;
   const int GP = Q + 1;  // LDS pitch of the per-pixel gradient rows
