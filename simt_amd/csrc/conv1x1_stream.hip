@@ -67,8 +67,9 @@ __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int
         ia_ok[q] = m < a.M;
         ia_off[q] = 0u;
         if (ia_ok[q]) {
-          const int b = m / hw, r = m - b * hw;
-          const int oy = r / a.Wo, ox = r - oy * a.Wo;
+          int b, r, oy, ox;
+          fast_divmod(m, hw, a.rcp_hw, b, r);
+          fast_divmod(r, a.Wo, a.rcp_wo, oy, ox);
           ia_off[q] = (unsigned)(((b * a.H + oy * a.stride) * a.W + ox * a.stride)) * (unsigned)a.pix_bytes + (unsigned)(a_cg * 16) + (unsigned)a.toff[0];
         }
       }

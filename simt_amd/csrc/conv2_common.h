@@ -23,6 +23,7 @@ struct Conv2KArgs {
   int out_f32;     // 1: y is fp32 and is stored straight from the accumulators (no bias/residual/ReLU/stats)
   int rows;        // pixels per tile (<= BM)
   int nblk128;     // stats slots allocated by the caller: ceil(M/128) >= ntiles_m
+  float rcp_hw, rcp_wo;   // 1 / (Ho*Wo), 1 / Wo for fast_divmod (exact below 2^24 pixels)
   int toff[SIMT_MAX_TAPS];   // (dy*W + dx) * pix_bytes: 32-bit so that the uniform per-stage lookup is an s_load_dword
                              // (a 16-bit table compiles to global_load_sshort, whose vmcnt(0) drains the glds ring)
   short dy[SIMT_MAX_TAPS], dx[SIMT_MAX_TAPS];

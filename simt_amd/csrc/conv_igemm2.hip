@@ -155,11 +155,9 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
     a_ok[i] = 0ull;
     a_off[i] = 0u;
     if (m < m_end) {
-      const int hw = a.Ho * a.Wo;
-      const int b = m / hw;
-      const int r = m - b * hw;
-      const int oy = r / a.Wo;
-      const int ox = r - oy * a.Wo;
+      int b, r, oy, ox;
+      fast_divmod(m, a.Ho * a.Wo, a.rcp_hw, b, r);
+      fast_divmod(r, a.Wo, a.rcp_wo, oy, ox);
       const int iy = oy * a.stride, ix = ox * a.stride;
       a_off[i] = (unsigned)(((b * a.H + iy) * a.W + ix)) * (unsigned)a.pix_bytes + (unsigned)(a_cg * 16);
       unsigned long long msk = 0ull;
@@ -622,6 +620,8 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
   if (k.out_f32) SIMT_CHECK(!d->bias && !d->res && !d->relu && !d->stats && d->Nstore % 4 == 0 && d->ldy % 4 == 0);
   k.H = d->H; k.W = d->W; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout; k.Nstore = d->Nstore; k.ldy = d->ldy; k.ldr = d->ldr;
   k.stride = d->stride; k.ntaps = d->ntaps; k.relu = d->relu; k.M = d->B * d->Ho * d->Wo;
+  k.rcp_hw = 1.0f / (float)(d->Ho * d->Wo); k.rcp_wo = 1.0f / (float)d->Wo;
+  SIMT_CHECK((long)d->B * d->Ho * d->Wo < (1l << 24));     // fast_divmod range
   k.kc_per_tap = d->Cin * 2 / 128;
   k.pix_bytes = d->Cin * 2;
   k.wrow_bytes = d->ntaps * d->Cin * 2;
