@@ -66,7 +66,8 @@ typedef struct {
 } simt_conv_desc;
 int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);
 /* which kernel instantiation simt_conv_fprop runs for d (profiling / reporting / tests that must hit a given instantiation):
- * returns 0 (conv_igemm_kernel, fp32 parity + narrow outputs) or 2 (conv_igemm2_kernel<bn, tm, nst>, the bf16 throughput kernel) */
+ * returns 0 (conv_igemm_kernel, fp32 parity + narrow outputs), 2 (conv_igemm2_kernel<bn, tm, nst>, the bf16 throughput kernel),
+ * 4 (conv1x1_stream_kernel) or 5 (conv1x1_rows_kernel): the short-reduction / wide-output 1x1 shapes */
 int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int* nst);
 /* number of pixel tiles (= statistics / bnr_part slots) the launch for d uses; 0 if d does not run on the bf16 v2 kernel */
 int simt_conv_mtiles(const simt_conv_desc* d);

@@ -21,6 +21,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(bf16_t, b);
 }
 
+// two floats -> one dword of two bf16 (lo = a, hi = b): ONE v_cvt_pk_bf16_f32 (the scalar casts combined with shifts cost five)
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }

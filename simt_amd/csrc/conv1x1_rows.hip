@@ -1,0 +1,439 @@
+// Row-streaming 1x1 convolution with the weights held in registers -- bf16, gfx950.
+// Shapes: the short-reduction / wide-output 1x1 convs of the Bottlenecks (model/deeplab_multi.py:62,73: conv3 256 -> 1024,
+// 128 -> 512, 64 -> 256 forward, and the dgrads of the matching conv1), dense NHWC input (stride 1), Cin in {64, 128, 256}.
+//
+// Why (measurements: DESIGN.md section 5, scratch/ldsbench.hip): these GEMMs have K <= 256, so a 128x128 output tile needs 128 KB of
+// operands for 32 KB of output.  A CU fills LDS from L2 at ~75 GB/s, which is what bounded conv1x1_stream_kernel (302 MB through
+// L1 per launch of 256 -> 1024), half of it the SAME weight tile re-read for every pixel tile; and its three barrier hand-shakes per
+// tile coupled the store waves' HBM write latency to the MFMA waves.  Here:
+//   * a workgroup owns 256 output channels; each of its 8 compute waves keeps its 32 x Cin weight slice as MFMA A-operand fragments
+//     in REGISTERS for the whole launch (Cin/32 x 2 x 4 VGPRs) -- weights never touch LDS;
+//   * pixels stream through a D-slot global_load_lds ring in stages of RS whole rows (RS * Cin * 2 bytes, up to D-1 stages in
+//     flight, counted vmcnt); a stage is a COMPLETE reduction, so its RS x 256 outputs leave the accumulators at once;
+//   * they go (bf16) to one of two LDS slabs; 4 store waves stream slab g-1 out (statistics, bias, residual, ReLU, fused
+//     BatchNorm-backward reduce) while the compute waves work on stage g: ONE barrier per stage, no hand-over section;
+//   * persistent workgroups on 128-row tiles (the statistics granule), XCD-aware: the workgroups of one XCD share pixel rows.
+// L2 -> LDS traffic per launch of 256 -> 1024: 4 x 19 MB instead of 302 MB.
+#include "conv2_common.h"
+
+// Compile-time timing ablations (scratch builds only; outputs meaningless): 1 = no fragment reads / MFMA, 2 = no global stores,
+// 4 = no LDS-DMA loads, 8 = store waves idle (barriers only)
+#ifndef SIMT_ROWS_ABL
+#define SIMT_ROWS_ABL 0
+#endif
+
+namespace {
+
+constexpr int NCW = 8, NSW = 4;                      // compute waves, store waves
+constexpr int NC = NCW * 64, NS = NSW * 64, NT = NC + NS;
+constexpr int BN = 256, TN = 2;                      // output channels per workgroup; 16-channel blocks per compute wave
+constexpr int CP = BN * 2 + 16;                      // slab pitch (bytes): 132 dwords, conflict-free for the accumulator writes
+constexpr int VPR = BN / 8;                          // 16-byte pieces per output row
+constexpr int RGS = NS / VPR;                        // row groups of the store waves (8)
+constexpr int SR_BYTES = NSW * 2 * BN * 4;
+
+template <int KS, int TM, int D> struct Geo {
+  static constexpr int RS = TM * 16;                 // pixel rows per stage
+  static constexpr int CIN = KS * 32;
+  static constexpr int KC = CIN / 64;                // 64-deep (128-byte) sub-tiles per stage
+  static constexpr int SB = RS * CIN * 2;            // stage bytes
+  static constexpr int PT = SB / 16 / NC;            // LDS-DMA pieces per compute thread per stage
+  static constexpr int SPT = 128 / RS;               // stages per 128-row tile
+  static constexpr int SLAB = RS * CP;
+  static constexpr int PASSES = RS / RGS;            // rows per store thread per slab
+  static constexpr int LDS = D * SB + 2 * SLAB + SR_BYTES;
+  static_assert(CIN % 64 == 0 && SB % (16 * NC) == 0 && PT >= 1 && 128 % RS == 0 && LDS <= 160 * 1024, "geometry");
+};
+
+// v[l] + v[l ^ 32]
+__device__ __forceinline__ float half_swap_sum(float v) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u2;
+  const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
+__device__ __forceinline__ void unpack8(const uint4& q, float* v) {
+  v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
+  v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+  v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xffff0000u);
+  v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xffff0000u);
+}
+
+struct Aux { uint4 res, by; unsigned rbits, ybits; };
+
+template <int KS, int TM, int D, bool AUX>
+__global__ __launch_bounds__(NT) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
+  using g = Geo<KS, TM, D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* slab = smem + D * g::SB;
+  float* sR = (float*)(smem + D * g::SB + 2 * g::SLAB);        // [store waves][2][BN]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = a.ntiles_m * a.ntiles_n;
+  const int my_n = (nwg - (int)blockIdx.x + G - 1) / G;        // 128-row tiles of this workgroup: blockIdx.x + i * G
+  const int tile0 = xcd_remap(blockIdx.x, nwg);
+  const int tstep = G >> 3;                                    // xcd_remap(b + i * G) = tile0 + i * G / 8
+  const int nt = tile0 % a.ntiles_n;                           // fixed per workgroup (host: ntiles_n divides G / 8)
+  const int n0 = nt * BN;
+  const int S_total = my_n * g::SPT;
+  const int mt0 = tile0 / a.ntiles_n, mt_step = tstep / a.ntiles_n;   // tile i of this workgroup covers rows (mt0 + i * mt_step) * 128 ...
+
+  if (wave < NCW) {
+    // ========================= compute waves: weights in registers, pixel stages by LDS-DMA, MFMA, accumulators -> slab =========================
+    bf16x8 wf[TN][KS];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        wf[j][ks] = *(const bf16x8*)(a.w + (size_t)(n0 + wave * 32 + j * 16 + (lane & 15)) * (unsigned)a.wrow_bytes + (ks * 32 + (lane >> 4) * 8) * 2);
+    // LDS-DMA pieces of this thread: linear LDS position p = q * NC + tid -> sub-tile kc = p / (RS * 8), row = (p / 8) % RS, chunk = p % 8
+    unsigned pconst[g::PT], pmax[g::PT];                       // byte offset of the piece inside a stage / clamp for rows past the end
+#pragma unroll
+    for (int q = 0; q < g::PT; ++q) {
+      const int p = q * NC + tid;
+      const int row = (p >> 3) % g::RS, kc = p / (g::RS * 8), c = p & 7;
+      const unsigned ko = (unsigned)(kc * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      pconst[q] = (unsigned)row * (unsigned)a.pix_bytes + ko;
+      pmax[q] = (unsigned)(a.M - 1) * (unsigned)a.pix_bytes + ko;      // rows past the end: recomputed from the last row, never stored
+    }
+    int ii = 0, is = 0;                                        // issue cursor: tile index of this workgroup, stage inside the tile
+    unsigned ibase = (unsigned)(mt0 * 128) * (unsigned)a.pix_bytes;    // uniform: first row of the stage to issue, in bytes
+    const unsigned stage_step = (unsigned)g::RS * (unsigned)a.pix_bytes, tile_step = (unsigned)(mt_step * 128) * (unsigned)a.pix_bytes;
+    unsigned tile_base = ibase;
+    auto issue = [&](int slot) {
+      char* sb = smem + slot * g::SB;
+#pragma unroll
+      for (int q = 0; q < g::PT; ++q) {
+        unsigned off = ibase + pconst[q];
+        off = off < pmax[q] ? off : pmax[q];
+        if (!(SIMT_ROWS_ABL & 4)) __builtin_amdgcn_global_load_lds(GPTR(a.x + off), LPTR(sb + (q * NC + wave * 64) * 16), 16, 0, 0);
+      }
+      ibase += stage_step;
+      if (++is == g::SPT) { is = 0; ++ii; tile_base += tile_step; ibase = tile_base; }
+    };
+    const int sw = (lane >> 1) & 7, kq = lane >> 4;
+    const int xrow = (lane & 15) * 128;
+    // accumulator -> slab addresses (LDS byte addresses): pixel i * 16 + (lane & 15), channels wave * 32 + j * 16 + (lane >> 4) * 4
+    const unsigned sl_addr = (unsigned)(size_t)LPTR(slab + (lane & 15) * CP + (wave * 32 + (lane >> 4) * 4) * 2);
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) if (s < S_total) issue(s);
+    int slot_c = 0, slot_i = D - 1;
+#ifdef SIMT_ABLATION
+    unsigned long long t_wait = 0, t_bar = 0, t_work = 0;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
+    for (int gi = 0; gi < S_total; ++gi) {
+#ifdef SIMT_ABLATION
+      const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
+      if (gi + D - 2 < S_total) wait_vmcnt<g::PT * (D - 2)>(); else wait_vmcnt<0>();     // stage gi landed (this wave's pieces)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  // this wave's slab writes of stage gi - 1
+#ifdef SIMT_ABLATION
+      const unsigned long long tw1 = __builtin_amdgcn_s_memtime();
+#endif
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#ifdef SIMT_ABLATION
+      const unsigned long long tw2 = __builtin_amdgcn_s_memtime();
+      t_wait += tw1 - tw0; t_bar += tw2 - tw1;
+#endif
+      if (gi + D - 1 < S_total) issue(slot_i);                 // into the slot every wave finished reading in stage gi - 1
+      if (++slot_i == D) slot_i = 0;
+      const char* st = smem + slot_c * g::SB + xrow;
+      if (++slot_c == D) slot_c = 0;
+      f32x4 acc[TN][TM];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks (the LDS round trip hides behind 4 MFMAs)
+      constexpr int KSN = (SIMT_ROWS_ABL & 1) ? 0 : KS;
+      bf16x8 xf[2][TM];
+      auto frags = [&](int ks, bf16x8* f) {
+        const int coff = ((4 * (ks & 1) + kq) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f[i] = *(const bf16x8*)(st + (ks >> 1) * (g::RS * 128) + i * 16 * 128 + coff);
+      };
+      if (KSN > 0) frags(0, xf[0]);
+#pragma unroll
+      for (int ks = 0; ks < KSN; ++ks) {
+        if (ks + 1 < KSN) frags(ks + 1, xf[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);                     // keep this order: the scheduler otherwise sinks the reads to their use
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], xf[ks & 1][i], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // written by inline asm: before a C++ LDS store the compiler drains vmcnt to 0 (it must assume the store aliases an LDS-DMA in flight)
+      const unsigned sbase = sl_addr + (unsigned)((gi & 1) * g::SLAB);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          uint2 pk;
+          pk.x = pack_bf16x2(acc[j][i][0], acc[j][i][1]);
+          pk.y = pack_bf16x2(acc[j][i][2], acc[j][i][3]);
+          asm volatile("ds_write_b64 %0, %1" :: "v"(sbase + (unsigned)(i * 16 * CP + j * 32)), "v"(pk) : "memory");
+        }
+#ifdef SIMT_ABLATION
+      asm volatile("s_nop 0" ::: "memory");
+      t_work += __builtin_amdgcn_s_memtime() - tw2;
+#endif
+    }
+#ifdef SIMT_ABLATION
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+      unsigned long long* o = g_stamps + blockIdx.x * 8;
+      o[0] = t_wait; o[1] = t_bar; o[2] = t_work; o[3] = __builtin_amdgcn_s_memtime() - t_begin; o[4] = (unsigned long long)S_total;
+    }
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // the last slab is visible to the store waves
+    __builtin_amdgcn_s_barrier();                              // ... and the last tile's statistics sit in sR
+    return;
+  }
+
+  // ================================ store waves: slab g - 1 -> epilogue -> HBM while stage g is computed ================================
+#ifndef SIMT_ROWS_PRIO
+#define SIMT_ROWS_PRIO 0
+#endif
+  if (SIMT_ROWS_PRIO) __builtin_amdgcn_s_setprio(SIMT_ROWS_PRIO);
+  const int st = tid - NC;
+  const int swv = wave - NCW;
+  const int vcol = (st % VPR) * 8, rg = st / VPR;
+  const int n = n0 + vcol;
+  const bool ncol_ok = n < a.Nstore;
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = (a.bias && ncol_ok && (n + e) < a.Cout) ? a.bias[n + e] : 0.f;
+  float bmu[8], brs[8];                                        // fused BN-backward reduce (bit-mask flavour): constants of the BatchNorm whose dz this is
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { bmu[e] = 0.f; brs[e] = 0.f; }
+  if (AUX && a.bnr_mode && ncol_ok) {
+    load8(a.bnr_mean + n, bmu);
+    load8(a.bnr_rstd + n, brs);
+  }
+  // Pin the waits of these loads HERE: left to the compiler, its s_waitcnt vmcnt(0) lands at the head of the slab loop, where it would
+  // also wait for every output store of the previous slab to be acknowledged by HBM.
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { asm volatile("" : "+v"(bias8[e])); if (AUX) { asm volatile("" : "+v"(bmu[e]), "+v"(brs[e])); } }
+  const bool plain = !a.bias && !a.res && !a.relu;
+  const bool want_sums = a.stats || (AUX && a.bnr_mode);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+
+  // operands the epilogue reads from global memory: requested one slab ahead (pass p of the next slab replaces pass p of this one).
+  // All addressing is 32-bit byte offsets from uniform bases (host: every operand < 4 GB).
+  const char* yb = (const char*)a.y;
+  const char* resb = (const char*)a.res;
+  const char* byb = (const char*)a.bnr_y;
+  const unsigned y_pitch = (unsigned)a.ldy * 2u, r_pitch = (unsigned)a.ldr * 2u, b_pitch = (unsigned)a.bnr_ld * 2u;
+  const unsigned y_c = (unsigned)rg * y_pitch + (unsigned)n * 2u;             // thread constants: row group and column of this thread
+  const unsigned r_c = (unsigned)rg * r_pitch + (unsigned)n * 2u;
+  const unsigned b_c = (unsigned)rg * b_pitch + (unsigned)n * 2u;
+  const bool all_cols = n0 + BN <= a.Nstore;                   // uniform
+  Aux q[g::PASSES];
+  auto aux_load = [&](Aux& d, int slab_row0, int p, bool guard) {
+    d.res = d.by = make_uint4(0u, 0u, 0u, 0u);
+    d.rbits = d.ybits = 0xffu;
+    if (!AUX) return;
+    if (guard && !(ncol_ok && slab_row0 + rg + p * RGS < a.M)) return;
+    if (a.res) {
+      const unsigned o = (unsigned)(slab_row0 + p * RGS) * r_pitch + r_c;
+      d.res = *(const uint4*)(resb + o);
+      if (a.res_bits) d.rbits = a.res_bits[o >> 4];
+    }
+    if (a.bnr_mode) {
+      const unsigned o = (unsigned)(slab_row0 + p * RGS) * b_pitch + b_c;
+      d.by = *(const uint4*)(byb + o);
+      d.ybits = a.bnr_bits[o >> 4];
+    }
+  };
+  int ci = 0, is = 0;                                          // slab cursor: tile of this workgroup, stage inside the tile
+  int cur_mt = mt0;
+  int row0 = cur_mt * 128;                                     // first pixel row of the slab being processed
+  auto next_row0 = [&](int& mt_next) {                        // first row of the slab after the cursor
+    if (is + 1 < g::SPT) { mt_next = cur_mt; return row0 + g::RS; }
+    mt_next = mt0 + (ci + 1) * mt_step;
+    return mt_next * 128;
+  };
+  if (AUX && S_total > 0) {
+#pragma unroll
+    for (int p = 0; p < g::PASSES; ++p) aux_load(q[p], row0, p, true);
+  }
+  bool stats_pending = false;
+  int pend_mt = 0;
+  auto sums_out = [&](int mt) {                                // the store waves' partial sums in fixed order -> HBM
+    const int nn = n0 + st;                                    // NS == BN: one column per store thread
+    if (nn < a.Cout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NSW; ++w) { t1 += sR[(w * 2 + 0) * BN + st]; t2 += sR[(w * 2 + 1) * BN + st]; }
+      if (AUX && a.bnr_mode) {                                 // [m-tile][3][Cout]: S1, S2 and the (unused) second-BN row
+        a.bnr_part[((long)mt * 3 + 0) * a.Cout + nn] = t1;
+        a.bnr_part[((long)mt * 3 + 1) * a.Cout + nn] = t2;
+        a.bnr_part[((long)mt * 3 + 2) * a.Cout + nn] = 0.f;
+      } else {
+        a.stats[((long)mt * 2 + 0) * a.Cout + nn] = t1;
+        a.stats[((long)mt * 2 + 1) * a.Cout + nn] = t2;
+      }
+    }
+  };
+  static_assert(NS == BN, "sums_out maps one column to one store thread");
+
+#ifdef SIMT_ABLATION
+  unsigned long long ts_bar = 0, ts_work = 0, ts_prev = 0, ts_lds = 0;
+#endif
+  for (int gi = 0; gi <= S_total; ++gi) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // slab reads / sR writes of the previous iteration
+#ifdef SIMT_ABLATION
+    const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+#endif
+    __builtin_amdgcn_s_barrier();
+#ifdef SIMT_ABLATION
+    const unsigned long long tb1 = __builtin_amdgcn_s_memtime();
+    ts_bar += tb1 - tb0;
+    if (gi > 0) ts_work += tb0 - ts_prev;
+#endif                              // barrier gi: slab gi - 1 is complete; slab gi - 2 may be overwritten
+    if (stats_pending) { sums_out(pend_mt); stats_pending = false; }
+#ifdef SIMT_ABLATION
+    ts_prev = tb1;
+#endif
+    if (gi == 0 || (SIMT_ROWS_ABL & 8)) continue;
+    const char* sl = slab + ((gi - 1) & 1) * g::SLAB;
+    int mt_next;
+    const int nrow0 = next_row0(mt_next);
+    const bool more = gi < S_total;
+    // all slab rows of this thread first (one LDS round trip per slab), then one 16-byte store per row from a single store site (with
+    // several, the compiler sinks them into a shared tail of a 4-byte and a 12-byte store)
+    uint4 ov[g::PASSES];                                       // (the aux flavours have no registers left for this: they read per pass)
+#pragma unroll
+    for (int p = 0; p < g::PASSES; ++p) if (!AUX) ov[p] = *(const uint4*)(sl + (rg + p * RGS) * CP + vcol * 2);
+#ifdef SIMT_ABLATION
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ts_lds += __builtin_amdgcn_s_memtime() - tb1;
+#endif
+    // full slabs of full-width tiles take the branch-free path (uniform test); only the last tile / a narrow last column tile is guarded
+    const bool guard_cur = !(all_cols && row0 + g::RS <= a.M);
+    auto pass = [&](int p, bool guard) {
+      const Aux cur = q[p];
+      if (AUX && more) aux_load(q[p], nrow0, p, true);
+      if (guard && !(ncol_ok && row0 + rg + p * RGS < a.M)) return;
+      uint4 o = AUX ? *(const uint4*)(sl + (rg + p * RGS) * CP + vcol * 2) : ov[p];
+      if (!plain || want_sums) {
+        float v[8];
+        unpack8(o, v);
+        if (a.stats) {                                         // forward: statistics of the stored value, before bias / residual / ReLU
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+        }
+        if (!plain) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+          if (AUX && a.res) {
+            float rv[8];
+            unpack8(cur.res, rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += ((cur.rbits >> e) & 1u) ? rv[e] : 0.f;
+          }
+          if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+        }
+        if (AUX && a.bnr_mode) {
+          // backward: S1 = sum g, S2 = sum g * xhat on the value as stored (bf16), masked like the backward masks it
+          if (!plain) unpack8(o, v);
+          float yv[8];
+          unpack8(cur.by, yv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = ((cur.ybits >> e) & 1u) ? v[e] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * ((yv[e] - bmu[e]) * brs[e]); }
+        }
+      }
+      const unsigned yo = (unsigned)(row0 + p * RGS) * y_pitch + y_c;
+      if (!(SIMT_ROWS_ABL & 2) || o.x == 0x12345678u) *(uint4*)(const_cast<char*>(yb) + yo) = o;
+    };
+    if (AUX || guard_cur) {                                    // (one copy of the pass code in the aux flavours: registers)
+#pragma unroll
+      for (int p = 0; p < g::PASSES; ++p) pass(p, true);
+    } else {
+#pragma unroll
+      for (int p = 0; p < g::PASSES; ++p) pass(p, false);
+    }
+    // end of a 128-row tile: the two row groups of a wave by a lane swap, the store waves through sR (read behind the next barrier)
+    if (is + 1 == g::SPT) {
+      if (want_sums) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t1 = half_swap_sum(s1[e]), t2 = half_swap_sum(s2[e]);
+          if (lane < 32) { sR[(swv * 2 + 0) * BN + vcol + e] = t1; sR[(swv * 2 + 1) * BN + vcol + e] = t2; }
+          s1[e] = 0.f; s2[e] = 0.f;
+        }
+        stats_pending = true; pend_mt = cur_mt;
+      }
+      is = 0; ++ci;
+    } else {
+      ++is;
+    }
+    row0 = nrow0; cur_mt = mt_next;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (stats_pending) sums_out(pend_mt);
+#ifdef SIMT_ABLATION
+  if (threadIdx.x == NC && blockIdx.x < 8192) { g_stamps[blockIdx.x * 8 + 5] = ts_bar; g_stamps[blockIdx.x * 8 + 6] = ts_work; g_stamps[blockIdx.x * 8 + 7] = ts_lds; }
+#endif
+}
+
+template <int KS, int TM, int D, bool AUX>
+int launch_rows(const Conv2KArgs& k, int G, hipStream_t st) {
+  using g = Geo<KS, TM, D>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv1x1_rows_kernel<KS, TM, D, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, g::LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv1x1_rows_kernel<KS, TM, D, AUX>), dim3(G), dim3(NT), g::LDS, st, k, G);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+}  // namespace
+
+#ifdef SIMT_ABLATION
+extern "C" int simt_debug_stamps_rows(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
+
+// Shapes this kernel takes over from conv_igemm2_kernel<128, *, 2> / conv1x1_stream_kernel (simt_conv_fprop_bf16_v2 fills the arguments).
+bool simt_conv_rows_eligible(const simt_conv_desc* d) {
+  if (d->dtype_in != SIMT_BF16 || d->dtype_out != SIMT_BF16 || d->ntaps != 1 || d->dy[0] != 0 || d->dx[0] != 0) return false;
+  if (d->stride != 1 || d->H != d->Ho || d->W != d->Wo) return false;          // dense pixel rows
+  if (d->mask || (d->bnr_mode != 0 && d->bnr_mode != 3)) return false;         // fused BN-backward reduce: bit-mask flavour only
+  if (d->Cin != 64 && d->Cin != 128 && d->Cin != 256) return false;
+  if (d->Cin != 256 && (d->res || d->bnr_mode)) return false;                  // the 64-row-stage variants spill with the aux operands
+  if (d->Npad % BN != 0) return false;
+  const long M = (long)d->B * d->Ho * d->Wo, lim = 1l << 32;                   // 32-bit byte offsets in the store waves
+  if (M * d->ldy * 2 >= lim || (d->res && M * d->ldr * 2 >= lim) || (d->bnr_mode && M * d->bnr_ld * 2 >= lim)) return false;
+  if (d->ldy % 8 != 0 || (d->res && d->ldr % 8 != 0)) return false;
+  const int ntn = d->Npad / BN;
+  return ntn == 1 || ntn == 2 || ntn == 4 || ntn == 8 || ntn == 16 || ntn == 32;      // ntiles_n | 256 / 8
+}
+
+int simt_conv_rows_launch(Conv2KArgs k, int npad, hipStream_t st) {
+  k.rows = 128;
+  k.ntiles_n = npad / BN;
+  k.ntiles_m = (k.M + 127) / 128;
+  const int nwg = k.ntiles_m * k.ntiles_n;
+  const int G = nwg < 256 ? nwg : 256;
+  const bool aux = k.res || k.bnr_mode;
+  const int cin = k.pix_bytes / 2;
+  if (cin == 256) return aux ? launch_rows<8, 2, 6, true>(k, G, st) : launch_rows<8, 2, 6, false>(k, G, st);
+  if (cin == 128) return launch_rows<4, 4, 4, false>(k, G, st);
+  return launch_rows<2, 4, 6, false>(k, G, st);
+}

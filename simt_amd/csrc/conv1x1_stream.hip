@@ -19,6 +19,12 @@
 // waves in fixed order), + bias / ReLU.  Residual / bit-mask / fused BN-backward flavours stay on conv_igemm2_kernel.
 #include "conv2_common.h"
 
+// Compile-time timing ablations (scratch builds only; outputs meaningless): 1 = no fragment reads / MFMA, 2 = no global stores,
+// 4 = no LDS-DMA loads, 8 = store waves idle (barriers only), 16 = no statistics, 32 = no accumulator -> LDS writes, 64 = no LDS reads in row passes
+#ifndef SIMT_STREAM_ABL
+#define SIMT_STREAM_ABL 0
+#endif
+
 namespace {
 
 constexpr int NC = 512, NS = 512, NT = NC + NS;      // 8 compute waves (LDS-DMA loads + MFMA) + 8 store waves (deferred epilogue)
@@ -30,6 +36,15 @@ constexpr int VPR = BN / 8, RPP = NS / VPR, NIT = BM / RPP;                // 16
 constexpr int NSW = NS / 64;                                               // store waves
 constexpr int RING = NST * STAGE, SC_BYTES = BM * CP, SR_BYTES = NSW * 2 * BN * 4;
 constexpr int LDS_BYTES = RING + SC_BYTES + SR_BYTES;
+
+// v[l] + v[l^16] + v[l^32] + v[l^48] in the order ((l, l^16), (l^32, l^48)) for the lanes of the first row
+__device__ __forceinline__ float quad_rows_sum(float v) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u2;
+  u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float s = __uint_as_float(r.x) + __uint_as_float(r.y);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
 
 __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int G) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -78,6 +93,7 @@ __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int
     tile_addr(0);
     auto issue = [&](int slot) {
       char* sbase = smem + slot * STAGE;
+#if !(SIMT_STREAM_ABL & 4)
 #pragma unroll
       for (int q = 0; q < A_IT; ++q) {
         const char* src = ia_ok[q] ? a.x + (unsigned)(ia_off[q] + (unsigned)(ikc * 128)) : zsrc;
@@ -86,6 +102,7 @@ __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int
 #pragma unroll
       for (int q = 0; q < B_IT; ++q)
         __builtin_amdgcn_global_load_lds(GPTR(a.w + (b_off[q] + (unsigned)(ikc * 128))), LPTR(sbase + A_BYTES + (q * NC + wave * 64) * 16), 16, 0, 0);
+#endif
       if (++ikc == nk) {
         ikc = 0;
         if (++ii < my_n) tile_addr(ii);
@@ -143,9 +160,13 @@ __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int
         t_wait += tw1 - tw0; t_bar += tw2 - tw1;
 #endif
         const int slot = g % NST;
+#if !(SIMT_STREAM_ABL & 1)
         load_frags(slot);
+#endif
         if (g + 2 < S_total) issue((g + 2) % NST);
+#if !(SIMT_STREAM_ABL & 1)
         mma();
+#endif
 #ifdef SIMT_ABLATION
         asm volatile("s_nop 0" ::: "memory");
         t_work += __builtin_amdgcn_s_memtime() - tw2;
@@ -156,6 +177,7 @@ __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int
 #endif
       // hand-over: barrier A (the store waves are done with the previous tile in sC), accumulators -> sC, barrier B (sC visible)
       __builtin_amdgcn_s_barrier();
+#if !(SIMT_STREAM_ABL & 32)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -165,8 +187,12 @@ __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int
           uint2 pk;
           pk.x = (uint32_t)f2bf(acc[j][i][0]) | ((uint32_t)f2bf(acc[j][i][1]) << 16);
           pk.y = (uint32_t)f2bf(acc[j][i][2]) | ((uint32_t)f2bf(acc[j][i][3]) << 16);
-          *(uint2*)(sC + r * CP + c * 2) = pk;
+          // written by inline asm: for a C++ LDS store the compiler first drains vmcnt to 0 (it assumes the store may alias an LDS-DMA
+          // in flight), i.e. it would wait here for the next tile's first two stages
+          const unsigned addr = (unsigned)(size_t)LPTR(sC + r * CP + c * 2);
+          asm volatile("ds_write_b64 %0, %1" :: "v"(addr), "v"(pk) : "memory");
         }
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #ifdef SIMT_ABLATION
@@ -177,7 +203,8 @@ __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int
 #ifdef SIMT_ABLATION
     if (threadIdx.x == 0 && blockIdx.x < 8192) { g_stamps[blockIdx.x * 8 + 4] = t_wait; g_stamps[blockIdx.x * 8 + 6] = t_bar; g_stamps[blockIdx.x * 8 + 7] = (unsigned long long)my_n; g_stamps[blockIdx.x * 8 + 0] = t_work; g_stamps[blockIdx.x * 8 + 2] = t_hand; }
 #endif
-    // drain: the store waves finish the last tile behind two more barriers (its statistics go through sR)
+    // drain: the store waves finish the last tile behind three more barriers (A, B, and C for its statistics in sR)
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
     return;
@@ -191,7 +218,14 @@ __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int
   float bias8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = (a.bias && ncol_ok && (n + e) < a.Cout) ? a.bias[n + e] : 0.f;
+  // Pin the bias loads' wait HERE: left to the compiler, its s_waitcnt vmcnt(0) for them lands at the head of the per-tile loop, where
+  // it also waits for every output store of the previous tile to be acknowledged by HBM (2-3 us per tile: 22 of the 57 us of a launch).
+#pragma unroll
+  for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bias8[e]));
   const bool plain = !a.bias && !a.relu;
+#if SIMT_STREAM_ABL & 16
+  a.stats = nullptr;
+#endif
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -202,7 +236,7 @@ __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int
   uint2 nlo = make_uint2(0u, 0u), nhi = make_uint2(0u, 0u);
   auto fetch_row = [&](int pass) {
     const int r = rg + pass * RPP;
-    if (pass < NIT && ncol_ok && prev_m0 + r < a.M) {
+    if (!(SIMT_STREAM_ABL & 64) && pass < NIT && ncol_ok && prev_m0 + r < a.M) {
       nlo = *(const uint2*)(sC + r * CP + vcol * 2);
       nhi = *(const uint2*)(sC + r * CP + vcol * 2 + 8);
     }
@@ -220,7 +254,7 @@ __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int
         v[2] = __uint_as_float(o.y << 16); v[3] = __uint_as_float(o.y & 0xffff0000u);
         v[4] = __uint_as_float(o.z << 16); v[5] = __uint_as_float(o.z & 0xffff0000u);
         v[6] = __uint_as_float(o.w << 16); v[7] = __uint_as_float(o.w & 0xffff0000u);
-        if (a.stats) {
+        if (!(SIMT_STREAM_ABL & 512) && a.stats) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
         }
@@ -231,23 +265,27 @@ __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int
           o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
         }
       }
+#if !(SIMT_STREAM_ABL & 2)
       *(uint4*)(a.y + (long)m * a.ldy + n) = o;
+#else
+      if (o.x == 0x12345678u && o.y == 0x9abcdef0u) *(uint4*)(a.y + (long)m * a.ldy + n) = o;
+#endif
     }
   };
-  // statistics of the previous tile: the 4 row groups of a wave by shuffles, then the store waves in fixed order through sR
+  // statistics of the previous tile: the 4 row groups of a wave by lane swaps, then the store waves in fixed order through sR
   auto stats_to_lds = [&]() {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float t1 = s1[e], t2 = s2[e];
-      t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
-      t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
-      if (lane < 16) { sR[(swv * 2 + 0) * BN + vcol + e] = t1; sR[(swv * 2 + 1) * BN + vcol + e] = t2; }
+      // lanes l, l^16, l^32, l^48 hold the four row groups of a column: v_permlane16_swap / v_permlane32_swap (VALU; a
+      // ds_bpermute shuffle here cost 13 us per launch: 256 LDS-crossbar instructions per tile inside the hand-over)
+      const float t1 = quad_rows_sum(s1[e]), t2 = quad_rows_sum(s2[e]);
+      if (!(SIMT_STREAM_ABL & 256) && lane < 16) { sR[(swv * 2 + 0) * BN + vcol + e] = t1; sR[(swv * 2 + 1) * BN + vcol + e] = t2; }
       s1[e] = 0.f; s2[e] = 0.f;
     }
   };
   auto stats_to_hbm = [&](int mt) {
     const int nn = n0 + st;
-    if (st < BN && nn < a.Cout) {
+    if (!(SIMT_STREAM_ABL & 128) && st < BN && nn < a.Cout) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int q = 0; q < NSW; ++q) { t1 += sR[(q * 2 + 0) * BN + st]; t2 += sR[(q * 2 + 1) * BN + st]; }
@@ -256,37 +294,40 @@ __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int
     }
   };
   const int passes_per_stage = (NIT + nk - 1) / nk;
-#ifdef SIMT_ABLATION
-  unsigned long long t_rows = 0;
-#endif
+  bool stats_pending = false;                          // sR holds the statistics of tile prev_stats_mt, visible after the next barrier
+  int prev_stats_mt = 0;
   for (int ci = 0; ci <= my_n; ++ci) {                 // iteration my_n is the drain of the last tile
     if (ci < my_n) {
       for (int kc = 0; kc < nk; ++kc) {
-#ifdef SIMT_ABLATION
-        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
-#endif
+#if !(SIMT_STREAM_ABL & 8)
         if (has_prev)
           for (int q = 0; q < passes_per_stage && rows_done < NIT; ++q) row_pass();
-#ifdef SIMT_ABLATION
-        t_rows += __builtin_amdgcn_s_memtime() - ts0;
 #endif
+        if (stats_pending) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                  // the compute waves' stage barrier
+        if (stats_pending) { stats_to_hbm(prev_stats_mt); stats_pending = false; }
       }
     }
+#if !(SIMT_STREAM_ABL & 8)
     if (has_prev)
       while (rows_done < NIT) row_pass();
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // barrier A: sC may be overwritten
-    if (has_prev && a.stats) stats_to_lds();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                      // barrier B: sC holds tile ci, sR the statistics of tile ci - 1
-    if (has_prev && a.stats) stats_to_hbm(prev_mt);
+    if (stats_pending) { stats_to_hbm(prev_stats_mt); stats_pending = false; }      // drain iteration only (no stage barrier came by)
+    __builtin_amdgcn_s_barrier();                      // barrier B: sC holds tile ci
+    // the statistics of tile ci - 1 leave the registers AFTER the hand-over (the compute waves are not held up by it); sR is read
+    // behind the next barrier (the first stage barrier of tile ci + 1, or the drain barrier)
+    if (has_prev && a.stats) { stats_to_lds(); stats_pending = true; prev_stats_mt = prev_mt; }
     if (ci < my_n) {
       const int cur_mt = (tile0 + ci * tstep) / a.ntiles_n;
       has_prev = true; prev_m0 = cur_mt * BM; prev_mt = cur_mt; rows_done = 0;
       fetch_row(0);
     }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                        // drain barrier C
+  if (stats_pending) stats_to_hbm(prev_stats_mt);
 #ifdef SIMT_ABLATION
   if (threadIdx.x == NC && blockIdx.x < 8192) { g_stamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memtime(); }
 #endif

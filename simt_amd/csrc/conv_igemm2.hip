@@ -22,6 +22,7 @@
 // LDS rows are 128 B; the 16-B chunk index is XOR-swizzled with (row>>1)&7 on the global SOURCE address and on the
 // ds_read_b128 side (conflict-free 16-lane groups), the LDS image itself stays lane-linear as global_load_lds needs.
 #include "conv2_common.h"
+#include <stdlib.h>
 
 #ifdef SIMT_ABLATION
 extern "C" int simt_debug_stamps(unsigned long long* out, int n) {
@@ -553,6 +554,12 @@ static void pick_rows(int M, int ntn, bool allow160, int* rows, int* tm) {
 
 bool simt_conv_stream_eligible(const simt_conv_desc* d);                  // conv1x1_stream.hip
 int simt_conv_stream_launch(Conv2KArgs k, int npad, hipStream_t st);
+bool simt_conv_rows_eligible(const simt_conv_desc* d);                    // conv1x1_rows.hip
+int simt_conv_rows_launch(Conv2KArgs k, int npad, hipStream_t st);
+static bool rows_enabled() {
+  static const int off = getenv("SIMT_NO_ROWS") ? atoi(getenv("SIMT_NO_ROWS")) : 0;     // A/B switch
+  return !off;
+}
 static bool stream_enabled() {
 #ifdef SIMT_ABLATION
   static const int off = getenv("SIMT_NO_STREAM") ? atoi(getenv("SIMT_NO_STREAM")) : 0;
@@ -561,7 +568,7 @@ static bool stream_enabled() {
   return true;
 #endif
 }
-struct Conv2Variant { int tile_n, tm, nst, rows, ntiles_n; bool stream; };
+struct Conv2Variant { int tile_n, tm, nst, rows, ntiles_n; bool stream, rowsk; };
 static Conv2Variant pick_variant(const simt_conv_desc* d) {
   Conv2Variant v;
   const int M = d->B * d->Ho * d->Wo;
@@ -571,8 +578,10 @@ static Conv2Variant pick_variant(const simt_conv_desc* d) {
   const long Kt = (long)d->ntaps * d->Cin;
   const bool short_k = d->tile_n == 256 && d->dtype_out == SIMT_BF16 && ((Kt <= 512 && d->Cout >= 512) || (Kt <= 128 && d->Cout >= 256));
 #ifdef SIMT_ABLATION
-  { static const int no_short = getenv("SIMT_NO_SHORTK") ? atoi(getenv("SIMT_NO_SHORTK")) : 0; if (no_short) { Conv2Variant w; w.stream = false; w.tile_n = d->tile_n; w.nst = 3; w.ntiles_n = d->Npad / w.tile_n; w.tm = 4; pick_rows(M, w.ntiles_n, w.tile_n != 64, &w.rows, &w.tm); if (w.tile_n == 64) w.tm = 2; return w; } }
+  { static const int no_short = getenv("SIMT_NO_SHORTK") ? atoi(getenv("SIMT_NO_SHORTK")) : 0; if (no_short) { Conv2Variant w; w.stream = false; w.rowsk = false; w.tile_n = d->tile_n; w.nst = 3; w.ntiles_n = d->Npad / w.tile_n; w.tm = 4; pick_rows(M, w.ntiles_n, w.tile_n != 64, &w.rows, &w.tm); if (w.tile_n == 64) w.tm = 2; return w; } }
 #endif
+  v.rowsk = short_k && rows_enabled() && simt_conv_rows_eligible(d);
+  if (v.rowsk) { v.stream = false; v.tile_n = 256; v.nst = 6; v.ntiles_n = d->Npad / 256; v.tm = 2; v.rows = 128; return v; }
   v.stream = short_k && stream_enabled() && simt_conv_stream_eligible(d);
   if (v.stream) { v.tile_n = 128; v.nst = 3; v.ntiles_n = d->Npad / 128; v.tm = 4; v.rows = 128; return v; }
   if (short_k) v.tile_n = 128;
@@ -592,13 +601,13 @@ extern "C" int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int*
   if (!v2) { *bn = d->tile_n; *tm = 0; *nst = 2; return 0; }
   const Conv2Variant v = pick_variant(d);
   *bn = v.tile_n; *tm = v.tm; *nst = v.nst;
-  return v.stream ? 4 : 2;
+  return v.rowsk ? 5 : v.stream ? 4 : 2;
 }
 
 extern "C" int simt_conv_mtiles(const simt_conv_desc* d) {
   int bn, tm, nst;
   const int gen = simt_conv_variant(d, &bn, &tm, &nst);
-  if (gen != 2 && gen != 4) return 0;
+  if (gen != 2 && gen != 4 && gen != 5) return 0;
   const Conv2Variant v = pick_variant(d);
   const int M = d->B * d->Ho * d->Wo;
   return (M + v.rows - 1) / v.rows;
@@ -640,6 +649,7 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
     k.toff[i] = (d->dy[i] * d->W + d->dx[i]) * k.pix_bytes;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (v.rowsk) return simt_conv_rows_launch(k, d->Npad, st);
   if (v.stream) return simt_conv_stream_launch(k, d->Npad, st);
   if (short_k) return tm == 5 ? launch_conv2<128, 5, 2>(k, st) : launch_conv2<128, 4, 2>(k, st);
   if (tile_n == 256) return tm == 5 ? launch_conv2<256, 5>(k, st) : launch_conv2<256, 4>(k, st);

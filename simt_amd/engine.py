@@ -337,7 +337,7 @@ class TrunkPlan:
         bn_, tm_, nst_ = C.c_int(), C.c_int(), C.c_int()
         gen = L.load().simt_conv_variant(C.byref(d), C.byref(bn_), C.byref(tm_), C.byref(nst_))
         tag = (f"conv_igemm2_kernel<{bn_.value}, {tm_.value}, {nst_.value}, 0, 0>" if gen == 2 else
-               "conv1x1_stream_kernel" if gen == 4 else
+               "conv1x1_stream_kernel" if gen == 4 else "conv1x1_rows_kernel" if gen == 5 else
                f"conv_igemm_kernel<{tn[x.dtype]}, {tn[y.dtype]}, {tile}>")
         nbytes = (Bn * Hi * Wi * Cin + npad * len(taps) * Cin) * x.element_size() + M * Cout * y.element_size()
         lst.add_desc("simt_conv_fprop", d, tag=tag, flops=alg_flops if alg_flops is not None else 2.0 * M * Cout * k,

@@ -50,15 +50,16 @@ def _bits(keep_nhwc):
     return (kb << torch.arange(8, dtype=torch.int32)).sum(-1).to(torch.uint8)
 
 
-STREAM = "stream"          # conv1x1_stream_kernel (persistent, deferred epilogue): the short-K / wide-output 1x1 shapes without a residual
+STREAM = "stream"          # conv1x1_stream_kernel (persistent, deferred epilogue): short-K / wide-output 1x1 shapes the rows kernel does not take
+ROWS = "rows"              # conv1x1_rows_kernel (weights in registers, pixel rows streamed): dense 1x1, Cin <= 256, wide outputs
 # (id, B, H, W, Cin, Cout, k, dil, stride, epilogue, expected conv_igemm2_kernel<BN, TM, NST> or STREAM)
 CONV_CASES = [
     ("l3.conv2 3x3 d2 + stats", B4, HW, HW, 256, 256, 3, 2, 1, "stats", (256, 5, 3)),
     ("l3.conv2 dgrad 3x3 d2 + bnr2", B4, HW, HW, 256, 256, 3, 2, 1, "bnr2", (256, 5, 3)),
     ("l4.conv2 3x3 d4 + stats", B4, HW, HW, 512, 512, 3, 4, 1, "stats", (256, 5, 3)),
-    ("l3.conv3 256->1024 + stats", B4, HW, HW, 256, 1024, 1, 1, 1, "stats", STREAM),
-    ("fixed l3.conv3 256->1024 bias+res+relu", B4, HW, HW, 256, 1024, 1, 1, 1, "bias_res_relu", (128, 4, 2)),
-    ("l3.conv1 dgrad 256->1024 + res_bits + bnr3", B4, HW, HW, 256, 1024, 1, 1, 1, "res_bits_bnr3", (128, 4, 2)),
+    ("l3.conv3 256->1024 + stats", B4, HW, HW, 256, 1024, 1, 1, 1, "stats", ROWS),
+    ("fixed l3.conv3 256->1024 bias+res+relu", B4, HW, HW, 256, 1024, 1, 1, 1, "bias_res_relu", ROWS),
+    ("l3.conv1 dgrad 256->1024 + res_bits + bnr3", B4, HW, HW, 256, 1024, 1, 1, 1, "res_bits_bnr3", ROWS),
     ("l3.conv1 1024->256 + stats", B4, HW, HW, 1024, 256, 1, 1, 1, "stats", (256, 5, 3)),
     ("l3.conv3 dgrad 1024->256 + bnr2", B4, HW, HW, 1024, 256, 1, 1, 1, "bnr2", (256, 5, 3)),
     ("l4.conv1 2048->512", B4, HW, HW, 2048, 512, 1, 1, 1, "stats", (256, 5, 3)),
@@ -66,11 +67,11 @@ CONV_CASES = [
     ("l4.0.downsample 1024->2048", B4, HW, HW, 1024, 2048, 1, 1, 1, "stats", (256, 4, 3)),
     ("l4.0.downsample dgrad 2048->1024", B4, HW, HW, 2048, 1024, 1, 1, 1, "plain", (256, 4, 3)),
     ("l4.0.conv1 1024->512", B4, HW, HW, 1024, 512, 1, 1, 1, "stats", (256, 5, 3)),
-    ("l2.conv3 128->512", B4, HW, HW, 128, 512, 1, 1, 1, "stats", STREAM),
+    ("l2.conv3 128->512", B4, HW, HW, 128, 512, 1, 1, 1, "stats", ROWS),
     ("l2.0.downsample 256->512 s2", B4, 193, 193, 256, 512, 1, 1, 2, "stats", STREAM),
     ("l2.conv2 3x3 128->128", B4, HW, HW, 128, 128, 3, 1, 1, "stats", (128, 5, 3)),
     ("l2.conv1 512->128", B4, HW, HW, 512, 128, 1, 1, 1, "stats", (128, 5, 3)),
-    ("l1.conv3 64->256", B4, 193, 193, 64, 256, 1, 1, 1, "stats", STREAM),
+    ("l1.conv3 64->256", B4, 193, 193, 64, 256, 1, 1, 1, "stats", ROWS),
     ("l1.conv2 3x3 64->64", B4, 193, 193, 64, 64, 3, 1, 1, "stats", (64, 2, 3)),
     ("l1.conv1 256->64", B4, 193, 193, 256, 64, 1, 1, 1, "stats", (64, 2, 3)),
 ]
@@ -120,7 +121,9 @@ def test_conv_production_shapes_bf16(dev, case):
     d = ops.make_conv_desc(x_d, wp, y_d, B=B, H=H, W=W, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, taps=taps, stride=stride, Npad=npad,
                            tile_n=tile, **kw)
     gen, var = _variant(d)
-    if want == STREAM:
+    if want == ROWS:
+        assert gen == 5, f"{_id}: the benchmark times conv1x1_rows_kernel, this runs generation {gen} <{var}>"
+    elif want == STREAM:
         assert gen == 4, f"{_id}: the benchmark times conv1x1_stream_kernel, this runs generation {gen} <{var}>"
     else:
         assert gen == 2 and var == want, f"{_id}: runs conv_igemm2_kernel<{var}>, the benchmark times <{want}>"
