@@ -24,15 +24,16 @@
 
 namespace {
 
-constexpr int NCW = 8, NSW = 4;                      // compute waves, store waves
-constexpr int NC = NCW * 64, NS = NSW * 64, NT = NC + NS;
+constexpr int NCW = 8;                               // compute waves (the store waves NSW are a template parameter: 4 or 8)
+constexpr int NC = NCW * 64;
 constexpr int BN = 256, TN = 2;                      // output channels per workgroup; 16-channel blocks per compute wave
 constexpr int CP = BN * 2 + 16;                      // slab pitch (bytes): 132 dwords, conflict-free for the accumulator writes
 constexpr int VPR = BN / 8;                          // 16-byte pieces per output row
-constexpr int RGS = NS / VPR;                        // row groups of the store waves (8)
-constexpr int SR_BYTES = NSW * 2 * BN * 4;
 
-template <int KS, int TM, int D> struct Geo {
+template <int KS, int TM, int D, int NSW> struct Geo {
+  static constexpr int NS = NSW * 64, NT = NC + NS;
+  static constexpr int RGS = NS / VPR;               // row groups of the store waves
+  static constexpr int SR_BYTES = NSW * 2 * BN * 4;
   static constexpr int RS = TM * 16;                 // pixel rows per stage
   static constexpr int CIN = KS * 32;
   static constexpr int KC = CIN / 64;                // 64-deep (128-byte) sub-tiles per stage
@@ -60,11 +61,26 @@ __device__ __forceinline__ void unpack8(const uint4& q, float* v) {
 }
 
 struct Aux { uint4 res, by; unsigned rbits, ybits; };
+enum { FL_GEN = 0, FL_GEN_AUX = 1, FL_STATS = 2, FL_BRR = 3, FL_BNR = 4 };
 
-template <int KS, int TM, int D, bool AUX>
-__global__ __launch_bounds__(NT) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
-  using g = Geo<KS, TM, D>;
+template <int KS, int TM, int D, int FL, int NSW>
+__global__ __launch_bounds__(NC + NSW * 64) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
+  using g = Geo<KS, TM, D, NSW>;
+  constexpr int RGS = g::RGS, NS = g::NS;
+  // Epilogue flavour, fixed at compile time for the three the nets use (the store waves share their SIMDs with the MFMA waves: every
+  // instruction they do not execute is MFMA time): FL_STATS = store + BatchNorm batch statistics (conv3, training forward), FL_BRR =
+  // bias + residual + ReLU (conv3 of the frozen net), FL_BNR = residual through its bit mask + fused BN-backward reduce (dgrad of conv1);
+  // FL_GEN / FL_GEN_AUX read the descriptor's flags at run time.
+  constexpr bool AUX = FL == FL_BRR || FL == FL_BNR || FL == FL_GEN_AUX;
+  constexpr bool GEN = FL == FL_GEN || FL == FL_GEN_AUX;
+  const bool has_bias = GEN ? a.bias != nullptr : FL == FL_BRR;
+  const bool has_relu = GEN ? a.relu != 0 : FL == FL_BRR;
+  const bool has_stats = GEN ? a.stats != nullptr : FL == FL_STATS;
+  const bool has_res = GEN ? (AUX && a.res != nullptr) : AUX;
+  const bool has_rbits = GEN ? (AUX && a.res_bits != nullptr) : FL == FL_BNR;
+  const bool has_bnr = GEN ? (AUX && a.bnr_mode != 0) : FL == FL_BNR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (SIMT_ROWS_ABL & 16) return;
   char* slab = smem + D * g::SB;
   float* sR = (float*)(smem + D * g::SB + 2 * g::SLAB);        // [store waves][2][BN]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -205,11 +221,11 @@ __global__ __launch_bounds__(NT) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
   const bool ncol_ok = n < a.Nstore;
   float bias8[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bias8[e] = (a.bias && ncol_ok && (n + e) < a.Cout) ? a.bias[n + e] : 0.f;
+  for (int e = 0; e < 8; ++e) bias8[e] = (has_bias && ncol_ok && (n + e) < a.Cout) ? a.bias[n + e] : 0.f;
   float bmu[8], brs[8];                                        // fused BN-backward reduce (bit-mask flavour): constants of the BatchNorm whose dz this is
 #pragma unroll
   for (int e = 0; e < 8; ++e) { bmu[e] = 0.f; brs[e] = 0.f; }
-  if (AUX && a.bnr_mode && ncol_ok) {
+  if (has_bnr && ncol_ok) {
     load8(a.bnr_mean + n, bmu);
     load8(a.bnr_rstd + n, brs);
   }
@@ -217,8 +233,8 @@ __global__ __launch_bounds__(NT) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
   // also wait for every output store of the previous slab to be acknowledged by HBM.
 #pragma unroll
   for (int e = 0; e < 8; ++e) { asm volatile("" : "+v"(bias8[e])); if (AUX) { asm volatile("" : "+v"(bmu[e]), "+v"(brs[e])); } }
-  const bool plain = !a.bias && !a.res && !a.relu;
-  const bool want_sums = a.stats || (AUX && a.bnr_mode);
+  const bool plain = !has_bias && !has_res && !has_relu;
+  const bool want_sums = has_stats || has_bnr;
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -239,12 +255,12 @@ __global__ __launch_bounds__(NT) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
     d.rbits = d.ybits = 0xffu;
     if (!AUX) return;
     if (guard && !(ncol_ok && slab_row0 + rg + p * RGS < a.M)) return;
-    if (a.res) {
+    if (has_res) {
       const unsigned o = (unsigned)(slab_row0 + p * RGS) * r_pitch + r_c;
       d.res = *(const uint4*)(resb + o);
-      if (a.res_bits) d.rbits = a.res_bits[o >> 4];
+      if (has_rbits) d.rbits = a.res_bits[o >> 4];
     }
-    if (a.bnr_mode) {
+    if (has_bnr) {
       const unsigned o = (unsigned)(slab_row0 + p * RGS) * b_pitch + b_c;
       d.by = *(const uint4*)(byb + o);
       d.ybits = a.bnr_bits[o >> 4];
@@ -265,12 +281,12 @@ __global__ __launch_bounds__(NT) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
   bool stats_pending = false;
   int pend_mt = 0;
   auto sums_out = [&](int mt) {                                // the store waves' partial sums in fixed order -> HBM
-    const int nn = n0 + st;                                    // NS == BN: one column per store thread
-    if (nn < a.Cout) {
+    const int nn = n0 + st;                                    // one column per store thread (the first BN of them)
+    if (st < BN && nn < a.Cout) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int w = 0; w < NSW; ++w) { t1 += sR[(w * 2 + 0) * BN + st]; t2 += sR[(w * 2 + 1) * BN + st]; }
-      if (AUX && a.bnr_mode) {                                 // [m-tile][3][Cout]: S1, S2 and the (unused) second-BN row
+      if (has_bnr) {                                           // [m-tile][3][Cout]: S1, S2 and the (unused) second-BN row
         a.bnr_part[((long)mt * 3 + 0) * a.Cout + nn] = t1;
         a.bnr_part[((long)mt * 3 + 1) * a.Cout + nn] = t2;
         a.bnr_part[((long)mt * 3 + 2) * a.Cout + nn] = 0.f;
@@ -280,7 +296,6 @@ __global__ __launch_bounds__(NT) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
       }
     }
   };
-  static_assert(NS == BN, "sums_out maps one column to one store thread");
 
 #ifdef SIMT_ABLATION
   unsigned long long ts_bar = 0, ts_work = 0, ts_prev = 0, ts_lds = 0;
@@ -324,26 +339,26 @@ __global__ __launch_bounds__(NT) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
       if (!plain || want_sums) {
         float v[8];
         unpack8(o, v);
-        if (a.stats) {                                         // forward: statistics of the stored value, before bias / residual / ReLU
+        if (has_stats) {                                       // forward: statistics of the stored value, before bias / residual / ReLU
 #pragma unroll
           for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
         }
         if (!plain) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += bias8[e];
-          if (AUX && a.res) {
+          if (has_res) {
             float rv[8];
             unpack8(cur.res, rv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += ((cur.rbits >> e) & 1u) ? rv[e] : 0.f;
+            for (int e = 0; e < 8; ++e) v[e] += (!has_rbits || ((cur.rbits >> e) & 1u)) ? rv[e] : 0.f;
           }
-          if (a.relu) {
+          if (has_relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
           }
           o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
         }
-        if (AUX && a.bnr_mode) {
+        if (has_bnr) {
           // backward: S1 = sum g, S2 = sum g * xhat on the value as stored (bf16), masked like the backward masks it
           if (!plain) unpack8(o, v);
           float yv[8];
@@ -389,15 +404,15 @@ __global__ __launch_bounds__(NT) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
 #endif
 }
 
-template <int KS, int TM, int D, bool AUX>
+template <int KS, int TM, int D, int FL, int NSW>
 int launch_rows(const Conv2KArgs& k, int G, hipStream_t st) {
-  using g = Geo<KS, TM, D>;
+  using g = Geo<KS, TM, D, NSW>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv1x1_rows_kernel<KS, TM, D, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, g::LDS);
+    (void)hipFuncSetAttribute((const void*)conv1x1_rows_kernel<KS, TM, D, FL, NSW>, hipFuncAttributeMaxDynamicSharedMemorySize, g::LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv1x1_rows_kernel<KS, TM, D, AUX>), dim3(G), dim3(NT), g::LDS, st, k, G);
+  hipLaunchKernelGGL((conv1x1_rows_kernel<KS, TM, D, FL, NSW>), dim3(G), dim3(g::NT), g::LDS, st, k, G);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
@@ -433,7 +448,15 @@ int simt_conv_rows_launch(Conv2KArgs k, int npad, hipStream_t st) {
   const int G = nwg < 256 ? nwg : 256;
   const bool aux = k.res || k.bnr_mode;
   const int cin = k.pix_bytes / 2;
-  if (cin == 256) return aux ? launch_rows<8, 2, 6, true>(k, G, st) : launch_rows<8, 2, 6, false>(k, G, st);
-  if (cin == 128) return launch_rows<4, 4, 4, false>(k, G, st);
-  return launch_rows<2, 4, 6, false>(k, G, st);
+  const bool f_stats = k.stats && !k.bias && !k.relu && !aux;
+  const bool f_brr = k.bias && k.relu && k.res && !k.res_bits && !k.bnr_mode && !k.stats;
+  const bool f_bnr = k.res && k.res_bits && k.bnr_mode == 3 && !k.bias && !k.relu && !k.stats;
+  if (cin == 256) {
+    if (f_stats) return launch_rows<8, 2, 6, FL_STATS, 4>(k, G, st);
+    if (f_brr) return launch_rows<8, 2, 6, FL_BRR, 4>(k, G, st);
+    if (f_bnr) return launch_rows<8, 2, 6, FL_BNR, 4>(k, G, st);
+    return aux ? launch_rows<8, 2, 6, FL_GEN_AUX, 4>(k, G, st) : launch_rows<8, 2, 6, FL_GEN, 4>(k, G, st);
+  }
+  if (cin == 128) return f_stats ? launch_rows<4, 4, 4, FL_STATS, 4>(k, G, st) : launch_rows<4, 4, 4, FL_GEN, 4>(k, G, st);
+  return f_stats ? launch_rows<2, 4, 6, FL_STATS, 4>(k, G, st) : launch_rows<2, 4, 6, FL_GEN, 4>(k, G, st);
 }
