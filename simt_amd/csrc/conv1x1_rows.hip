@@ -15,22 +15,24 @@
 //   * persistent workgroups on 128-row tiles (the statistics granule), XCD-aware: the workgroups of one XCD share pixel rows.
 // L2 -> LDS traffic per launch of 256 -> 1024: 4 x 19 MB instead of 302 MB.
 #include "conv2_common.h"
+#include <type_traits>
 
 // Compile-time timing ablations (scratch builds only; outputs meaningless): 1 = no fragment reads / MFMA, 2 = no global stores,
-// 4 = no LDS-DMA loads, 8 = store waves idle (barriers only)
+// 4 = no LDS-DMA loads, 8 = store waves idle (barriers only), 64 = no epilogue in the compute waves, 128 = no fragment reads, 256 = no statistics
 #ifndef SIMT_ROWS_ABL
 #define SIMT_ROWS_ABL 0
 #endif
 
 namespace {
 
-constexpr int NCW = 8;                               // compute waves (the store waves NSW are a template parameter: 4 or 8)
-constexpr int NC = NCW * 64;
-constexpr int BN = 256, TN = 2;                      // output channels per workgroup; 16-channel blocks per compute wave
-constexpr int CP = BN * 2 + 16;                      // slab pitch (bytes): 132 dwords, conflict-free for the accumulator writes
-constexpr int VPR = BN / 8;                          // 16-byte pieces per output row
+constexpr int TN = 2;                                // 16-channel blocks per compute wave (32 output channels per wave)
 
-template <int KS, int TM, int D, int NSW> struct Geo {
+// NCW compute waves (each 32 output channels: BN = 32 * NCW per workgroup) + NSW store waves.  <8, 4>: one 768-thread workgroup per CU;
+// <4, 2>: two 384-thread workgroups per CU, which drift apart so that one's store phase overlaps the other's MFMA phase.
+template <int KS, int TM, int D, int NSW, int NCW> struct Geo {
+  static constexpr int NC = NCW * 64, BN = NCW * 32;
+  static constexpr int CP = BN * 2 + 16;             // slab pitch (bytes): 4 * odd dwords, conflict-free for the accumulator writes
+  static constexpr int VPR = BN / 8;                 // 16-byte pieces per output row
   static constexpr int NS = NSW * 64, NT = NC + NS;
   static constexpr int RGS = NS / VPR;               // row groups of the store waves
   static constexpr int SR_BYTES = NSW * 2 * BN * 4;
@@ -43,14 +45,27 @@ template <int KS, int TM, int D, int NSW> struct Geo {
   static constexpr int SLAB = RS * CP;
   static constexpr int PASSES = RS / RGS;            // rows per store thread per slab
   static constexpr int LDS = D * SB + 2 * SLAB + SR_BYTES;
-  static_assert(CIN % 64 == 0 && SB % (16 * NC) == 0 && PT >= 1 && 128 % RS == 0 && LDS <= 160 * 1024, "geometry");
+  static_assert(CIN % 64 == 0 && SB % (16 * NC) == 0 && PT >= 1 && 128 % RS == 0 && LDS <= 160 * 1024 && NS == BN && RS % RGS == 0, "geometry");
 };
 
-// v[l] + v[l ^ 32]
-__device__ __forceinline__ float half_swap_sum(float v) {
+// sum over the row groups of a wave: lanes l, l ^ 32 (two groups of 32 lanes) or l, l ^ 16, l ^ 32, l ^ 48 (four groups of 16)
+template <int GROUPS> __device__ __forceinline__ float row_groups_sum(float v) {
   typedef __attribute__((ext_vector_type(2))) unsigned u2;
+  if (GROUPS == 4) {
+    const u2 q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(q.x) + __uint_as_float(q.y);
+  }
   const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
+// sum over the 16 lanes of a DPP row by rotations (8, 4, 2, 1): every lane of the row ends with the total
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
+  return v;
 }
 
 __device__ __forceinline__ void unpack8(const uint4& q, float* v) {
@@ -63,24 +78,35 @@ __device__ __forceinline__ void unpack8(const uint4& q, float* v) {
 struct Aux { uint4 res, by; unsigned rbits, ybits; };
 enum { FL_GEN = 0, FL_GEN_AUX = 1, FL_STATS = 2, FL_BRR = 3, FL_BNR = 4 };
 
-template <int KS, int TM, int D, int FL, int NSW>
-__global__ __launch_bounds__(NC + NSW * 64) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
-  using g = Geo<KS, TM, D, NSW>;
-  constexpr int RGS = g::RGS, NS = g::NS;
+template <int KS, int TM, int D, int FL, int NSW, int NCW>
+__global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
+  using g = Geo<KS, TM, D, NSW, NCW>;
+  constexpr int RGS = g::RGS, NS = g::NS, NC = g::NC, BN = g::BN, CP = g::CP, VPR = g::VPR;
   // Epilogue flavour, fixed at compile time for the three the nets use (the store waves share their SIMDs with the MFMA waves: every
   // instruction they do not execute is MFMA time): FL_STATS = store + BatchNorm batch statistics (conv3, training forward), FL_BRR =
   // bias + residual + ReLU (conv3 of the frozen net), FL_BNR = residual through its bit mask + fused BN-backward reduce (dgrad of conv1);
   // FL_GEN / FL_GEN_AUX read the descriptor's flags at run time.
   constexpr bool AUX = FL == FL_BRR || FL == FL_BNR || FL == FL_GEN_AUX;
   constexpr bool GEN = FL == FL_GEN || FL == FL_GEN_AUX;
+  // Store waves without global operands run TWO slabs behind the compute waves: the rows of slab g - 2 are already in registers when
+  // barrier g falls, so a stage starts with its stores (the step that blocks, on HBM write back-pressure), then requests slab g - 1 from
+  // LDS, then does the statistics of slab g - 2 while both are in flight.
+  constexpr bool PIPE = !AUX;
+  // FL_STATS: the BatchNorm statistics are taken by the COMPUTE waves from the values they round for the slab (a compute wave owns its 32
+  // channels for every pixel: per-lane partial sums over a 128-row tile, one 16-lane DPP reduction per tile, no LDS, no second pass over
+  // the tile) -- the store waves are left with a pure LDS -> HBM copy.
+  constexpr bool CSTAT = FL == FL_STATS;
   const bool has_bias = GEN ? a.bias != nullptr : FL == FL_BRR;
   const bool has_relu = GEN ? a.relu != 0 : FL == FL_BRR;
-  const bool has_stats = GEN ? a.stats != nullptr : FL == FL_STATS;
+  const bool has_stats = GEN ? a.stats != nullptr : false;      // statistics taken by the store waves (FL_STATS: by the compute waves)
   const bool has_res = GEN ? (AUX && a.res != nullptr) : AUX;
   const bool has_rbits = GEN ? (AUX && a.res_bits != nullptr) : FL == FL_BNR;
   const bool has_bnr = GEN ? (AUX && a.bnr_mode != 0) : FL == FL_BNR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (SIMT_ROWS_ABL & 16) return;
+#ifdef SIMT_ROWS_STAGGER
+  { const int ph = (blockIdx.x >> 3) & 3; for (int i = 0; i < ph * SIMT_ROWS_STAGGER; ++i) __builtin_amdgcn_s_sleep(1); }
+#endif
   char* slab = smem + D * g::SB;
   float* sR = (float*)(smem + D * g::SB + 2 * g::SLAB);        // [store waves][2][BN]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -103,14 +129,15 @@ __global__ __launch_bounds__(NC + NSW * 64) void conv1x1_rows_kernel(Conv2KArgs 
       for (int ks = 0; ks < KS; ++ks)
         wf[j][ks] = *(const bf16x8*)(a.w + (size_t)(n0 + wave * 32 + j * 16 + (lane & 15)) * (unsigned)a.wrow_bytes + (ks * 32 + (lane >> 4) * 8) * 2);
     // LDS-DMA pieces of this thread: linear LDS position p = q * NC + tid -> sub-tile kc = p / (RS * 8), row = (p / 8) % RS, chunk = p % 8
-    unsigned pconst[g::PT], pmax[g::PT];                       // byte offset of the piece inside a stage / clamp for rows past the end
+    unsigned pconst[g::PT], pmax[g::PT], pzero[g::PT];         // byte offset of the piece inside a stage / last valid offset / its place in the zero page
 #pragma unroll
     for (int q = 0; q < g::PT; ++q) {
       const int p = q * NC + tid;
       const int row = (p >> 3) % g::RS, kc = p / (g::RS * 8), c = p & 7;
       const unsigned ko = (unsigned)(kc * 128 + ((c ^ ((row >> 1) & 7)) << 4));
       pconst[q] = (unsigned)row * (unsigned)a.pix_bytes + ko;
-      pmax[q] = (unsigned)(a.M - 1) * (unsigned)a.pix_bytes + ko;      // rows past the end: recomputed from the last row, never stored
+      pmax[q] = (unsigned)(a.M - 1) * (unsigned)a.pix_bytes + ko;      // rows past the end read the zero page: exact zeros, never stored,
+      pzero[q] = ko;                                                   // and they add nothing to the statistics
     }
     int ii = 0, is = 0;                                        // issue cursor: tile index of this workgroup, stage inside the tile
     unsigned ibase = (unsigned)(mt0 * 128) * (unsigned)a.pix_bytes;    // uniform: first row of the stage to issue, in bytes
@@ -120,9 +147,9 @@ __global__ __launch_bounds__(NC + NSW * 64) void conv1x1_rows_kernel(Conv2KArgs 
       char* sb = smem + slot * g::SB;
 #pragma unroll
       for (int q = 0; q < g::PT; ++q) {
-        unsigned off = ibase + pconst[q];
-        off = off < pmax[q] ? off : pmax[q];
-        if (!(SIMT_ROWS_ABL & 4)) __builtin_amdgcn_global_load_lds(GPTR(a.x + off), LPTR(sb + (q * NC + wave * 64) * 16), 16, 0, 0);
+        const unsigned off = ibase + pconst[q];
+        const char* src = off <= pmax[q] ? a.x + off : a.zero + pzero[q];
+        if (!(SIMT_ROWS_ABL & 4)) __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sb + (q * NC + wave * 64) * 16), 16, 0, 0);
       }
       ibase += stage_step;
       if (++is == g::SPT) { is = 0; ++ii; tile_base += tile_step; ibase = tile_base; }
@@ -134,16 +161,131 @@ __global__ __launch_bounds__(NC + NSW * 64) void conv1x1_rows_kernel(Conv2KArgs 
 #pragma unroll
     for (int s = 0; s < D - 1; ++s) if (s < S_total) issue(s);
     int slot_c = 0, slot_i = D - 1;
+    float cs1[TN][4], cs2[TN][4];                              // CSTAT: this lane's sums over its pixels (lane & 15, every 16-row block)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { cs1[j][e] = 0.f; cs2[j][e] = 0.f; }
+    int c_is = 0, c_ci = 0;                                    // cursor of the stage whose epilogue runs: stage inside the tile, tile
 #ifdef SIMT_ABLATION
     unsigned long long t_wait = 0, t_bar = 0, t_work = 0;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
-    for (int gi = 0; gi < S_total; ++gi) {
+    // The epilogue of stage g - 1 (round to bf16, write the slab, statistics) is DEFERRED into the MFMA loop of stage g, two VALU
+    // operations behind every MFMA: a wave issues in order, so its own VALU work only overlaps its MFMAs if it sits between them (measured,
+    // scratch/mixbench2.hip: up to two plain VALU per MFMA are free with two waves per SIMD; v_pk_*_f32 never is -- the library is built
+    // without packed fp32).  All waves of a workgroup are phase-locked by the stage barrier, so nothing else would fill the MFMA shadow.
+    constexpr int NQ = TN * TM;
+    f32x4 prev[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) prev[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto epi_quad = [&](int qd, unsigned sbase) {             // one accumulator quad of the previous stage: 4 channels of one pixel per lane
+      const int j = qd / TM, i = qd % TM;
+      uint2 pk;
+      pk.x = pack_bf16x2(prev[j][i][0], prev[j][i][1]);
+      pk.y = pack_bf16x2(prev[j][i][2], prev[j][i][3]);
+      // LDS traffic of the compute waves is inline asm with hand-counted lgkmcnt: before a C++ LDS store the compiler drains vmcnt to 0 (it
+      // must assume the store aliases an LDS-DMA in flight -- also with separate static LDS arrays), and around C++ LDS loads it waits
+      // lgkmcnt(0) right after requesting the next fragments
+      asm volatile("ds_write_b64 %0, %1" :: "v"(sbase + (unsigned)(i * 16 * CP + j * 32)), "v"(pk));
+      if (CSTAT && !(SIMT_ROWS_ABL & 256)) {                   // statistics of the values as stored (bf16); rows past the end are exact zeros
+        const float v0 = __uint_as_float(pk.x << 16), v1 = __uint_as_float(pk.x & 0xffff0000u);
+        const float v2 = __uint_as_float(pk.y << 16), v3 = __uint_as_float(pk.y & 0xffff0000u);
+        cs1[j][0] += v0; cs1[j][1] += v1; cs1[j][2] += v2; cs1[j][3] += v3;
+        cs2[j][0] = fmaf(v0, v0, cs2[j][0]); cs2[j][1] = fmaf(v1, v1, cs2[j][1]);
+        cs2[j][2] = fmaf(v2, v2, cs2[j][2]); cs2[j][3] = fmaf(v3, v3, cs2[j][3]);
+      }
+    };
+    auto tile_end = [&]() {                                    // after the epilogue of a stage: statistics of a finished 128-row tile
+      if (!CSTAT) return;
+      if (++c_is < g::SPT) return;
+      // sum over the 16 pixel lanes of a DPP row (rotations: every lane ends with the total, fixed order); lane 0 of each row stores 2 x 4 channels
+      const int mt = mt0 + c_ci * mt_step;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float t1[4], t2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { t1[e] = row16_sum(cs1[j][e]); t2[e] = row16_sum(cs2[j][e]); cs1[j][e] = 0.f; cs2[j][e] = 0.f; }
+        const int nn = n0 + wave * 32 + j * 16 + (lane >> 4) * 4;
+        if ((lane & 15) == 0 && nn < a.Cout) {                 // Cout % 4 == 0 (host)
+          *(float4*)(a.stats + ((long)mt * 2 + 0) * a.Cout + nn) = make_float4(t1[0], t1[1], t1[2], t1[3]);
+          *(float4*)(a.stats + ((long)mt * 2 + 1) * a.Cout + nn) = make_float4(t2[0], t2[1], t2[2], t2[3]);
+        }
+      }
+      c_is = 0; ++c_ci;
+    };
+    auto body = [&](auto do_mma, auto do_epi, int gi) {
+      constexpr bool MMA = decltype(do_mma)::value, EPI = decltype(do_epi)::value;
+      const char* st = smem + slot_c * g::SB + xrow;
+      if (MMA) { if (++slot_c == D) slot_c = 0; }
+      const unsigned sbase = sl_addr + (unsigned)(((gi - 1) & 1) * g::SLAB);      // slab of stage gi - 1
+      f32x4 acc[TN][TM];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      constexpr int KSN = (SIMT_ROWS_ABL & 1) ? 0 : KS;
+      // pixel fragments: requested PF k-steps ahead into PF + 1 rotating register sets (an LDS round trip under load is longer than the
+      // 4 MFMAs of one k-step)
+      constexpr int PF = TM == 2 ? 2 : 1;
+      bf16x8 xf[PF + 1][TM];
+      const unsigned st_addr = (unsigned)(size_t)LPTR(st);
+      auto frags = [&](int ks, bf16x8* f) {                    // request the pixel fragments of k-step ks (TM x ds_read_b128)
+        const unsigned ad = st_addr + (unsigned)((ks >> 1) * (g::RS * 128)) + (unsigned)(((4 * (ks & 1) + kq) ^ sw) << 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          if (SIMT_ROWS_ABL & 128) asm volatile("" : "=v"(f[i]) : "v"(ad));
+          else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[i]) : "v"(ad), "n"(i * 16 * 128));
+        }
+      };
+      auto landed = [&](bf16x8* f, int younger) {              // f is complete: everything but the `younger` most recent LDS operations has returned
+        static_assert(TM == 2 || TM == 4, "fragment blocks");
+#define SIMT_LANDED(N) if (younger == N) { if (TM == 2) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0]), "+v"(f[1])); \
+                                             else asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2 % TM]), "+v"(f[3 % TM])); }
+        SIMT_LANDED(0) SIMT_LANDED(2) SIMT_LANDED(4)
+#undef SIMT_LANDED
+      };
+      if (MMA) {
+#pragma unroll
+        for (int k0 = 0; k0 < PF && k0 < KSN; ++k0) frags(k0, xf[k0 % (PF + 1)]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (MMA && ks + PF < KSN) frags(ks + PF, xf[(ks + PF) % (PF + 1)]);
+        if (MMA && ks < KSN) {
+          const int ahead = (KSN - 1 - ks) < PF ? (KSN - 1 - ks) : PF;      // k-steps requested after this one
+          landed(xf[ks % (PF + 1)], ahead * TM);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], xf[ks % (PF + 1)][i], acc[j][i], 0, 0, 0);
+        }
+        if (EPI) {                                             // the quads of the previous stage, spread evenly over the k-steps
+#pragma unroll
+          for (int qd = 0; qd < NQ; ++qd) if (!(SIMT_ROWS_ABL & 64) && qd * KS / NQ == ks) epi_quad(qd, sbase);
+        }
+      }
+      if (MMA && EPI) {                                        // 1 MFMA, then at most 2 VALU, ... (whatever is left follows the last MFMA)
+#pragma unroll
+        for (int n = 0; n < KSN * NQ; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+      }
+      if (EPI) tile_end();
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) prev[j][i] = acc[j][i];
+    };
+    for (int gi = 0; gi <= S_total; ++gi) {
 #ifdef SIMT_ABLATION
       const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
 #endif
       if (gi + D - 2 < S_total) wait_vmcnt<g::PT * (D - 2)>(); else wait_vmcnt<0>();     // stage gi landed (this wave's pieces)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  // this wave's slab writes of stage gi - 1
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  // this wave's slab writes (stage gi - 2)
 #ifdef SIMT_ABLATION
       const unsigned long long tw1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -155,43 +297,9 @@ __global__ __launch_bounds__(NC + NSW * 64) void conv1x1_rows_kernel(Conv2KArgs 
 #endif
       if (gi + D - 1 < S_total) issue(slot_i);                 // into the slot every wave finished reading in stage gi - 1
       if (++slot_i == D) slot_i = 0;
-      const char* st = smem + slot_c * g::SB + xrow;
-      if (++slot_c == D) slot_c = 0;
-      f32x4 acc[TN][TM];
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks (the LDS round trip hides behind 4 MFMAs)
-      constexpr int KSN = (SIMT_ROWS_ABL & 1) ? 0 : KS;
-      bf16x8 xf[2][TM];
-      auto frags = [&](int ks, bf16x8* f) {
-        const int coff = ((4 * (ks & 1) + kq) ^ sw) << 4;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) f[i] = *(const bf16x8*)(st + (ks >> 1) * (g::RS * 128) + i * 16 * 128 + coff);
-      };
-      if (KSN > 0) frags(0, xf[0]);
-#pragma unroll
-      for (int ks = 0; ks < KSN; ++ks) {
-        if (ks + 1 < KSN) frags(ks + 1, xf[(ks + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);                     // keep this order: the scheduler otherwise sinks the reads to their use
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int i = 0; i < TM; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], xf[ks & 1][i], acc[j][i], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // written by inline asm: before a C++ LDS store the compiler drains vmcnt to 0 (it must assume the store aliases an LDS-DMA in flight)
-      const unsigned sbase = sl_addr + (unsigned)((gi & 1) * g::SLAB);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          uint2 pk;
-          pk.x = pack_bf16x2(acc[j][i][0], acc[j][i][1]);
-          pk.y = pack_bf16x2(acc[j][i][2], acc[j][i][3]);
-          asm volatile("ds_write_b64 %0, %1" :: "v"(sbase + (unsigned)(i * 16 * CP + j * 32)), "v"(pk) : "memory");
-        }
+      if (gi == 0) body(std::true_type{}, std::false_type{}, gi);
+      else if (gi < S_total) body(std::true_type{}, std::true_type{}, gi);
+      else body(std::false_type{}, std::true_type{}, gi);
 #ifdef SIMT_ABLATION
       asm volatile("s_nop 0" ::: "memory");
       t_work += __builtin_amdgcn_s_memtime() - tw2;
@@ -202,10 +310,16 @@ __global__ __launch_bounds__(NC + NSW * 64) void conv1x1_rows_kernel(Conv2KArgs 
       unsigned long long* o = g_stamps + blockIdx.x * 8;
       o[0] = t_wait; o[1] = t_bar; o[2] = t_work; o[3] = __builtin_amdgcn_s_memtime() - t_begin; o[4] = (unsigned long long)S_total;
     }
+    if (lane == 0 && blockIdx.x < 256) {                       // per compute wave: work / barrier ticks (second half of the stamp array)
+      unsigned long long* o = g_stamps + 4096 * 8 + (blockIdx.x * 8 + wave) * 2;
+      o[0] = t_work; o[1] = t_bar;
+    }
 #endif
+    // drain: the store waves run one (two: pipelined path) slabs behind the last slab write, then the last tile's sums go through sR
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                              // the last slab is visible to the store waves
-    __builtin_amdgcn_s_barrier();                              // ... and the last tile's statistics sit in sR
+    __builtin_amdgcn_s_barrier();
+    if (PIPE) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     return;
   }
 
@@ -300,7 +414,11 @@ __global__ __launch_bounds__(NC + NSW * 64) void conv1x1_rows_kernel(Conv2KArgs 
 #ifdef SIMT_ABLATION
   unsigned long long ts_bar = 0, ts_work = 0, ts_prev = 0, ts_lds = 0;
 #endif
-  for (int gi = 0; gi <= S_total; ++gi) {
+  uint4 ov[g::PASSES];                                         // PIPE: the rows of the slab to be stored, read during the previous stage
+  const int LAST = PIPE ? S_total + 1 : S_total;
+  __builtin_amdgcn_s_barrier();                                // the compute waves' barrier 0: they write the slab of stage g - 1 during stage g,
+                                                               // so "barrier gi" below is their barrier gi + 1
+  for (int gi = 0; gi <= LAST; ++gi) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // slab reads / sR writes of the previous iteration
 #ifdef SIMT_ABLATION
     const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
@@ -317,12 +435,72 @@ __global__ __launch_bounds__(NC + NSW * 64) void conv1x1_rows_kernel(Conv2KArgs 
 #endif
     if (gi == 0 || (SIMT_ROWS_ABL & 8)) continue;
     const char* sl = slab + ((gi - 1) & 1) * g::SLAB;
+    if (PIPE) {
+      const bool guard_cur = !(all_cols && row0 + g::RS <= a.M);
+      if (gi >= 2) {                                           // slab gi - 2: (bias, ReLU,) stores
+#pragma unroll
+        for (int p = 0; p < g::PASSES; ++p) {
+          if (guard_cur && !(ncol_ok && row0 + rg + p * RGS < a.M)) continue;
+          uint4 o = ov[p];
+          if (!plain) {
+            float v[8];
+            unpack8(o, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[e] += bias8[e]; if (has_relu) v[e] = v[e] > 0.f ? v[e] : 0.f; }
+            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+          }
+          unsigned yo = (unsigned)(row0 + p * RGS) * y_pitch + y_c;
+          if (SIMT_ROWS_ABL & 32) yo = (yo & 0x3fffu) + blockIdx.x * 0x4000u;
+          if (!(SIMT_ROWS_ABL & 2) || o.x == 0x12345678u) *(uint4*)(const_cast<char*>(yb) + yo) = o;
+        }
+      }
+#ifdef SIMT_ABLATION
+      asm volatile("s_nop 0" ::: "memory");
+      ts_lds += __builtin_amdgcn_s_memtime() - tb1;            // (PIPE: barrier -> stores issued)
+#endif
+      uint4 nv[g::PASSES];
+      if (gi <= S_total) {                                     // slab gi - 1: LDS -> registers (in flight during the statistics below)
+#pragma unroll
+        for (int p = 0; p < g::PASSES; ++p) nv[p] = *(const uint4*)(sl + (rg + p * RGS) * CP + vcol * 2);
+      }
+      if (gi >= 2) {
+        if (has_stats) {                                       // statistics of the stored value, before bias / ReLU
+#pragma unroll
+          for (int p = 0; p < g::PASSES; ++p) {
+            if (guard_cur && !(ncol_ok && row0 + rg + p * RGS < a.M)) continue;
+            float v[8];
+            unpack8(ov[p], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+          }
+        }
+        int mt_next;
+        const int nrow0 = next_row0(mt_next);
+        if (is + 1 == g::SPT) {                                // end of a 128-row tile
+          if (want_sums) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float t1 = row_groups_sum<64 / VPR>(s1[e]), t2 = row_groups_sum<64 / VPR>(s2[e]);
+              if (lane < VPR) { sR[(swv * 2 + 0) * BN + vcol + e] = t1; sR[(swv * 2 + 1) * BN + vcol + e] = t2; }
+              s1[e] = 0.f; s2[e] = 0.f;
+            }
+            stats_pending = true; pend_mt = cur_mt;
+          }
+          is = 0; ++ci;
+        } else {
+          ++is;
+        }
+        row0 = nrow0; cur_mt = mt_next;
+      }
+#pragma unroll
+      for (int p = 0; p < g::PASSES; ++p) ov[p] = nv[p];
+      continue;
+    }
     int mt_next;
     const int nrow0 = next_row0(mt_next);
     const bool more = gi < S_total;
     // all slab rows of this thread first (one LDS round trip per slab), then one 16-byte store per row from a single store site (with
     // several, the compiler sinks them into a shared tail of a 4-byte and a 12-byte store)
-    uint4 ov[g::PASSES];                                       // (the aux flavours have no registers left for this: they read per pass)
 #pragma unroll
     for (int p = 0; p < g::PASSES; ++p) if (!AUX) ov[p] = *(const uint4*)(sl + (rg + p * RGS) * CP + vcol * 2);
 #ifdef SIMT_ABLATION
@@ -369,7 +547,8 @@ __global__ __launch_bounds__(NC + NSW * 64) void conv1x1_rows_kernel(Conv2KArgs 
           for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * ((yv[e] - bmu[e]) * brs[e]); }
         }
       }
-      const unsigned yo = (unsigned)(row0 + p * RGS) * y_pitch + y_c;
+      unsigned yo = (unsigned)(row0 + p * RGS) * y_pitch + y_c;
+      if (SIMT_ROWS_ABL & 32) yo = (yo & 0x3fffu) + blockIdx.x * 0x4000u;        // ablation: every store hits the same 16 KB per workgroup (L2-resident)
       if (!(SIMT_ROWS_ABL & 2) || o.x == 0x12345678u) *(uint4*)(const_cast<char*>(yb) + yo) = o;
     };
     if (AUX || guard_cur) {                                    // (one copy of the pass code in the aux flavours: registers)
@@ -384,8 +563,8 @@ __global__ __launch_bounds__(NC + NSW * 64) void conv1x1_rows_kernel(Conv2KArgs 
       if (want_sums) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float t1 = half_swap_sum(s1[e]), t2 = half_swap_sum(s2[e]);
-          if (lane < 32) { sR[(swv * 2 + 0) * BN + vcol + e] = t1; sR[(swv * 2 + 1) * BN + vcol + e] = t2; }
+          const float t1 = row_groups_sum<64 / VPR>(s1[e]), t2 = row_groups_sum<64 / VPR>(s2[e]);
+          if (lane < VPR) { sR[(swv * 2 + 0) * BN + vcol + e] = t1; sR[(swv * 2 + 1) * BN + vcol + e] = t2; }
           s1[e] = 0.f; s2[e] = 0.f;
         }
         stats_pending = true; pend_mt = cur_mt;
@@ -404,15 +583,21 @@ __global__ __launch_bounds__(NC + NSW * 64) void conv1x1_rows_kernel(Conv2KArgs 
 #endif
 }
 
-template <int KS, int TM, int D, int FL, int NSW>
-int launch_rows(const Conv2KArgs& k, int G, hipStream_t st) {
-  using g = Geo<KS, TM, D, NSW>;
+template <int KS, int TM, int D, int FL, int NSW, int NCW>
+int launch_rows(Conv2KArgs k, int npad, hipStream_t st) {
+  using g = Geo<KS, TM, D, NSW, NCW>;
+  k.rows = 128;
+  k.ntiles_n = npad / g::BN;
+  k.ntiles_m = (k.M + 127) / 128;
+  const int nwg = k.ntiles_m * k.ntiles_n;
+  const int cap = NCW == 8 ? 256 : 512;                        // persistent: one (768 threads) or two (384 threads) workgroups per CU
+  const int G = nwg < cap ? nwg : cap;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv1x1_rows_kernel<KS, TM, D, FL, NSW>, hipFuncAttributeMaxDynamicSharedMemorySize, g::LDS);
+    (void)hipFuncSetAttribute((const void*)conv1x1_rows_kernel<KS, TM, D, FL, NSW, NCW>, hipFuncAttributeMaxDynamicSharedMemorySize, g::LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv1x1_rows_kernel<KS, TM, D, FL, NSW>), dim3(G), dim3(g::NT), g::LDS, st, k, G);
+  hipLaunchKernelGGL((conv1x1_rows_kernel<KS, TM, D, FL, NSW, NCW>), dim3(G), dim3(g::NT), g::LDS, st, k, G);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
@@ -432,31 +617,30 @@ bool simt_conv_rows_eligible(const simt_conv_desc* d) {
   if (d->mask || (d->bnr_mode != 0 && d->bnr_mode != 3)) return false;         // fused BN-backward reduce: bit-mask flavour only
   if (d->Cin != 64 && d->Cin != 128 && d->Cin != 256) return false;
   if (d->Cin != 256 && (d->res || d->bnr_mode)) return false;                  // the 64-row-stage variants spill with the aux operands
-  if (d->Npad % BN != 0) return false;
+  if (d->Npad % 256 != 0) return false;
   const long M = (long)d->B * d->Ho * d->Wo, lim = 1l << 32;                   // 32-bit byte offsets in the store waves
   if (M * d->ldy * 2 >= lim || (d->res && M * d->ldr * 2 >= lim) || (d->bnr_mode && M * d->bnr_ld * 2 >= lim)) return false;
   if (d->ldy % 8 != 0 || (d->res && d->ldr % 8 != 0)) return false;
-  const int ntn = d->Npad / BN;
-  return ntn == 1 || ntn == 2 || ntn == 4 || ntn == 8 || ntn == 16 || ntn == 32;      // ntiles_n | 256 / 8
+  const int ntn = d->Npad / 128;                                               // column tiles of the narrowest variant
+  return ntn == 2 || ntn == 4 || ntn == 8 || ntn == 16 || ntn == 32;           // ntiles_n | grid / 8
 }
 
 int simt_conv_rows_launch(Conv2KArgs k, int npad, hipStream_t st) {
-  k.rows = 128;
-  k.ntiles_n = npad / BN;
-  k.ntiles_m = (k.M + 127) / 128;
-  const int nwg = k.ntiles_m * k.ntiles_n;
-  const int G = nwg < 256 ? nwg : 256;
   const bool aux = k.res || k.bnr_mode;
   const int cin = k.pix_bytes / 2;
-  const bool f_stats = k.stats && !k.bias && !k.relu && !aux;
+  const bool f_stats = k.stats && !k.bias && !k.relu && !aux && k.Cout % 4 == 0;
   const bool f_brr = k.bias && k.relu && k.res && !k.res_bits && !k.bnr_mode && !k.stats;
   const bool f_bnr = k.res && k.res_bits && k.bnr_mode == 3 && !k.bias && !k.relu && !k.stats;
+#ifndef SIMT_ROWS_NCW
+#define SIMT_ROWS_NCW 8
+#endif
+  constexpr int CW = SIMT_ROWS_NCW, SW = CW / 2, D256 = CW == 8 ? 6 : 3;
   if (cin == 256) {
-    if (f_stats) return launch_rows<8, 2, 6, FL_STATS, 4>(k, G, st);
-    if (f_brr) return launch_rows<8, 2, 6, FL_BRR, 4>(k, G, st);
-    if (f_bnr) return launch_rows<8, 2, 6, FL_BNR, 4>(k, G, st);
-    return aux ? launch_rows<8, 2, 6, FL_GEN_AUX, 4>(k, G, st) : launch_rows<8, 2, 6, FL_GEN, 4>(k, G, st);
+    if (f_stats) return launch_rows<8, 2, D256, FL_STATS, SW, CW>(k, npad, st);
+    if (f_brr) return launch_rows<8, 2, D256, FL_BRR, SW, CW>(k, npad, st);
+    if (f_bnr) return launch_rows<8, 2, D256, FL_BNR, SW, CW>(k, npad, st);
+    return aux ? launch_rows<8, 2, 6, FL_GEN_AUX, 4, 8>(k, npad, st) : launch_rows<8, 2, 6, FL_GEN, 4, 8>(k, npad, st);
   }
-  if (cin == 128) return f_stats ? launch_rows<4, 4, 4, FL_STATS, 4>(k, G, st) : launch_rows<4, 4, 4, FL_GEN, 4>(k, G, st);
-  return f_stats ? launch_rows<2, 4, 6, FL_STATS, 4>(k, G, st) : launch_rows<2, 4, 6, FL_GEN, 4>(k, G, st);
+  if (cin == 128) return f_stats ? launch_rows<4, 4, 4, FL_STATS, 4, 8>(k, npad, st) : launch_rows<4, 4, 4, FL_GEN, 4, 8>(k, npad, st);
+  return f_stats ? launch_rows<2, 4, 6, FL_STATS, 4, 8>(k, npad, st) : launch_rows<2, 4, 6, FL_GEN, 4, 8>(k, npad, st);
 }

@@ -39,7 +39,7 @@ def test_upsample_sum_argmax_and_histogram(dev):
     srt = np.sort(ref_sum, axis=1)
     margin = srt[:, -1] - srt[:, -2]
     diff = got != ref
-    assert diff.sum() <= 2 and np.all(margin[diff] < 1e-5), f"{diff.sum()} mismatches, margins {margin[diff]}"
+    assert diff.sum() <= 2 and np.all(margin[diff] < 5e-5), f"{diff.sum()} mismatches, margins {margin[diff]}"
     # single scale
     L.call("simt_upsample_sum_argmax", ops._p(a_d), 13, 21, 32, None, 0, 0, 0, B, H, W, C, ops._p(pred), ops.stream_ptr())
     ref1 = F.interpolate(la, size=(H, W), mode="bilinear", align_corners=True).argmax(1).numpy()
@@ -143,7 +143,9 @@ def test_upsample_sum_argmax_at_cityscapes_resolution(dev):
     srt = np.sort(ref_sum, axis=1)
     margin = srt[:, -1] - srt[:, -2]
     diff = got != ref
-    assert diff.sum() <= 20 and np.all(margin[diff] < 1e-5), f"{diff.sum()} mismatches of {got.size}, margins {margin[diff][:5]}"
+    # arg-max of fp32 sums: only near-ties may differ (margin below ~40 ulp of sums of magnitude 10: the two bilinear terms are rounded in a
+    # different order than torch's; which way a tie falls changes with the compiler's fma contraction)
+    assert diff.sum() <= 20 and np.all(margin[diff] < 5e-5), f"{diff.sum()} mismatches of {got.size}, margins {margin[diff][:5]}"
     gt = torch.randint(0, C, (B, H, W), generator=g)
     gt[torch.rand(B, H, W, generator=g) < 0.1] = 255
     hist = torch.zeros(C * C, device=dev, dtype=torch.int64)
