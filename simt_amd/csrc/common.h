@@ -57,10 +57,10 @@ __device__ __forceinline__ void store8(float* p, const float* v) {
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float* v) {
   uint4 r;
-  r.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-  r.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-  r.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-  r.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  r.x = pack_bf16x2(v[0], v[1]);
+  r.y = pack_bf16x2(v[2], v[3]);
+  r.z = pack_bf16x2(v[4], v[5]);
+  r.w = pack_bf16x2(v[6], v[7]);
   *(uint4*)p = r;
 }
 

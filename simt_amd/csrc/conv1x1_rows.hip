@@ -25,12 +25,12 @@
 
 namespace {
 
-constexpr int TN = 2;                                // 16-channel blocks per compute wave (32 output channels per wave)
 
 // NCW compute waves (each 32 output channels: BN = 32 * NCW per workgroup) + NSW store waves.  <8, 4>: one 768-thread workgroup per CU;
 // <4, 2>: two 384-thread workgroups per CU, which drift apart so that one's store phase overlaps the other's MFMA phase.
-template <int KS, int TM, int D, int NSW, int NCW> struct Geo {
-  static constexpr int NC = NCW * 64, BN = NCW * 32;
+// TN: 16-channel blocks per compute wave (weights per wave: TN x Cin/32 x 4 registers -- 2 up to Cin = 256, 1 for Cin = 512).
+template <int KS, int TM, int D, int NSW, int NCW, int TN> struct Geo {
+  static constexpr int NC = NCW * 64, BN = NCW * TN * 16;
   static constexpr int CP = BN * 2 + 16;             // slab pitch (bytes): 4 * odd dwords, conflict-free for the accumulator writes
   static constexpr int VPR = BN / 8;                 // 16-byte pieces per output row
   static constexpr int NS = NSW * 64, NT = NC + NS;
@@ -78,9 +78,10 @@ __device__ __forceinline__ void unpack8(const uint4& q, float* v) {
 struct Aux { uint4 res, by; unsigned rbits, ybits; };
 enum { FL_GEN = 0, FL_GEN_AUX = 1, FL_STATS = 2, FL_BRR = 3, FL_BNR = 4 };
 
-template <int KS, int TM, int D, int FL, int NSW, int NCW>
+template <int KS, int TM, int D, int FL, int NSW, int NCW, int TN>
 __global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
-  using g = Geo<KS, TM, D, NSW, NCW>;
+  using g = Geo<KS, TM, D, NSW, NCW, TN>;
+  constexpr int WCOLS = TN * 16;                               // output channels per compute wave
   constexpr int RGS = g::RGS, NS = g::NS, NC = g::NC, BN = g::BN, CP = g::CP, VPR = g::VPR;
   // Epilogue flavour, fixed at compile time for the three the nets use (the store waves share their SIMDs with the MFMA waves: every
   // instruction they do not execute is MFMA time): FL_STATS = store + BatchNorm batch statistics (conv3, training forward), FL_BRR =
@@ -127,7 +128,7 @@ __global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
-        wf[j][ks] = *(const bf16x8*)(a.w + (size_t)(n0 + wave * 32 + j * 16 + (lane & 15)) * (unsigned)a.wrow_bytes + (ks * 32 + (lane >> 4) * 8) * 2);
+        wf[j][ks] = *(const bf16x8*)(a.w + (size_t)(n0 + wave * WCOLS + j * 16 + (lane & 15)) * (unsigned)a.wrow_bytes + (ks * 32 + (lane >> 4) * 8) * 2);
     // LDS-DMA pieces of this thread: linear LDS position p = q * NC + tid -> sub-tile kc = p / (RS * 8), row = (p / 8) % RS, chunk = p % 8
     unsigned pconst[g::PT], pmax[g::PT], pzero[g::PT];         // byte offset of the piece inside a stage / last valid offset / its place in the zero page
 #pragma unroll
@@ -156,8 +157,8 @@ __global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2
     };
     const int sw = (lane >> 1) & 7, kq = lane >> 4;
     const int xrow = (lane & 15) * 128;
-    // accumulator -> slab addresses (LDS byte addresses): pixel i * 16 + (lane & 15), channels wave * 32 + j * 16 + (lane >> 4) * 4
-    const unsigned sl_addr = (unsigned)(size_t)LPTR(slab + (lane & 15) * CP + (wave * 32 + (lane >> 4) * 4) * 2);
+    // accumulator -> slab addresses (LDS byte addresses): pixel i * 16 + (lane & 15), channels wave * WCOLS + j * 16 + (lane >> 4) * 4
+    const unsigned sl_addr = (unsigned)(size_t)LPTR(slab + (lane & 15) * CP + (wave * WCOLS + (lane >> 4) * 4) * 2);
 #pragma unroll
     for (int s = 0; s < D - 1; ++s) if (s < S_total) issue(s);
     int slot_c = 0, slot_i = D - 1;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2
         float t1[4], t2[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { t1[e] = row16_sum(cs1[j][e]); t2[e] = row16_sum(cs2[j][e]); cs1[j][e] = 0.f; cs2[j][e] = 0.f; }
-        const int nn = n0 + wave * 32 + j * 16 + (lane >> 4) * 4;
+        const int nn = n0 + wave * WCOLS + j * 16 + (lane >> 4) * 4;
         if ((lane & 15) == 0 && nn < a.Cout) {                 // Cout % 4 == 0 (host)
           *(float4*)(a.stats + ((long)mt * 2 + 0) * a.Cout + nn) = make_float4(t1[0], t1[1], t1[2], t1[3]);
           *(float4*)(a.stats + ((long)mt * 2 + 1) * a.Cout + nn) = make_float4(t2[0], t2[1], t2[2], t2[3]);
@@ -583,21 +584,21 @@ __global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2
 #endif
 }
 
-template <int KS, int TM, int D, int FL, int NSW, int NCW>
+template <int KS, int TM, int D, int FL, int NSW, int NCW, int TN = 2>
 int launch_rows(Conv2KArgs k, int npad, hipStream_t st) {
-  using g = Geo<KS, TM, D, NSW, NCW>;
+  using g = Geo<KS, TM, D, NSW, NCW, TN>;
   k.rows = 128;
   k.ntiles_n = npad / g::BN;
   k.ntiles_m = (k.M + 127) / 128;
   const int nwg = k.ntiles_m * k.ntiles_n;
-  const int cap = NCW == 8 ? 256 : 512;                        // persistent: one (768 threads) or two (384 threads) workgroups per CU
+  const int cap = NCW == 8 ? 256 : 512;                        // persistent: one or two (NCW = 4: 384 threads) workgroups per CU
   const int G = nwg < cap ? nwg : cap;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv1x1_rows_kernel<KS, TM, D, FL, NSW, NCW>, hipFuncAttributeMaxDynamicSharedMemorySize, g::LDS);
+    (void)hipFuncSetAttribute((const void*)conv1x1_rows_kernel<KS, TM, D, FL, NSW, NCW, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, g::LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv1x1_rows_kernel<KS, TM, D, FL, NSW, NCW>), dim3(G), dim3(g::NT), g::LDS, st, k, G);
+  hipLaunchKernelGGL((conv1x1_rows_kernel<KS, TM, D, FL, NSW, NCW, TN>), dim3(G), dim3(g::NT), g::LDS, st, k, G);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
@@ -615,8 +616,8 @@ bool simt_conv_rows_eligible(const simt_conv_desc* d) {
   if (d->dtype_in != SIMT_BF16 || d->dtype_out != SIMT_BF16 || d->ntaps != 1 || d->dy[0] != 0 || d->dx[0] != 0) return false;
   if (d->stride != 1 || d->H != d->Ho || d->W != d->Wo) return false;          // dense pixel rows
   if (d->mask || (d->bnr_mode != 0 && d->bnr_mode != 3)) return false;         // fused BN-backward reduce: bit-mask flavour only
-  if (d->Cin != 64 && d->Cin != 128 && d->Cin != 256) return false;
-  if (d->Cin != 256 && (d->res || d->bnr_mode)) return false;                  // the 64-row-stage variants spill with the aux operands
+  if (d->Cin != 64 && d->Cin != 128 && d->Cin != 256 && d->Cin != 512) return false;
+  if (d->Cin == 512 && d->bnr_mode) return false;                              // measured: 214 us here vs 203 us on conv_igemm2_kernel<128, 4, 2>
   if (d->Npad % 256 != 0) return false;
   const long M = (long)d->B * d->Ho * d->Wo, lim = 1l << 32;                   // 32-bit byte offsets in the store waves
   if (M * d->ldy * 2 >= lim || (d->res && M * d->ldr * 2 >= lim) || (d->bnr_mode && M * d->bnr_ld * 2 >= lim)) return false;
@@ -641,6 +642,21 @@ int simt_conv_rows_launch(Conv2KArgs k, int npad, hipStream_t st) {
     if (f_bnr) return launch_rows<8, 2, D256, FL_BNR, SW, CW>(k, npad, st);
     return aux ? launch_rows<8, 2, 6, FL_GEN_AUX, 4, 8>(k, npad, st) : launch_rows<8, 2, 6, FL_GEN, 4, 8>(k, npad, st);
   }
-  if (cin == 128) return f_stats ? launch_rows<4, 4, 4, FL_STATS, 4, 8>(k, npad, st) : launch_rows<4, 4, 4, FL_GEN, 4, 8>(k, npad, st);
-  return f_stats ? launch_rows<2, 4, 6, FL_STATS, 4, 8>(k, npad, st) : launch_rows<2, 4, 6, FL_GEN, 4, 8>(k, npad, st);
+  if (cin == 512) {                                            // 16 channels per wave: 128-column workgroups, 8 + 2 waves
+    if (f_stats) return launch_rows<16, 2, 3, FL_STATS, 2, 8, 1>(k, npad, st);
+    if (f_brr) return launch_rows<16, 2, 3, FL_BRR, 2, 8, 1>(k, npad, st);
+    return aux ? launch_rows<16, 2, 3, FL_GEN_AUX, 2, 8, 1>(k, npad, st) : launch_rows<16, 2, 3, FL_GEN, 2, 8, 1>(k, npad, st);
+  }
+  // Cin 128 / 64: 64-row stages without global epilogue operands; with them 32-row stages (the operands of a 64-row slab do not fit
+  // the store waves' registers), for Cin = 64 as two 384-thread workgroups per CU (a 32-row stage is only 4 KB)
+  if (cin == 128) {
+    if (f_stats) return launch_rows<4, 4, 4, FL_STATS, 4, 8>(k, npad, st);
+    if (f_brr) return launch_rows<4, 2, 6, FL_BRR, 4, 8>(k, npad, st);
+    if (f_bnr) return launch_rows<4, 2, 6, FL_BNR, 4, 8>(k, npad, st);
+    return aux ? launch_rows<4, 2, 6, FL_GEN_AUX, 4, 8>(k, npad, st) : launch_rows<4, 4, 4, FL_GEN, 4, 8>(k, npad, st);
+  }
+  if (f_stats) return launch_rows<2, 4, 6, FL_STATS, 4, 8>(k, npad, st);
+  if (f_brr) return launch_rows<2, 2, 6, FL_BRR, 2, 4>(k, npad, st);
+  if (f_bnr) return launch_rows<2, 2, 6, FL_BNR, 2, 4>(k, npad, st);
+  return aux ? launch_rows<2, 2, 6, FL_GEN_AUX, 2, 4>(k, npad, st) : launch_rows<2, 4, 6, FL_GEN, 4, 8>(k, npad, st);
 }

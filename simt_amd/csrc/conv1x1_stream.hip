@@ -185,8 +185,8 @@ __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int
           const int r = wm * TM * 16 + i * 16 + (lane & 15);
           const int c = wn * TN * 16 + j * 16 + (lane >> 4) * 4;
           uint2 pk;
-          pk.x = (uint32_t)f2bf(acc[j][i][0]) | ((uint32_t)f2bf(acc[j][i][1]) << 16);
-          pk.y = (uint32_t)f2bf(acc[j][i][2]) | ((uint32_t)f2bf(acc[j][i][3]) << 16);
+          pk.x = pack_bf16x2(acc[j][i][0], acc[j][i][1]);
+          pk.y = pack_bf16x2(acc[j][i][2], acc[j][i][3]);
           // written by inline asm: for a C++ LDS store the compiler first drains vmcnt to 0 (it assumes the store may alias an LDS-DMA
           // in flight), i.e. it would wait here for the next tile's first two stages
           const unsigned addr = (unsigned)(size_t)LPTR(sC + r * CP + c * 2);
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int
         if (!plain) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) { v[e] += bias8[e]; if (a.relu) v[e] = v[e] > 0.f ? v[e] : 0.f; }
-          o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-          o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+          o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+          o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
         }
       }
 #if !(SIMT_STREAM_ABL & 2)

@@ -351,8 +351,8 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
       const int r = wm * TM * 16 + i * 16 + (lane & 15);
       const int c = wn * TN * 16 + j * 16 + (lane >> 4) * 4;
       uint2 pk;
-      pk.x = (uint32_t)f2bf(acc[j][i][0]) | ((uint32_t)f2bf(acc[j][i][1]) << 16);
-      pk.y = (uint32_t)f2bf(acc[j][i][2]) | ((uint32_t)f2bf(acc[j][i][3]) << 16);
+      pk.x = pack_bf16x2(acc[j][i][0], acc[j][i][1]);
+      pk.y = pack_bf16x2(acc[j][i][2], acc[j][i][3]);
       *(uint2*)(sC + r * CP + c * 2) = pk;
     }
   struct Aux { uint4 res, by; unsigned rbits, ybits; };   // by: saved activation (bnr) or ReLU mask operand (VGG): exclusive

@@ -63,15 +63,21 @@ CONV_CASES = [
     ("l3.conv1 1024->256 + stats", B4, HW, HW, 1024, 256, 1, 1, 1, "stats", (256, 5, 3)),
     ("l3.conv3 dgrad 1024->256 + bnr2", B4, HW, HW, 1024, 256, 1, 1, 1, "bnr2", (256, 5, 3)),
     ("l4.conv1 2048->512", B4, HW, HW, 2048, 512, 1, 1, 1, "stats", (256, 5, 3)),
-    ("l4.conv3 512->2048", B4, HW, HW, 512, 2048, 1, 1, 1, "stats", STREAM),
+    ("l4.conv3 512->2048", B4, HW, HW, 512, 2048, 1, 1, 1, "stats", ROWS),
+    ("fixed l4.conv3 512->2048 bias+res+relu", B4, HW, HW, 512, 2048, 1, 1, 1, "bias_res_relu", ROWS),
+    ("l4.conv1 dgrad 512->2048 + res_bits + bnr3", B4, HW, HW, 512, 2048, 1, 1, 1, "res_bits_bnr3", (128, 4, 2)),
     ("l4.0.downsample 1024->2048", B4, HW, HW, 1024, 2048, 1, 1, 1, "stats", (256, 4, 3)),
     ("l4.0.downsample dgrad 2048->1024", B4, HW, HW, 2048, 1024, 1, 1, 1, "plain", (256, 4, 3)),
     ("l4.0.conv1 1024->512", B4, HW, HW, 1024, 512, 1, 1, 1, "stats", (256, 5, 3)),
     ("l2.conv3 128->512", B4, HW, HW, 128, 512, 1, 1, 1, "stats", ROWS),
+    ("fixed l2.conv3 128->512 bias+res+relu", B4, HW, HW, 128, 512, 1, 1, 1, "bias_res_relu", ROWS),
+    ("l2.conv1 dgrad 128->512 + res_bits + bnr3", B4, HW, HW, 128, 512, 1, 1, 1, "res_bits_bnr3", ROWS),
     ("l2.0.downsample 256->512 s2", B4, 193, 193, 256, 512, 1, 1, 2, "stats", STREAM),
     ("l2.conv2 3x3 128->128", B4, HW, HW, 128, 128, 3, 1, 1, "stats", (128, 5, 3)),
     ("l2.conv1 512->128", B4, HW, HW, 512, 128, 1, 1, 1, "stats", (128, 5, 3)),
     ("l1.conv3 64->256", B4, 193, 193, 64, 256, 1, 1, 1, "stats", ROWS),
+    ("fixed l1.conv3 64->256 bias+res+relu", B4, 193, 193, 64, 256, 1, 1, 1, "bias_res_relu", ROWS),
+    ("l1.conv1 dgrad 64->256 + res_bits + bnr3", B4, 193, 193, 64, 256, 1, 1, 1, "res_bits_bnr3", ROWS),
     ("l1.conv2 3x3 64->64", B4, 193, 193, 64, 64, 3, 1, 1, "stats", (64, 2, 3)),
     ("l1.conv1 256->64", B4, 193, 193, 256, 64, 1, 1, 1, "stats", (64, 2, 3)),
 ]
@@ -344,7 +350,7 @@ def test_full_depth_r101_bf16_forward_b4_768(dev):
     p = {k: v.clone().to(dev) for k, v in st.items()}
     ev = TrunkPlan(p, B, H, W, multi_heads(19, K, True), dtype=BF, train=False)
     tags = {it.tag for it in ev.fwd_list.items}
-    assert "conv_igemm2_kernel<256, 5, 3, 0, 0>" in tags and "conv_igemm2_kernel<128, 4, 2, 0, 0>" in tags
+    assert "conv_igemm2_kernel<256, 5, 3, 0, 0>" in tags and "conv1x1_rows_kernel" in tags
     out = ev.forward(img.to(dev))
     torch.cuda.synchronize()
     e1, e2 = _nchw(out["x1"], 22), _nchw(out["x2"], 22)

@@ -194,7 +194,8 @@ def test_v3_simt_iterations_fp32(dev):
         r32 = np.array([float(a[k].detach()) for k in KEYS])
         r64 = np.array([float(b[k].detach()) for k in KEYS])
         print(f"it {it}: gpu {got}\n      f32 {r32}\n      f64 {r64}")
-        bound = 5 * np.abs(r32 - r64) + 1e-4 * (1 + np.abs(r64)) if it == 0 else 5 * np.abs(r32 - r64) + 2e-2 * (1 + np.abs(r64))
+        # it 0: 2e-4 as in the VGG iteration test (a cross-entropy of 22 on the 4x-scaled classifiers)
+        bound = 5 * np.abs(r32 - r64) + (2e-4 if it == 0 else 2e-2) * (1 + np.abs(r64))
         assert np.all(np.abs(got - r64) <= bound), f"it {it}"
         np.testing.assert_allclose(got[4:6], r32[4:6], rtol=2e-5)                  # Convex, Volume: NTM algebra only
         if it == 0:
