@@ -96,10 +96,13 @@ __global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2
   // FL_STATS: the BatchNorm statistics are taken by the COMPUTE waves from the values they round for the slab (a compute wave owns its 32
   // channels for every pixel: per-lane partial sums over a 128-row tile, one 16-lane DPP reduction per tile, no LDS, no second pass over
   // the tile) -- the store waves are left with a pure LDS -> HBM copy.
-  constexpr bool CSTAT = FL == FL_STATS;
+#ifndef SIMT_ROWS_CSTAT
+#define SIMT_ROWS_CSTAT 1
+#endif
+  constexpr bool CSTAT = FL == FL_STATS && SIMT_ROWS_CSTAT;
   const bool has_bias = GEN ? a.bias != nullptr : FL == FL_BRR;
   const bool has_relu = GEN ? a.relu != 0 : FL == FL_BRR;
-  const bool has_stats = GEN ? a.stats != nullptr : false;      // statistics taken by the store waves (FL_STATS: by the compute waves)
+  const bool has_stats = GEN ? a.stats != nullptr : (FL == FL_STATS && !SIMT_ROWS_CSTAT);      // statistics taken by the store waves (FL_STATS: by the compute waves)
   const bool has_res = GEN ? (AUX && a.res != nullptr) : AUX;
   const bool has_rbits = GEN ? (AUX && a.res_bits != nullptr) : FL == FL_BNR;
   const bool has_bnr = GEN ? (AUX && a.bnr_mode != 0) : FL == FL_BNR;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2
       // LDS traffic of the compute waves is inline asm with hand-counted lgkmcnt: before a C++ LDS store the compiler drains vmcnt to 0 (it
       // must assume the store aliases an LDS-DMA in flight -- also with separate static LDS arrays), and around C++ LDS loads it waits
       // lgkmcnt(0) right after requesting the next fragments
-      asm volatile("ds_write_b64 %0, %1" :: "v"(sbase + (unsigned)(i * 16 * CP + j * 32)), "v"(pk));
+      asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(sbase), "v"(pk), "n"(i * 16 * CP + j * 32));
       if (CSTAT && !(SIMT_ROWS_ABL & 256)) {                   // statistics of the values as stored (bf16); rows past the end are exact zeros
         const float v0 = __uint_as_float(pk.x << 16), v1 = __uint_as_float(pk.x & 0xffff0000u);
         const float v2 = __uint_as_float(pk.y << 16), v3 = __uint_as_float(pk.y & 0xffff0000u);
@@ -233,12 +236,12 @@ __global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2
       constexpr int PF = TM == 2 ? 2 : 1;
       bf16x8 xf[PF + 1][TM];
       const unsigned st_addr = (unsigned)(size_t)LPTR(st);
-      auto frags = [&](int ks, bf16x8* f) {                    // request the pixel fragments of k-step ks (TM x ds_read_b128)
-        const unsigned ad = st_addr + (unsigned)((ks >> 1) * (g::RS * 128)) + (unsigned)(((4 * (ks & 1) + kq) ^ sw) << 4);
+      const unsigned ad01[2] = {st_addr + (unsigned)(((0 + kq) ^ sw) << 4), st_addr + (unsigned)(((4 + kq) ^ sw) << 4)};   // even / odd k-steps
+      auto frags = [&](int ks, bf16x8* f) {                    // request the pixel fragments of k-step ks (TM x ds_read_b128, immediate offsets)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          if (SIMT_ROWS_ABL & 128) asm volatile("" : "=v"(f[i]) : "v"(ad));
-          else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[i]) : "v"(ad), "n"(i * 16 * 128));
+          if (SIMT_ROWS_ABL & 128) asm volatile("" : "=v"(f[i]) : "v"(ad01[ks & 1]));
+          else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[i]) : "v"(ad01[ks & 1]), "n"((ks >> 1) * (g::RS * 128) + i * 16 * 128));
         }
       };
       auto landed = [&](bf16x8* f, int younger) {              // f is complete: everything but the `younger` most recent LDS operations has returned
