@@ -11,6 +11,7 @@
 // Stride-1 convolutions need no per-stage division for the tap-shifted source pixel: input pixel = m + dy*W + dx.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct Wgrad2KArgs {
   const char* dy;
@@ -137,23 +138,36 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
     offb[t] = (1 + (wn >> 1)) * SUB + (8 * g + q) * ROWB + ((((cbb >> 3) + (pp >> 1)) ^ hh) << 4) + (pp & 1) * 8;
   }
   bf16x8 af[2][4], bfr[2][4];
+  // The transposed fragment reads are inline asm with a hand-placed lgkmcnt wait: in front of the ds_read_tr builtin the compiler drains
+  // vmcnt to 0 (it cannot tell the read from an LDS-DMA in flight), i.e. every stage waited for ALL the loads just issued -- the ring
+  // never overlapped loads with MFMAs (round 1/2 measurements: product time = loads-only + MFMA-only).
+  auto trd = [](unsigned addr, auto off) {
+    bf16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(decltype(off)::value));
+    return r;
+  };
   auto load_frags = [&](int buf) {
-    const char* base = smem + buf * STAGE;
+    const unsigned base = (unsigned)(size_t)LPTR(smem + buf * STAGE);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const char* pa = base + ks * 32 * ROWB + offa[t];
-        const char* pb = base + ks * 32 * ROWB + offb[t];
-        bf4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)(pa));
-        bf4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)(pa + 4 * ROWB));
-        bf4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)(pb));
-        bf4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)(pb + 4 * ROWB));
-        bf16x4 a0s = __builtin_bit_cast(bf16x4, a0), a1s = __builtin_bit_cast(bf16x4, a1);
-        bf16x4 b0s = __builtin_bit_cast(bf16x4, b0), b1s = __builtin_bit_cast(bf16x4, b1);
-        af[ks][t] = (bf16x8){a0s[0], a0s[1], a0s[2], a0s[3], a1s[0], a1s[1], a1s[2], a1s[3]};
-        bfr[ks][t] = (bf16x8){b0s[0], b0s[1], b0s[2], b0s[3], b1s[0], b1s[1], b1s[2], b1s[3]};
+    for (int t = 0; t < 4; ++t) {
+      const unsigned pa = base + (unsigned)offa[t], pb = base + (unsigned)offb[t];
+      {
+        const bf16x4 a0 = trd(pa, std::integral_constant<int, 0>{}), a1 = trd(pa, std::integral_constant<int, 4 * ROWB>{});
+        const bf16x4 b0 = trd(pb, std::integral_constant<int, 0>{}), b1 = trd(pb, std::integral_constant<int, 4 * ROWB>{});
+        af[0][t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        bfr[0][t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
       }
+      {
+        const bf16x4 a0 = trd(pa, std::integral_constant<int, 32 * ROWB>{}), a1 = trd(pa, std::integral_constant<int, 36 * ROWB>{});
+        const bf16x4 b0 = trd(pb, std::integral_constant<int, 32 * ROWB>{}), b1 = trd(pb, std::integral_constant<int, 36 * ROWB>{});
+        af[1][t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        bfr[1][t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    }
+  };
+  auto frags_landed = [&]() {                                  // every fragment read has returned; the MFMAs depend on these statements
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]));
+    asm volatile("" : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[0][2]), "+v"(bfr[0][3]), "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(bfr[1][2]), "+v"(bfr[1][3]));
   };
   auto mma = [&]() {
 #pragma unroll
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
       asm volatile("" ::: "memory");
       if (MODE != 1) load_frags(buf);                     // fragment reads first: their latency gates the MFMAs
       if (MODE != 2 && kt + 2 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
-      if (MODE != 1) mma();
+      if (MODE != 1) { frags_landed(); mma(); }
       buf = (buf + 1 == NST) ? 0 : buf + 1;
     }
   } else {
@@ -186,12 +200,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (MODE != 1 && kt > 0) mma();
+      if (MODE != 1 && kt > 0) { frags_landed(); mma(); }
       if (MODE != 2 && kt + 2 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
       if (MODE != 1) load_frags(buf);
       buf = (buf + 1 == NST) ? 0 : buf + 1;
     }
-    if (MODE != 1 && nk > 0) mma();
+    if (MODE != 1 && nk > 0) { frags_landed(); mma(); }
   }
 
   // slab[split][co][k]: the X columns are the MFMA's row operand, so every accumulator quad is 4 consecutive k of one dY

@@ -87,7 +87,8 @@ def side_stream(device=None):
     if os.environ.get("SIMT_SINGLE_STREAM") == "1":     # profiling aid: serial schedule, per-kernel durations without CU sharing
         return torch.cuda.current_stream(dev)
     if dev not in _SIDE_STREAMS:
-        _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        prio = int(os.environ.get("SIMT_SIDE_PRIORITY", "0"))
+        _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=prio)
     return _SIDE_STREAMS[dev]
 
 
@@ -98,13 +99,14 @@ class LaunchList:
         self.items = []
         self.graph = None
 
-    def capture(self):
+    def capture(self, warm=True):
         """Capture the whole list (both streams, with its fork/join events) into one hipGraph: run() then costs one graph
         launch instead of len(self) host calls -- what the launch-bound plans (DeepLabv3 at 512x1024: ~450 launches of
         ~15 us) need.  Every buffer and descriptor is preallocated, so the captured kernel arguments stay valid; the list
         is replayed once eagerly first so that lazily created workspaces exist before capture."""
         self.graph = None
-        self.run()
+        if warm:
+            self.run()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):

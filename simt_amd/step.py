@@ -80,8 +80,25 @@ class SimTTrainer:
         self.fixed = TrunkPlan(self.fixed_params, B, H, W, multi_heads(Cn, 0, False), dtype=dtype, train=False,
                                stem_from=self.plan, **kw)
         assert self.plan.fwd_list.items[0].tag == "simt_im2col_stem"
+        import os
+        # hipGraphs of the three launch lists (frozen forward, trainable forward, backward with its two streams): the host spends
+        # ~18 us per eager launch (ctypes + Python), ~1 000 launches per step -- most of a 28 ms step, and the ORDER in which the two
+        # streams' launches reach the GPU was the host's, not the plan's.  SIMT_GRAPHS=0 keeps eager launches (needed by nothing;
+        # the data-parallel backward with its per-bucket hooks stays eager by construction).
+        self._fixed_graph = False
+        # SIMT_GRAPHS: -1 (default) eager launches; 0 frozen forward as a hipGraph, 1 + trainable forward, 2 + backward (measured: 27.6 /
+        # 27.7 / 27.7 / 29.9 ms per step -- the graph executor runs the two-stream backward worse than the eager streams do)
+        self._graph_level = int(os.environ.get("SIMT_GRAPHS", "-1"))
+        self._graphs = self._graph_level >= 0 and torch.device(dev).type == "cuda"
+        self._steps_run = 0
+        self._main_hi = os.environ.get("SIMT_MAIN_PRIORITY", "0") == "1"
+        # host enqueue order of the two forwards (both reach the GPU within ~2 ms; the hardware then favours the queue that was fed
+        # first): "main" = trainable first (default), "side" = frozen first, "interleave" = one list alternating 1:1
+        self._fwd_order = os.environ.get("SIMT_FWD_ORDER", "main")
+        self._hi_stream = None
         self._fwd_rest = LaunchList()
         self._fwd_rest.items = self.plan.fwd_list.items[1:]
+        self._fwd_both = None                      # built on first use (needs self.fixp): both forwards interleaved, see _micro_batch
         h, w = self.plan.heads[1].h, self.plan.heads[1].w
         self.h, self.w = h, w
         Q = self.Q
@@ -195,31 +212,106 @@ class SimTTrainer:
         if rc != 0:
             L.check(rc)
         # 2. frozen model -> low-res posterior, on the side stream: its eval-mode convs share the CUs with the HBM-bound
-        #    BatchNorm passes of the trainable forward (3.) instead of running before it
-        main = torch.cuda.current_stream()
-        side = side_stream(self.dev)
-        ev_in = torch.cuda.Event()
-        ev_in.record(main)
-        with torch.cuda.stream(side):
-            side.wait_event(ev_in)
-            self.fixed.forward()
-            ops.softmax_rows(self.fixed.out["x2"], self.ldf, self.fixp, self.ldf, self.B * self.h * self.w, self.C)
-            ev_fix = torch.cuda.Event()
-            ev_fix.record(side)
-        # 3. trainable forward (its im2col already ran above)
-        self._fwd_rest.run()
-        main.wait_event(ev_fix)
+        #    BatchNorm passes of the trainable forward (3.) instead of running before it.  The host enqueues ~350 launches per forward
+        #    at ~5 us each, so the ORDER of the two enqueue loops matters: the trainable forward (critical path) goes first -- enqueued
+        #    second, its first conv reached the GPU 3.6 ms into the step (rocprofv3 kernel trace) -- and the frozen forward is one
+        #    hipGraph launch when SIMT_FIXED_GRAPH != 0.
+        order = self._fwd_order
+        if self._fixed_graph or order != "interleave":
+            main = torch.cuda.current_stream()
+            side = side_stream(self.dev)
+            ev_in = torch.cuda.Event()
+            ev_in.record(main)
+
+            def frozen():
+                with torch.cuda.stream(side):
+                    side.wait_event(ev_in)
+                    self.fixed.forward()
+                    ops.softmax_rows(self.fixed.out["x2"], self.ldf, self.fixp, self.ldf, self.B * self.h * self.w, self.C)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                return ev
+            if self._fixed_graph or order == "side":
+                ev_fix = frozen()
+                self._fwd_rest.run()               # 3. trainable forward (its im2col already ran above)
+            else:
+                self._fwd_rest.run()
+                ev_fix = frozen()
+            main.wait_event(ev_fix)
+        else:
+            # ONE list with the launches of the two forwards interleaved 1:1
+            if self._fwd_both is None:
+                self._fwd_both = self._interleaved_forwards()
+            self._fwd_both.run()
         # 4. fused head + NTM regularisers + gradients of the low-res logits (every term scaled by 1 / iter_size, :427;
         #    the NTM gradients accumulate on top of the inner loop's leak and of earlier micro-batches)
         L.call("simt_head_loss", C.byref(self.head_desc), st)
         L.call("simt_ntm_post", C.byref(self.post_desc), st)
         L.call("simt_head_grad", C.byref(self.head_desc), st)
 
+    def _interleaved_forwards(self):
+        """fwd_rest (main stream) and the frozen forward + its soft-max (side stream) as one launch list, alternating."""
+        from .engine import _Launch
+        lib = L.load()
+        both = LaunchList()
+        ev_in = both.record(0)
+        both.wait(ev_in, 1)
+        a = list(self._fwd_rest.items)
+        b = []
+        for it in self.fixed.fwd_list.items:
+            assert it.stream == 0 and it.fn is not None
+            b.append(_Launch(it.fn, it.args, it.keep, it.tag, it.flops, it.bytes, it.shape, stream=1))
+        b.append(_Launch(lib.simt_softmax_rows, (ops._p(self.fixed.out["x2"]), self.ldf, ops._p(self.fixp), self.ldf, self.B * self.h * self.w,
+                                                 self.C), (self.fixed.out["x2"], self.fixp), "simt_softmax_rows", stream=1))
+        assert all(it.stream == 0 for it in a)
+        i = j = 0
+        while i < len(a) or j < len(b):
+            if j < len(b):
+                both.items.append(b[j]); j += 1
+            if i < len(a):
+                both.items.append(a[i]); i += 1
+        ev_fix = both.record(1)
+        both.wait(ev_fix, 0)
+        return both
+
+    def _capture_graphs(self):
+        """Record (not run) the three launch lists into hipGraphs, once, after the first eager step created every workspace."""
+        self._graphs = False
+        try:
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side_stream(self.dev)):
+                self.fixed.fwd_list.capture(warm=False)
+            if self._graph_level >= 1:
+                self._fwd_rest.capture(warm=False)
+            if self.reducer is None and self._graph_level >= 2:
+                self.plan.bwd_list.capture(warm=False)
+            self._fixed_graph = True
+        except Exception as e:                     # capture is an optimisation of the host side only
+            self.fixed.fwd_list.graph = self._fwd_rest.graph = self.plan.bwd_list.graph = None
+            self._fixed_graph = False
+            print(f"[simt] hipGraph capture failed ({e}); eager launches", flush=True)
+
     def step(self, image, label, it=None):
+        """Runs _step (below); with SIMT_MAIN_PRIORITY=1 on a high-priority HIP stream ordered after / before the caller's stream."""
+        if not self._main_hi:
+            return self._step(image, label, it)
+        caller = torch.cuda.current_stream()
+        if self._hi_stream is None:
+            self._hi_stream = torch.cuda.Stream(device=self.dev, priority=-1)
+        self._hi_stream.wait_stream(caller)
+        with torch.cuda.stream(self._hi_stream):
+            out = self._step(image, label, it)
+        caller.wait_stream(self._hi_stream)
+        return out
+
+    def _step(self, image, label, it=None):
         """image [B,3,H,W] fp32 (device or host), label [B,H,W] int64 -- or, with hp.iter_size > 1 (gradient accumulation,
         trainV2_simt.py:341-432), sequences of iter_size micro-batches.  Returns the device tensor `lout`
         (total, loss_p1, loss_p2, loss_y1, loss_y2, Place, Convex, Volume, Anchor, vol_ok, ...) of the last micro-batch."""
         hp = self.hp
+        if self._graphs and self._steps_run >= 1:
+            self._capture_graphs()
+        self._steps_run += 1
         it = self.it_done if it is None else it
         lr = lr_poly(hp.lr, it, hp.num_steps, hp.power)
         lr_T = lr_poly(hp.lr_T, it, hp.num_steps, hp.power)
