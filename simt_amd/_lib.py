@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsimt_hip.so")
+LIB_PATH = os.environ.get("SIMT_LIB_PATH") or os.path.join(_HERE, "libsimt_hip.so")      # SIMT_LIB_PATH: A/B a scratch build (measurements only)
 
 SIMT_F32, SIMT_BF16 = 0, 1
 MAX_TAPS = 36

@@ -84,33 +84,52 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
   const char* zsrc = a.zero + c_pos * 16;
 
   int ld_m = m_begin;
+  // Stride-1 convolutions (all but the downsample / stem ones): the source of output pixel m under tap (dy, dx) is pixel m + dy*W + dx,
+  // valid iff (oy + dy, ox + dx) is inside the image.  (oy, ox) of this thread's two rows advance by 64 pixels per stage: one division
+  // before the loop instead of two fast_divmod per row and stage (the issue phase is what the partner wave's MFMA shadow has to hide).
+  int r_oy[2], r_ox[2];
+  unsigned r_xo[2], r_do[2];                                   // running byte offsets of the row's pixel in x / dy
+  const int adv_y = BP / a.Wo, adv_x = BP % a.Wo;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m_begin + i * 32 + row_in_iter;
+    int b, r;
+    fast_divmod(m < a.M ? m : 0, HoWo, a.rcpHoWo, b, r);
+    fast_divmod(r, a.Wo, a.rcpWo, r_oy[i], r_ox[i]);
+    r_xo[i] = (unsigned)m * (unsigned)pix_bytes;
+    r_do[i] = (unsigned)m * (unsigned)ldd_bytes + (unsigned)(dch * 2);
+  }
+  const unsigned x_step = (unsigned)BP * (unsigned)pix_bytes, d_step = (unsigned)BP * (unsigned)ldd_bytes;
   auto issue = [&](int buf) {
     char* sbase = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int m = ld_m + i * 32 + row_in_iter;
       const bool mok = m < m_end;
-      const char* srcd = (mok && d_ok) ? a.dy + ((unsigned)m * (unsigned)ldd_bytes + (unsigned)(dch * 2)) : zsrc;
-      int oy = 0, ox = 0, b = 0;
-      if (!(s1 && center[0] && center[1])) {
-        int r;
+      const char* srcd;
+      const char* srcx[2];
+      if (s1) {
+        srcd = (mok && d_ok) ? a.dy + r_do[i] : zsrc;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const bool in = (unsigned)(r_oy[i] + tdy[s]) < (unsigned)a.H && (unsigned)(r_ox[i] + tdx[s]) < (unsigned)a.W;
+          srcx[s] = (mok && k_ok[s] && in) ? a.x + (r_xo[i] + (unsigned)xoff[s]) : zsrc;
+        }
+        r_do[i] += d_step; r_xo[i] += x_step;
+        r_oy[i] += adv_y; r_ox[i] += adv_x;
+        if (r_ox[i] >= a.Wo) { r_ox[i] -= a.Wo; r_oy[i] += 1; }
+        if (r_oy[i] >= a.Ho) r_oy[i] -= a.Ho;                  // next image: the offsets simply run on
+      } else {
+        srcd = (mok && d_ok) ? a.dy + ((unsigned)m * (unsigned)ldd_bytes + (unsigned)(dch * 2)) : zsrc;
+        int b, r, oy, ox;
         fast_divmod(m, HoWo, a.rcpHoWo, b, r);
         fast_divmod(r, a.Wo, a.rcpWo, oy, ox);
-      }
-      const char* srcx[2];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        srcx[s] = zsrc;
-        if (mok && k_ok[s]) {
-          if (s1) {
-            const int iy = oy + tdy[s], ix = ox + tdx[s];
-            if (center[s] || (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W))
-              srcx[s] = a.x + (unsigned)((unsigned)m * (unsigned)pix_bytes + (unsigned)xoff[s]);
-          } else {
-            const int iy = oy * a.stride + tdy[s], ix = ox * a.stride + tdx[s];
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-              srcx[s] = a.x + ((unsigned)((b * a.H + iy) * a.W + ix) * (unsigned)pix_bytes + (unsigned)(xoff[s] - (tdy[s] * a.W + tdx[s]) * pix_bytes));
-          }
+        for (int s = 0; s < 2; ++s) {
+          srcx[s] = zsrc;
+          const int iy = oy * a.stride + tdy[s], ix = ox * a.stride + tdx[s];
+          if (mok && k_ok[s] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+            srcx[s] = a.x + ((unsigned)((b * a.H + iy) * a.W + ix) * (unsigned)pix_bytes + (unsigned)(xoff[s] - (tdy[s] * a.W + tdx[s]) * pix_bytes));
         }
       }
       const int ldsoff = (i * NT + wave * 64) * 16;
