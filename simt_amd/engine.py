@@ -267,8 +267,19 @@ class TrunkPlan:
         if train:
             self._alloc_grads(grad_names)
             self._build_backward()
+        self._pack_items_raw = list(self.pack_list.items)          # before coalescing: pack_subset() filters these
         self._pack_tables = self.pack_list.coalesce_packs(self.dev)
         self.repack()
+
+    def pack_subset(self, names):
+        """A launch list that refreshes only the packed operands of the parameters `names` (plus every non-weight entry of the pack
+        list: bias sums, BN folds) -- for a stage whose optimiser updates part of the model (SimT: layer3, layer4, heads)."""
+        ptrs = {self.p[n].data_ptr() for n in names}
+        lib = L.load()
+        sub = LaunchList()
+        sub.items = [it for it in self._pack_items_raw if it.fn is not lib.simt_pack_weight or it.args[0] in ptrs]
+        sub._tables = sub.coalesce_packs(self.dev)
+        return sub
 
     # ------------------------------------------------------------------ buffers
     def buf(self, role, *shape, dtype=None, zero=False):

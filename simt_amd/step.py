@@ -159,6 +159,14 @@ class SimTTrainer:
         # ---- SGD segments (duplicate listings replayed in registers)
         self._build_sgd()
         self.it_done = 0
+        # ---- early optimiser step: the gradients SGD applies (layer3, layer4, heads) are final long before the backward has walked
+        # through layer2 / layer1 / the stem (whose gradients this stage computes but never applies), so SGD and the re-pack of the
+        # updated weights run on the side stream from that point on instead of after the backward (0.7 ms of exclusive tail).
+        applied = [n for n in self.sgd_names if self.plan.grad_ready.get(n, 0) > 0]
+        self._early_cut = max(self.plan.grad_ready[n] for n in applied) if applied else None
+        self._early_sgd = (os.environ.get("SIMT_EARLY_SGD", "1") != "0" and self._early_cut is not None and process_group is None
+                           and hp.iter_size == 1 and self._early_cut < len(self.plan.bwd_list.items))
+        self._pack_applied = self.plan.pack_subset(self.sgd_names) if self._early_sgd else None
         # ---- data parallel: bucketed mean all-reduce overlapped with backward
         self._grad_acc = torch.zeros_like(self.plan.flat_grad) if hp.iter_size > 1 else None
         self.reducer = None
@@ -342,6 +350,9 @@ class SimTTrainer:
                 self.plan.backward(hook=self.reducer.ready_upto)
                 self.reducer.finish()
                 continue
+            if self._early_sgd:
+                self._backward_early_sgd(lr, st)
+                continue
             self.plan.backward()
             if hp.iter_size > 1:      # loss.backward() accumulates into .grad (:428): keep the running sum beside the plan's buffer
                 if mi == 0:
@@ -354,16 +365,41 @@ class SimTTrainer:
                         self.reducer.start()
                         self.reducer.finish()
         # 7. optimisers
-        d = self.sgd_desc
-        d.lr[0], d.lr[1] = lr, lr * 10.0
-        d.wd[0], d.wd[1] = hp.weight_decay, hp.weight_decay
-        d.first_step = 1 if self.it_done == 0 else 0
-        L.call("simt_sgd_multi", C.byref(d), st)
+        if not self._early_sgd:
+            self._sgd(lr, st)
         for k in range(2):
             ops.adam_step(self.ntm[k], self.ntm_grad[k], self.ntm_m[k], self.ntm_v[k], lr=lr_T, step=self.it_done + 1)
-        self.plan.repack()
+        if not self._early_sgd:
+            self.plan.repack()
         self.it_done += 1
         return self.lout
+
+    def _sgd(self, lr, st):
+        d = self.sgd_desc
+        d.lr[0], d.lr[1] = lr, lr * 10.0
+        d.wd[0], d.wd[1] = self.hp.weight_decay, self.hp.weight_decay
+        d.first_step = 1 if self.it_done == 0 else 0
+        L.call("simt_sgd_multi", C.byref(d), st)
+
+    def _backward_early_sgd(self, lr, st):
+        """Backward with the SGD step and the re-pack of the updated layers enqueued on the side stream as soon as the last applied
+        gradient has been enqueued.  The side stream first waits for the main stream's launches up to that point (the dgrad convs of
+        layer3 read the packed weights the re-pack overwrites); the list's final join makes the main stream wait for all of it."""
+        main, side = torch.cuda.current_stream(), side_stream(self.dev)
+        done = [False]
+
+        def hook(n, ev):
+            if done[0] or n < self._early_cut:
+                return
+            done[0] = True
+            ev_main = torch.cuda.Event()
+            ev_main.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_main)
+                self._sgd(lr, side.cuda_stream)
+                self._pack_applied.run()
+        self.plan.backward(hook=hook)
+        assert done[0]
 
     def state_dict(self):
         """Host copy of the trainable model's state (the reference's `model.state_dict()` of :449,461): every key, NCHW fp32, with

@@ -80,6 +80,14 @@ CONV_CASES = [
     ("l1.conv1 dgrad 64->256 + res_bits + bnr3", B4, 193, 193, 64, 256, 1, 1, 1, "res_bits_bnr3", ROWS),
     ("l1.conv2 3x3 64->64", B4, 193, 193, 64, 64, 3, 1, 1, "stats", (64, 2, 3)),
     ("l1.conv1 256->64", B4, 193, 193, 256, 64, 1, 1, 1, "stats", (64, 2, 3)),
+    # the rows kernel on ragged pixel counts (M = 442 / 1 330: partial last 128-row tile, fewer tiles than workgroups, zero-page rows)
+    ("rows ragged 256->1024 + stats", 2, 13, 17, 256, 1024, 1, 1, 1, "stats", ROWS),
+    ("rows ragged 256->1024 bias+res+relu", 2, 13, 17, 256, 1024, 1, 1, 1, "bias_res_relu", ROWS),
+    ("rows ragged 256->1024 + res_bits + bnr3", 2, 35, 19, 256, 1024, 1, 1, 1, "res_bits_bnr3", ROWS),
+    ("rows ragged 512->2048 + stats", 2, 13, 17, 512, 2048, 1, 1, 1, "stats", ROWS),
+    ("rows ragged 128->512 + res_bits + bnr3", 2, 35, 19, 128, 512, 1, 1, 1, "res_bits_bnr3", ROWS),
+    ("rows ragged 64->256 bias+res+relu", 2, 35, 19, 64, 256, 1, 1, 1, "bias_res_relu", ROWS),
+    ("rows ragged 64->256 + stats", 3, 9, 11, 64, 256, 1, 1, 1, "stats", ROWS),
 ]
 
 
