@@ -286,3 +286,35 @@ def test_skip_unapplied_grads_same_trajectory(dev):
     assert all(torch.equal(a, b) for a, b in zip(l0, l1))
     assert all(torch.equal(p0[k], p1[k]) for k in p0)
     assert all(torch.equal(a, b) for a, b in zip(n0, n1))
+
+
+def test_early_sgd_and_schedule_switches_same_trajectory(dev, monkeypatch):
+    """The host-side schedule options of SimTTrainer (SGD + re-pack of the applied layers on the side stream as soon as their gradients
+    are final, hipGraph replay of the forwards, enqueue order of the two forwards) only move launches between streams / host calls:
+    losses, EVERY parameter, momentum buffer and NTM after three bf16 iterations are bit-identical to the plain schedule."""
+    layers = (1, 1, 2, 1)
+    K, B, H, W = 3, 2, 65, 65
+    st = so.recipe_state(so.state_shapes(19, K, True, layers=layers), seed=31, head_scale=8.0)
+    fst = so.recipe_state(so.state_shapes(19, 0, False, layers=layers), seed=32, head_scale=8.0)
+    runs = []
+    for env in ({"SIMT_EARLY_SGD": "0", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "main"}, {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "side"},
+                {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "1", "SIMT_FWD_ORDER": "main"}, {"SIMT_EARLY_SGD": "0", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "interleave"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        hp = Hyper(open_classes=K, lambda_convex=0.1, lambda_volume=1.0, lambda_anchor=1.0, lr=6e-4, lr_T=6e-3)
+        tr = SimTTrainer(st, fst, so.ntm_init(19, K, 911), so.ntm_init(19, K, 912), hp, CD, B, H, W, dtype=torch.bfloat16, device=dev,
+                         layers=layers)
+        assert tr._early_sgd == (env["SIMT_EARLY_SGD"] == "1")
+        ls = []
+        for it in range(3):
+            img, lab = so.synthetic_batch(B, H, W, CD.numpy(), seed=900 + it, block=8)
+            tr.step(img.to(dev), lab.to(dev), it)
+            ls.append(tr.lout.clone())
+        torch.cuda.synchronize()
+        runs.append((ls, {k: v.clone() for k, v in tr.params.items()}, {k: v.clone() for k, v in tr.mom.items()}, [n.clone() for n in tr.ntm]))
+    l0, p0, m0, n0 = runs[0]
+    for l1, p1, m1, n1 in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(l0, l1))
+        assert all(torch.equal(p0[k], p1[k]) for k in p0)
+        assert all(torch.equal(m0[k], m1[k]) for k in m0)
+        assert all(torch.equal(a, b) for a, b in zip(n0, n1))
