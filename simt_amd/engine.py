@@ -721,11 +721,12 @@ class TrunkPlan:
         dz = None  # gradient w.r.t. the current block's output z
         # Two-stream schedule: the dgrad / BN-backward chain is the critical path (stream 0); every weight-gradient GEMM
         # (+ slab reduce, bias column sums) runs on the side stream (1) behind an event recorded after the kernel that
-        # produced its dY.  dY buffers are double-buffered by block parity; stream 0 waits for the side stream's work of
-        # the block two steps back before it overwrites them.
+        # produced its dY.  dY buffers rotate over the blocks; stream 0 waits for the side stream's work of
+        # the block SIMT_DY_BUFFERS (default 4; memory is not the constraint) steps back before it overwrites them.
         e0 = b.record(0)
         b.wait(e0, 1)
-        last_side = {0: None, 1: None}
+        npar = max(2, int(os.environ.get("SIMT_DY_BUFFERS", "4")))      # dY buffer sets: the dgrad chain may run this many blocks ahead of the weight gradients
+        last_side = {i: None for i in range(npar)}
         pending_bn3 = 0       # slots of bn3-backward partials the previous iteration's dx GEMM already reduced (0: none)
         for bi in range(n_blocks - 1, -1, -1):
             rec = self.block_io[bi]
@@ -746,7 +747,7 @@ class TrunkPlan:
                     pending_bn3 = self._head_bnr_nblk
             assert dz is not None, "no gradient reaches the last block (a head must sit on the last layer)"
             blk_start = len(b)
-            par = bi & 1
+            par = bi % npar
             if last_side[par] is not None:
                 b.wait(last_side[par], 0)
             # ---- z = relu(bn3(y3) + shortcut)
