@@ -272,12 +272,28 @@ class SimTTrainer:
         b.append(_Launch(lib.simt_softmax_rows, (ops._p(self.fixed.out["x2"]), self.ldf, ops._p(self.fixp), self.ldf, self.B * self.h * self.w,
                                                  self.C), (self.fixed.out["x2"], self.fixp), "simt_softmax_rows", stream=1))
         assert all(it.stream == 0 for it in a)
-        i = j = 0
-        while i < len(a) or j < len(b):
-            if j < len(b):
-                both.items.append(b[j]); j += 1
-            if i < len(a):
-                both.items.append(a[i]); i += 1
+        # paced: the launches of each stream in chunks of `pace`; chunk c of one stream waits for chunk c - 2 of the other, so neither
+        # queue can run more than two chunks ahead (left alone, the GPU serves one queue exclusively for milliseconds: the two forwards
+        # then run one after the other and fill none of each other's tails)
+        import os
+        pace = int(os.environ.get("SIMT_FWD_PACE", "8"))
+        ca = [a[k:k + pace] for k in range(0, len(a), pace)]
+        cb = [b[k:k + pace] for k in range(0, len(b), pace)]
+        # proportional pairing: both streams finish their last chunk together
+        n = max(len(ca), len(cb))
+        ia = [min(len(ca), (k + 1) * len(ca) // n) for k in range(n)]
+        ib = [min(len(cb), (k + 1) * len(cb) // n) for k in range(n)]
+        ev_a, ev_b = [], []
+        pa = pb = 0
+        for k in range(n):
+            if pace > 0 and k >= 2:
+                if ev_b[k - 2] is not None: both.wait(ev_b[k - 2], 0)
+                if ev_a[k - 2] is not None: both.wait(ev_a[k - 2], 1)
+            for c in cb[pb:ib[k]]: both.items.extend(c)
+            for c in ca[pa:ia[k]]: both.items.extend(c)
+            ev_b.append(both.record(1) if ib[k] > pb else None)
+            ev_a.append(both.record(0) if ia[k] > pa else None)
+            pa, pb = ia[k], ib[k]
         ev_fix = both.record(1)
         both.wait(ev_fix, 0)
         return both
