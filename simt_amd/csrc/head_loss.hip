@@ -241,15 +241,30 @@ __device__ __forceinline__ float wave_sum_dpp63(float v) {
   return __int_as_float(x);
 }
 
+// Full-wave max / OR with DPP row operations, broadcast from lane 63 through an SGPR (v_readlane): no LDS crossbar.  The
+// __shfl_xor forms of these (6 ds_bpermute per value, 2 x Q values per 64 pixels for the anchor arg-max) were the largest single cost of
+// pass 1.  `old` = the lane's own value: lanes a row mask leaves out keep it (max(x, x) = x).
 __device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  int x = __float_as_int(v);
+#define DPP_MAX(ctrl, rmask) x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, ctrl, rmask, 0xf, false))))
+  DPP_MAX(0xB1, 0xf);    // quad_perm [1,0,3,2]
+  DPP_MAX(0x4E, 0xf);    // quad_perm [2,3,0,1]
+  DPP_MAX(0x141, 0xf);   // row_half_mirror
+  DPP_MAX(0x140, 0xf);   // row_mirror      -> every lane holds its 16-lane row max
+  DPP_MAX(0x142, 0xa);   // row_bcast:15    -> rows 1 and 3: max with the previous row
+  DPP_MAX(0x143, 0xc);   // row_bcast:31    -> rows 2 and 3: max with row 1 (lane 31)
+#undef DPP_MAX
+  return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+  int x = (int)v;
+#define DPP_OR(ctrl, rmask) x |= __builtin_amdgcn_update_dpp(x, x, ctrl, rmask, 0xf, false)
+  DPP_OR(0xB1, 0xf); DPP_OR(0x4E, 0xf); DPP_OR(0x141, 0xf); DPP_OR(0x140, 0xf); DPP_OR(0x142, 0xa); DPP_OR(0x143, 0xc);
+#undef DPP_OR
+  return (unsigned)__builtin_amdgcn_readlane(x, 63);
 }
 __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
-  return v;
+  return ((unsigned long long)wave_or_u32((unsigned)(v >> 32)) << 32) | wave_or_u32((unsigned)v);
 }
 
 template <int QM>
