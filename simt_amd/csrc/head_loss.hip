@@ -632,6 +632,7 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
           }
       }
       const float is1 = 1.0f / e1.sum2, is2 = 1.0f / e2.sum2;
+      const float ir1 = lab_ok ? 1.0f / r1 : 0.f, ir2 = lab_ok ? 1.0f / r2 : 0.f;
 #pragma unroll
       for (int j = 0; j < QM; ++j)
         if (j < Q) {
@@ -651,9 +652,9 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
               G2 += gk2 * (q2 - ((j == e2.arg) ? 1.f : 0.f));
               if (j != e2.arg) G2 += gu2 * (expf(v2[j] - e2.m2) * is2 - ((j == e2.yopen) ? 1.f : 0.f));
             }
-            if (lab_ok) {
-              G1 += gy1 * (q1 - q1 * sT[j * C + labi] / r1);
-              G2 += gy2 * (q2 - q2 * sT[QC + j * C + labi] / r2);
+            if (lab_ok) {                  // (a reciprocal per pixel, not two divisions per class)
+              G1 += gy1 * (q1 - q1 * sT[j * C + labi] * ir1);
+              G2 += gy2 * (q2 - q2 * sT[QC + j * C + labi] * ir2);
             }
           }
           sG[(0 * 256 + tid) * GP + j] = G1;
