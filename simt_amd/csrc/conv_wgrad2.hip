@@ -46,10 +46,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;   // 2 x 4 waves, 64 x 64 outputs each
 
-  int bid = blockIdx.x;
-  const int split = bid % a.nsplit;
-  bid /= a.nsplit;
-  const int kt_ = bid % a.ktiles, ct = bid / a.ktiles;
+  // Workgroup -> (pixel split, tile): split-major linear order cut into one contiguous chunk per XCD (blocks b and b + 8 share an
+  // XCD), so the tiles of one pixel split run on one XCD (two at a chunk boundary): its dY / X rows are fetched from HBM once or twice
+  // per launch and re-read by the other tiles from that XCD's L2.  (Round 1's order put the tiles of a split on eight XCDs: rocprofv3
+  // FETCH_SIZE 233 MB per launch against 96-115 MB algorithmic.)
+  const int tiles = a.cotiles * a.ktiles;
+  const int lin = xcd_remap(blockIdx.x, tiles * a.nsplit);
+  const int split = lin / tiles;
+  const int tix = lin - split * tiles;
+  const int kt_ = tix % a.ktiles, ct = tix / a.ktiles;
   const int co0 = ct * 128, k0 = kt_ * 256;
 
   // chunk q = i*NT + tid of an image: row = q>>4 = i*32 + (tid>>4), position q&15
