@@ -414,19 +414,29 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
       ex1 = wave_or_u64(ex1);
       ex2 = wave_or_u64(ex2);
       if (lane == 0) { atomicOr(&sEx[0], ex1); atomicOr(&sEx[1], ex2); }
+      // A channel's block-wide best so far (upper half of its key in LDS) is read once per group: lane t holds channel t of both heads.  A wave only reduces a channel when one of its pixels reaches that value (>=: ties go through the key,
+      // whose low half prefers the smaller pixel index) -- after the first groups that is rare, and the 2 x Q wave reductions per 64
+      // pixels were a fifth of this kernel.  A stale (lower) best only makes a wave do the reduction needlessly.
+      unsigned bestv1 = 0u, bestv2 = 0u;
+      if (lane < Q) { bestv1 = (unsigned)(sKey[lane] >> 32); bestv2 = (unsigned)(sKey[QMAX + lane] >> 32); }
 #pragma unroll
       for (int j = 0; j < QM; ++j)
         if (j < Q) {
           float a1 = live ? v1[j] : -INFINITY, a2 = live ? v2[j] : -INFINITY;
-          float m1 = wave_max_f(a1), m2 = wave_max_f(a2);
-          unsigned long long b1 = __ballot(live && a1 == m1), b2 = __ballot(live && a2 == m2);
-          if (lane == 0) {
-            if (b1) {
+          const unsigned best1 = (unsigned)__builtin_amdgcn_readlane((int)bestv1, j), best2 = (unsigned)__builtin_amdgcn_readlane((int)bestv2, j);
+          if (__ballot(live && f32_ord(a1) >= best1)) {
+            float m1 = wave_max_f(a1);
+            unsigned long long b1 = __ballot(live && a1 == m1);
+            if (lane == 0 && b1) {
               long pp = grp * 256 + wave * 64 + (__ffsll((long long)b1) - 1);
               unsigned long long key = ((unsigned long long)f32_ord(m1) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)pp);
               atomicMax(&sKey[j], key);
             }
-            if (b2) {
+          }
+          if (__ballot(live && f32_ord(a2) >= best2)) {
+            float m2 = wave_max_f(a2);
+            unsigned long long b2 = __ballot(live && a2 == m2);
+            if (lane == 0 && b2) {
               long pp = grp * 256 + wave * 64 + (__ffsll((long long)b2) - 1);
               unsigned long long key = ((unsigned long long)f32_ord(m2) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)pp);
               atomicMax(&sKey[QMAX + j], key);
