@@ -88,6 +88,12 @@ CONV_CASES = [
     ("rows ragged 128->512 + res_bits + bnr3", 2, 35, 19, 128, 512, 1, 1, 1, "res_bits_bnr3", ROWS),
     ("rows ragged 64->256 bias+res+relu", 2, 35, 19, 64, 256, 1, 1, 1, "bias_res_relu", ROWS),
     ("rows ragged 64->256 + stats", 3, 9, 11, 64, 256, 1, 1, 1, "stats", ROWS),
+    ("rows ragged 256->1024 plain", 2, 13, 17, 256, 1024, 1, 1, 1, "plain", ROWS),
+    ("rows ragged 256->1024 bias+relu", 2, 13, 17, 256, 1024, 1, 1, 1, "bias_relu", ROWS),
+    ("rows ragged 128->512 bias+stats", 2, 35, 19, 128, 512, 1, 1, 1, "bias_stats", ROWS),
+    ("rows ragged 256->1024 residual only", 2, 35, 19, 256, 1024, 1, 1, 1, "res_only", ROWS),
+    ("rows ragged 512->2048 residual only", 2, 13, 17, 512, 2048, 1, 1, 1, "res_only", ROWS),
+    ("rows ragged 64->256 bias+relu", 3, 9, 11, 64, 256, 1, 1, 1, "bias_relu", ROWS),
 ]
 
 
@@ -113,13 +119,25 @@ def test_conv_production_shapes_bf16(dev, case):
     if epi == "stats":
         stats = torch.full(((M + 127) // 128, 2, Cout), float("nan"), device=dev)
         kw["stats"] = stats
-    if epi in ("bias_res_relu", "res_bits_bnr3"):
+    if epi in ("bias_relu", "bias_stats"):                 # generic (run-time flag) flavours of the rows kernel
+        bias = torch.randn(Cout, generator=g)
+        kw.update(bias=bias.to(dev), relu=(epi == "bias_relu"))
+        ref_conv = ref
+        ref = ref + bias.view(1, -1, 1, 1)
+        if epi == "bias_relu":
+            ref = torch.relu(ref)
+        if epi == "bias_stats":
+            stats = torch.full(((M + 127) // 128, 2, Cout), float("nan"), device=dev)
+            kw["stats"] = stats
+    if epi in ("bias_res_relu", "res_bits_bnr3", "res_only"):
         r = torch.randn(B, Cout, Ho, Wo, generator=g).to(BF)
         kw["res"] = r.permute(0, 2, 3, 1).contiguous().to(dev)
         if epi == "bias_res_relu":
             bias = torch.randn(Cout, generator=g)
             kw.update(bias=bias.to(dev), relu=True)
             ref = torch.relu(ref + bias.view(1, -1, 1, 1) + r.float())
+        elif epi == "res_only":
+            ref = ref + r.float()
         else:
             keep = torch.rand(B, Cout, Ho, Wo, generator=g) > 0.5
             kw["res_bits"] = _bits(keep.permute(0, 2, 3, 1).reshape(M, Cout)).to(dev)
@@ -150,7 +168,10 @@ def test_conv_production_shapes_bf16(dev, case):
     if stats is not None:                                  # BN batch statistics of the STORED bf16 values, every slot summed
         s = stats.double().sum(0)
         assert torch.isfinite(s).all()
-        assert _rel(s[0].cpu(), stored.sum(0).cpu()) < 2e-3 and _rel(s[1].cpu(), (stored * stored).sum(0).cpu()) < 2e-3
+        pre = stored                                       # statistics are taken BEFORE bias / ReLU (of the rounded conv result)
+        if epi == "bias_stats":
+            pre = ref_conv.permute(0, 2, 3, 1).reshape(M, Cout).to(torch.bfloat16).double().to(stored.device)
+        assert _rel(s[0].cpu(), pre.sum(0).cpu()) < 2e-3 and _rel(s[1].cpu(), (pre * pre).sum(0).cpu()) < 2e-3
     if bnr is not None:                                    # fused first pass of the BatchNorm backward (simt_conv_desc.bnr_*)
         nblk = L.load().simt_conv_mtiles(C.byref(d))
         assert 0 < nblk <= bnr["part"].shape[0]
