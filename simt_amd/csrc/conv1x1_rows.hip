@@ -10,8 +10,10 @@
 //     in REGISTERS for the whole launch (Cin/32 x 2 x 4 VGPRs) -- weights never touch LDS;
 //   * pixels stream through a D-slot global_load_lds ring in stages of RS whole rows (RS * Cin * 2 bytes, up to D-1 stages in
 //     flight, counted vmcnt); a stage is a COMPLETE reduction, so its RS x 256 outputs leave the accumulators at once;
-//   * they go (bf16) to one of two LDS slabs; 4 store waves stream slab g-1 out (statistics, bias, residual, ReLU, fused
-//     BatchNorm-backward reduce) while the compute waves work on stage g: ONE barrier per stage, no hand-over section;
+//   * the accumulators of stage g-1 are rounded to bf16 and written to one of two LDS slabs INSIDE the MFMA loop of stage g (two VALU
+//     behind every MFMA; for the training forward the BatchNorm batch statistics are taken there too, per channel, one DPP row reduction
+//     per 128-row tile); 4 (2) store waves stream the finished slabs out (bias, residual, bit-masked residual, ReLU, fused BatchNorm-
+//     backward reduce) while the compute waves work on: ONE barrier per stage, no hand-over section;
 //   * persistent workgroups on 128-row tiles (the statistics granule), XCD-aware: the workgroups of one XCD share pixel rows.
 // L2 -> LDS traffic per launch of 256 -> 1024: 4 x 19 MB instead of 302 MB.
 #include "conv2_common.h"

@@ -30,9 +30,11 @@ template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
 }
 
 // MODE 0 = product; 1 = loads only, 2 = fragment reads + MFMA only (timing ablations, env SIMT_WGRAD2_MODE)
-// Measured (scratch/wgradbench.py): 3x3 256<-256 83 us = loads-only 52 + MFMA-only 43 with little overlap; the 1x1 shapes are
-// LOAD-bound (41 us, loads-only 39, MFMA-only 23): two ring stages = 96 KB in flight per CU against HBM latency.  A ninth
-// wave prefetching one dword per 128-B line four stages ahead made them slower (62-67 us): it doubles the line requests.
+// Round 1 measured 3x3 256<-256 83 us = loads-only 52 + MFMA-only 43 "with little overlap": a compiler-inserted s_waitcnt vmcnt(0) in
+// front of the ds_read_tr builtin drained the ring every stage.  Round 2 (profiles/tools/ab_wgrad.py): asm fragment reads 84 -> 70 us,
+// incremental pixel coordinates in the issue phase -> 57 us (loads-only 42, MFMA-only 43), XCD-aware block order: 1x1 1024<-256
+// 44 -> 35 us and 233 -> 124 MB of HBM traffic per launch.  A ninth wave prefetching one dword per 128-B line four stages ahead made
+// the 1x1 shapes slower (62-67 us): it doubles the line requests.
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
   constexpr int NT = 512, NST = 3, BP = 64;
