@@ -101,10 +101,17 @@ __global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2
 #ifndef SIMT_ROWS_CSTAT
 #define SIMT_ROWS_CSTAT 1
 #endif
-  constexpr bool CSTAT = FL == FL_STATS && SIMT_ROWS_CSTAT;
+  // SIMT_ROWS_CSTAT: where FL_STATS takes the statistics (compile-time A/B; all three pass the parity tests).  2: the store waves, on the MFMA pipe -- a transposed read of the
+  // finished slab (ds_read_b64_tr_b16: 8 pixels of one channel per lane) is at once the A and the B operand of v_mfma_f32_16x16x32_bf16:
+  // ones x Y gives the column sums, Y^T x Y has the sums of squares on its diagonal (bf16 products are exact in fp32): 2 MFMAs and 2 LDS
+  // reads per 16 channels and 32 pixels instead of 3 VALU per element (measured 39.0 us on 256 -> 1024).  1 (default): the compute waves (VALU behind their MFMAs, DPP
+  // reduce; 39.7 us).  0: the store waves' VALU (register sums, row groups through sR; 39.7-41 us).  The stage time is set by the barrier-
+  // coupled pair of chains (HBM write back-pressure on the store waves, MFMA + epilogue on the compute waves), not by where these sums run.
+  constexpr bool CSTAT = FL == FL_STATS && SIMT_ROWS_CSTAT == 1;
+  constexpr bool MSTAT = FL == FL_STATS && SIMT_ROWS_CSTAT == 2;
   const bool has_bias = GEN ? a.bias != nullptr : FL == FL_BRR;
   const bool has_relu = GEN ? a.relu != 0 : FL == FL_BRR;
-  const bool has_stats = GEN ? a.stats != nullptr : (FL == FL_STATS && !SIMT_ROWS_CSTAT);      // statistics taken by the store waves (FL_STATS: by the compute waves)
+  const bool has_stats = GEN ? a.stats != nullptr : (FL == FL_STATS && SIMT_ROWS_CSTAT == 0);      // statistics taken by the store waves (FL_STATS: by the compute waves)
   const bool has_res = GEN ? (AUX && a.res != nullptr) : AUX;
   const bool has_rbits = GEN ? (AUX && a.res_bits != nullptr) : FL == FL_BNR;
   const bool has_bnr = GEN ? (AUX && a.bnr_mode != 0) : FL == FL_BNR;
@@ -420,6 +427,16 @@ __global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2
 #ifdef SIMT_ABLATION
   unsigned long long ts_bar = 0, ts_work = 0, ts_prev = 0, ts_lds = 0;
 #endif
+  // MSTAT: this wave's channel blocks (16 channels each): running ones x Y and Y^T x Y of the tile in progress
+  constexpr int MBLK = BN / 16 / NSW;
+  f32x4 m1[MBLK], m2[MBLK];
+#pragma unroll
+  for (int t = 0; t < MBLK; ++t) { m1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; m2[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  int ms_is = 0, ms_ci = 0;                                    // cursor of the slab the statistics are taken from (the one just finished)
+  const bf16x8 ones8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  // transposed-read addressing: lane 4q + p of a 16-lane group supplies row q, channels 4p .. 4p + 3 of a 4-pixel x 16-channel block;
+  // group g = lane >> 4 covers pixels 8g .. 8g + 7 of a 32-pixel k-step (two reads)
+  const unsigned tr_lane = (unsigned)(((lane >> 4) * 8 + ((lane & 15) >> 2)) * CP + (lane & 3) * 8);
   uint4 ov[g::PASSES];                                         // PIPE: the rows of the slab to be stored, read during the previous stage
   const int LAST = PIPE ? S_total + 1 : S_total;
   __builtin_amdgcn_s_barrier();                                // the compute waves' barrier 0: they write the slab of stage g - 1 during stage g,
@@ -468,6 +485,38 @@ __global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2
       if (gi <= S_total) {                                     // slab gi - 1: LDS -> registers (in flight during the statistics below)
 #pragma unroll
         for (int p = 0; p < g::PASSES; ++p) nv[p] = *(const uint4*)(sl + (rg + p * RGS) * CP + vcol * 2);
+        if (MSTAT) {
+          const unsigned sl_a = (unsigned)(size_t)LPTR(sl) + tr_lane;
+#pragma unroll
+          for (int t = 0; t < MBLK; ++t) {
+            const int c0 = (swv * MBLK + t) * 16;              // channel block inside the workgroup's columns
+#pragma unroll
+            for (int ks = 0; ks < g::RS / 32; ++ks) {
+              bf16x4 lo, hi;
+              asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(sl_a + (unsigned)(c0 * 2)), "n"(ks * 32 * CP));
+              asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(sl_a + (unsigned)(c0 * 2)), "n"(ks * 32 * CP + 4 * CP));
+              bf16x8 yb = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+              asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yb));
+              m1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, yb, m1[t], 0, 0, 0);
+              m2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yb, yb, m2[t], 0, 0, 0);
+            }
+          }
+          if (++ms_is == g::SPT) {                             // the slab closes a 128-row tile: row 0 of ones x Y, diagonal of Y^T x Y
+            const int mt = mt0 + ms_ci * mt_step;
+#pragma unroll
+            for (int t = 0; t < MBLK; ++t) {
+              const int nn = n0 + (swv * MBLK + t) * 16 + (lane & 15);
+              const int e = lane & 3;
+              const float dg = e == 0 ? m2[t][0] : e == 1 ? m2[t][1] : e == 2 ? m2[t][2] : m2[t][3];
+              if (nn < a.Cout) {
+                if (lane < 16) a.stats[((long)mt * 2 + 0) * a.Cout + nn] = m1[t][0];
+                if (((lane & 15) >> 2) == (lane >> 4)) a.stats[((long)mt * 2 + 1) * a.Cout + nn] = dg;
+              }
+              m1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; m2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            ms_is = 0; ++ms_ci;
+          }
+        }
       }
       if (gi >= 2) {
         if (has_stats) {                                       // statistics of the stored value, before bias / ReLU
