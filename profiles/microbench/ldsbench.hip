@@ -2,7 +2,7 @@
 //   V0: current streaming kernel's shape (per K-stage: 128 rows x 128 B of x at 512-B pitch + the same of W; 3-slot ring)
 //   V1: W tile resident (64 KB, loaded once), x streamed as whole rows: RS rows x 512 B contiguous per stage, D slots
 //   V2: V1 without sharing (every workgroup reads its own slice of x once: pure HBM -> LDS)
-// build: hipcc --offload-arch=gfx950 -O3 -o scratch/ldsbench scratch/ldsbench.hip
+// build: hipcc --offload-arch=gfx950 -O3 -o ldsbench ldsbench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

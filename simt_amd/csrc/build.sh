@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=../libsimt_hip.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-# -packed-fp32-ops: v_pk_*_f32 cannot issue in the shadow of an MFMA (scratch/mixbench2.hip: one per MFMA costs +77 %), plain VALU can
+# -packed-fp32-ops: v_pk_*_f32 cannot issue in the shadow of an MFMA (profiles/microbench/mixbench2.hip: one per MFMA costs +77 %), plain VALU can
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -Xclang -target-feature -Xclang -packed-fp32-ops"
 # ABLATION=1: also compile the timing-ablation / loader-wave experiment instantiations (outputs meaningless; never shipped)
 if [ "${ABLATION:-0}" = "1" ]; then FLAGS="$FLAGS -DSIMT_ABLATION"; fi

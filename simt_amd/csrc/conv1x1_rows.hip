@@ -2,7 +2,7 @@
 // Shapes: the short-reduction / wide-output 1x1 convs of the Bottlenecks (model/deeplab_multi.py:62,73: conv3 256 -> 1024,
 // 128 -> 512, 64 -> 256 forward, and the dgrads of the matching conv1), dense NHWC input (stride 1), Cin in {64, 128, 256}.
 //
-// Why (measurements: DESIGN.md section 5, scratch/ldsbench.hip): these GEMMs have K <= 256, so a 128x128 output tile needs 128 KB of
+// Why (measurements: DESIGN.md section 5, profiles/microbench/ldsbench.hip): these GEMMs have K <= 256, so a 128x128 output tile needs 128 KB of
 // operands for 32 KB of output.  A CU fills LDS from L2 at ~75 GB/s, which is what bounded conv1x1_stream_kernel (302 MB through
 // L1 per launch of 256 -> 1024), half of it the SAME weight tile re-read for every pixel tile; and its three barrier hand-shakes per
 // tile coupled the store waves' HBM write latency to the MFMA waves.  Here:
@@ -186,7 +186,7 @@ __global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2
 #endif
     // The epilogue of stage g - 1 (round to bf16, write the slab, statistics) is DEFERRED into the MFMA loop of stage g, two VALU
     // operations behind every MFMA: a wave issues in order, so its own VALU work only overlaps its MFMAs if it sits between them (measured,
-    // scratch/mixbench2.hip: up to two plain VALU per MFMA are free with two waves per SIMD; v_pk_*_f32 never is -- the library is built
+    // profiles/microbench/mixbench2.hip: up to two plain VALU per MFMA are free with two waves per SIMD; v_pk_*_f32 never is -- the library is built
     // without packed fp32).  All waves of a workgroup are phase-locked by the stage barrier, so nothing else would fill the MFMA shadow.
     constexpr int NQ = TN * TM;
     f32x4 prev[TN][TM];

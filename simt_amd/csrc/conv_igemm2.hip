@@ -34,7 +34,7 @@ extern "C" int simt_debug_stamps(unsigned long long* out, int n) {
 // variable SIMT_CONV2_MODE; their outputs are meaningless.
 // LW = 4 / 8: wave specialisation (experiments, off by default; SIMT_CONV2_LW=4|8).  Extra waves do nothing but fill the ring;
 // the eight consumer waves never issue a global_load_lds and never wait on vmcnt.  NST = 3 variants only.  Measured on MI355X
-// (scratch/convbench.py, 3x3 256->256): default 48-50 us, LW=4 51.6 us (four waves issue the 13 pieces per stage more slowly
+// (round-1 A/B harness, now profiles/tools/ab_conv.py; 3x3 256->256): default 48-50 us, LW=4 51.6 us (four waves issue the 13 pieces per stage more slowly
 // than eight waves issue 7 each), LW=8 (8 loaders + 8 consumers at 125 VGPRs, single-buffered fragments) 50.5 us = unchanged.
 // Three very different schedules, one time: the kernel is bound by a shared resource, not by issue slots.  Per 64-deep stage the
 // LDS sees 52 KB of DMA writes (loads-only ablation: 31 us = ~30 B/clk/CU of L2->LDS fill) and 144 KB of fragment reads
