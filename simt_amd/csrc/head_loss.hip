@@ -71,6 +71,12 @@ __device__ __forceinline__ float lerp4(const Taps& t, float v00, float v01, floa
   return t.wy0 * (t.wx0 * v00 + t.wx1 * v01) + t.wy1 * (t.wx0 * v10 + t.wx1 * v11);
 }
 
+// e^x for x <= 0 (every call site subtracts the running maximum first): one v_exp_f32 of x*log2(e).  The rounding of the product is
+// |x| 2^-24 relative in the result, so an entry's ABSOLUTE error is at most |x| e^x 2^-24 <= 2.2e-8: below half an ulp of the softmax
+// sum (>= 1) it goes into.  expf's extended-precision range reduction (13 instructions per call, ~1 600 of pass 2's 8 000) bought
+// nothing those sums keep.
+__device__ __forceinline__ float exp_le0(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
 template <int NMAX>
 __device__ __forceinline__ void interp_vec(const float* src, int ld, int n, const Taps& t, float* out) {
   const float* p00 = src + (long)t.o00 * ld;
@@ -116,19 +122,19 @@ __device__ __forceinline__ void interp_argmax(const float* src, int ld, int n, c
 
 // frozen model's posterior at one pixel -> (max probability, its first arg-max).  fix_logits: softmax AFTER the interpolation.
 template <int NMAX>
-__device__ __forceinline__ void fixed_posterior(const HeadGeom& g, const float* fixp, const Taps& t, float& fm, int& fa) {
-  if (!g.fix_logits) { interp_argmax<NMAX>(fixp, g.ldf, g.C, t, fm, fa); return; }
+__device__ __forceinline__ void fixed_posterior(const HeadGeom& g, int C, const float* fixp, const Taps& t, float& fm, int& fa) {
+  if (!g.fix_logits) { interp_argmax<NMAX>(fixp, g.ldf, C, t, fm, fa); return; }
   float v[NMAX];
-  interp_vec<NMAX>(fixp, g.ldf, g.C, t, v);
+  interp_vec<NMAX>(fixp, g.ldf, C, t, v);
   float mx = v[0];
   fa = 0;
 #pragma unroll
   for (int j = 1; j < NMAX; ++j)
-    if (j < g.C && v[j] > mx) { mx = v[j]; fa = j; }
+    if (j < C && v[j] > mx) { mx = v[j]; fa = j; }
   float sum = 0.f;
 #pragma unroll
   for (int j = 0; j < NMAX; ++j)
-    if (j < g.C) sum += expf(v[j] - mx);
+    if (j < C) sum += exp_le0(v[j] - mx);
   fm = 1.0f / sum;                      // = exp(mx - mx) / sum, the value torch.softmax(...).max() returns
 }
 
@@ -150,7 +156,7 @@ __device__ __forceinline__ void eval_head(const float* v, int Q, int C, float th
   float sum = 0.f;
 #pragma unroll
   for (int j = 0; j < QM; ++j)
-    if (j < Q) sum += expf(v[j] - vmax);
+    if (j < Q) sum += exp_le0(v[j] - vmax);
   e.arg = arg; e.vmax = vmax; e.sum = sum; e.lse = vmax + logf(sum);
   float pm = 1.0f / sum;
   e.pseudo1 = (arg < C && pm > th_high) ? arg : 255;
@@ -164,10 +170,10 @@ __device__ __forceinline__ void eval_head(const float* v, int Q, int C, float th
       m2 = fmaxf(m2, v[j]);
       if (j >= C && v[j] > best) { best = v[j]; y = j; }
     }
-  float s2 = expf(0.f - m2);
+  float s2 = exp_le0(0.f - m2);
 #pragma unroll
   for (int j = 0; j < QM; ++j)
-    if (j < Q && j != arg) s2 += expf(v[j] - m2);
+    if (j < Q && j != arg) s2 += exp_le0(v[j] - m2);
   e.yopen = y; e.m2 = m2; e.sum2 = s2; e.lse2 = m2 + logf(s2);
 }
 
@@ -267,10 +273,13 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
   return ((unsigned long long)wave_or_u32((unsigned)(v >> 32)) << 32) | wave_or_u32((unsigned)v);
 }
 
-template <int QM>
+// QT / CT: the channel counts as compile-time constants (0 = taken from the geometry at run time): every `j < Q` predicate of the unrolled
+// per-channel loops folds away -- with run-time counts they were a third of the instructions and spilled SGPR masks into VGPR lanes.
+template <int QM, int QT, int CT>
 __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(HeadArgs a) {
   const HeadGeom g = a.g;
-  const int Q = g.Q, C = g.C, QC = Q * C;
+  const int Q = QT ? QT : g.Q, C = CT ? CT : g.C, QC = Q * C;
+  constexpr int CM = CT ? (CT + 3) / 4 * 4 : QM;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sT = (float*)smem;                                        // [2][QC]
   float* sdT = sT + 2 * QC;                                        // [4 waves][2][QC]
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
     // ---- fixed-model posterior -> confidence label (reference :354-361)
     float fm = 0.f;
     int fa = 0;
-    if (a.mode == 0) fixed_posterior<QM>(g, a.fixp, tp, fm, fa);
+    if (a.mode == 0) fixed_posterior<CM>(g, C, a.fixp, tp, fm, fa);
     asm volatile("" ::: "memory");   // keep the next gathers from being hoisted above (register pressure)
     int conf = (fm > a.th_high) ? fa : 255;
     if (fm < a.th_low) conf = C;
@@ -370,8 +379,8 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
     if (__ballot(lab_ok)) {
 #pragma unroll
       for (int j = 0; j < QM; ++j) {
-        q1[j] = (j < Q) ? expf(v1[j] - e1.vmax) * inv1 : 0.f;
-        q2[j] = (j < Q) ? expf(v2[j] - e2.vmax) * inv2 : 0.f;
+        q1[j] = (j < Q) ? exp_le0(v1[j] - e1.vmax) * inv1 : 0.f;
+        q2[j] = (j < Q) ? exp_le0(v2[j] - e2.vmax) * inv2 : 0.f;
       }
     }
     if (lab_ok) {
@@ -568,10 +577,11 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(HeadArgs a, int nblk
 // launch bounds: 2 waves per SIMD for every QM.  With 3 (170 VGPRs) the QM = 24 build spilled 272 B per lane to scratch -- the
 // 256 MB of HBM traffic per launch that round 1's PMC pass showed against ~30 MB algorithmic; without the spill 1 016 -> 826 us on
 // cold operands at 4 x 768 x 768 (pass 1 is the other way round: 630 us with its 104-byte spill at 3 waves, 802 us without at 2).
-template <int QM>
+template <int QM, int QT, int CT>
 __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
   const HeadGeom g = a.g;
-  const int Q = g.Q, C = g.C, QC = Q * C, QP = a.QP;
+  const int Q = QT ? QT : g.Q, C = CT ? CT : g.C, QC = Q * C, QP = a.QP;
+  constexpr int CM = CT ? (CT + 3) / 4 * 4 : QM;
   const int GP = Q + 1;  // LDS pitch of the per-pixel gradient rows
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sT = (float*)smem;          // [2][QC]
@@ -606,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
       }
       float fm = 0.f;
       int fa = 0;
-      if (a.mode == 0) fixed_posterior<QM>(g, a.fixp, tp, fm, fa);
+      if (a.mode == 0) fixed_posterior<CM>(g, C, a.fixp, tp, fm, fa);
       asm volatile("" ::: "memory");
       int conf = (fm > a.th_high) ? fa : 255;
       if (fm < a.th_low) conf = C;
@@ -637,8 +647,8 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
 #pragma unroll
         for (int j = 0; j < QM; ++j)
           if (j < Q) {
-            r1 += (expf(v1[j] - e1.vmax) * inv1) * sT[j * C + labi];
-            r2 += (expf(v2[j] - e2.vmax) * inv2) * sT[QC + j * C + labi];
+            r1 += (exp_le0(v1[j] - e1.vmax) * inv1) * sT[j * C + labi];
+            r2 += (exp_le0(v2[j] - e2.vmax) * inv2) * sT[QC + j * C + labi];
           }
       }
       const float is1 = 1.0f / e1.sum2, is2 = 1.0f / e2.sum2;
@@ -646,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
 #pragma unroll
       for (int j = 0; j < QM; ++j)
         if (j < Q) {
-          float q1 = expf(v1[j] - e1.vmax) * inv1, q2 = expf(v2[j] - e2.vmax) * inv2;
+          float q1 = exp_le0(v1[j] - e1.vmax) * inv1, q2 = exp_le0(v2[j] - e2.vmax) * inv2;
           float G1 = 0.f, G2 = 0.f;
           if (live) {
             if (conf != 255) {
@@ -656,11 +666,11 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
             }
             if (e1.pseudo1 != 255) {
               G1 += gk1 * (q1 - ((j == e1.arg) ? 1.f : 0.f));
-              if (j != e1.arg) G1 += gu1 * (expf(v1[j] - e1.m2) * is1 - ((j == e1.yopen) ? 1.f : 0.f));
+              if (j != e1.arg) G1 += gu1 * (exp_le0(v1[j] - e1.m2) * is1 - ((j == e1.yopen) ? 1.f : 0.f));
             }
             if (e2.pseudo1 != 255) {
               G2 += gk2 * (q2 - ((j == e2.arg) ? 1.f : 0.f));
-              if (j != e2.arg) G2 += gu2 * (expf(v2[j] - e2.m2) * is2 - ((j == e2.yopen) ? 1.f : 0.f));
+              if (j != e2.arg) G2 += gu2 * (exp_le0(v2[j] - e2.m2) * is2 - ((j == e2.yopen) ? 1.f : 0.f));
             }
             if (lab_ok) {                  // (a reciprocal per pixel, not two divisions per class)
               G1 += gy1 * (q1 - q1 * sT[j * C + labi] * ir1);
@@ -798,10 +808,12 @@ extern "C" int simt_head_loss(const simt_head_desc* d, simt_stream_t stream) {
   const int nblk = simt_head_nblk(d->B, d->H, d->W);
   (void)hipMemsetAsync(d->keys, 0, (2 * QMAX + 2) * sizeof(unsigned long long), st);
   size_t lds1 = pass1_lds(d->Q, d->C);
-  if (d->Q <= 24)
-    hipLaunchKernelGGL(head_pass1_kernel<24>, dim3(nblk), dim3(256), lds1, st, a);
-  else
-    hipLaunchKernelGGL(head_pass1_kernel<QMAX>, dim3(nblk), dim3(256), lds1, st, a);
+#define P1(QM, QT, CT) hipLaunchKernelGGL((head_pass1_kernel<QM, QT, CT>), dim3(nblk), dim3(256), lds1, st, a)
+  if (d->Q == 22 && d->C == 19) P1(24, 22, 19);          // Cityscapes, K = 3 open classes (BASELINE configs[0..2], [4])
+  else if (d->Q == 25 && d->C == 19) P1(28, 25, 19);     // K = 6 (configs[3])
+  else if (d->Q <= 24) P1(24, 0, 0);
+  else P1(QMAX, 0, 0);
+#undef P1
   SIMT_LAUNCH_CHECK();
   {
     const int ncols = NSCAL + 2 * d->Q * d->C;
@@ -825,14 +837,17 @@ extern "C" int simt_head_grad(const simt_head_desc* d, simt_stream_t stream) {
   SIMT_CHECK(lds2 <= 160 * 1024);
   static size_t lds2_set = 0;
   if (lds2 > lds2_set) {
-    (void)hipFuncSetAttribute((const void*)head_pass2_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    (void)hipFuncSetAttribute((const void*)head_pass2_kernel<QMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+#define P2ATTR(QM, QT, CT) (void)hipFuncSetAttribute((const void*)head_pass2_kernel<QM, QT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)
+    P2ATTR(24, 22, 19); P2ATTR(28, 25, 19); P2ATTR(24, 0, 0); P2ATTR(QMAX, 0, 0);
+#undef P2ATTR
     lds2_set = lds2;
   }
-  if (d->Q <= 24)
-    hipLaunchKernelGGL(head_pass2_kernel<24>, dim3(d->B * d->H), dim3(256), lds2, st, a);
-  else
-    hipLaunchKernelGGL(head_pass2_kernel<QMAX>, dim3(d->B * d->H), dim3(256), lds2, st, a);
+#define P2(QM, QT, CT) hipLaunchKernelGGL((head_pass2_kernel<QM, QT, CT>), dim3(d->B * d->H), dim3(256), lds2, st, a)
+  if (d->Q == 22 && d->C == 19) P2(24, 22, 19);
+  else if (d->Q == 25 && d->C == 19) P2(28, 25, 19);
+  else if (d->Q <= 24) P2(24, 0, 0);
+  else P2(QMAX, 0, 0);
+#undef P2
   SIMT_LAUNCH_CHECK();
   long total = 2l * d->B * d->h * d->w * d->QP;
   unsigned grid = (unsigned)((total + 255) / 256);
