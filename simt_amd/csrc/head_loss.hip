@@ -21,6 +21,7 @@
 
 #define QMAX 40
 #define NSCAL 12
+#define XR_MAX 287   // low-res columns one 256-pixel chunk may touch on the run-based x-reduction of pass 2 (more: the scanning form)
 
 struct HeadGeom {
   int B, h, w, H, W, C, Q, ldp, ldf;
@@ -589,6 +590,7 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
   float* sAcc = sG + 2 * 256 * GP;   // [2][w][Q]
   int* sI0 = (int*)(sAcc + 2 * g.w * Q);     // [256] low-res column of each pixel of the chunk
   float* sL1 = (float*)(sI0 + 256);          // [256] its right-tap weight
+  int* sStart = (int*)(sL1 + 256);           // [XR_MAX + 1] first pixel of the chunk whose low-res column is >= xl_lo + k
   const int tid = threadIdx.x;
   const int b = blockIdx.x / g.H, y = blockIdx.x % g.H;
   for (int i = tid; i < QC; i += 256) { sT[i] = a.mode == 0 ? a.T1[i] : 0.f; sT[QC + i] = a.mode == 0 ? a.T2[i] : 0.f; }
@@ -613,6 +615,17 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
         if (i0 > g.w - 1) i0 = g.w - 1;
         sI0[tid] = live ? i0 : -100;
         sL1[tid] = fx - (float)i0;
+        // run starts of the (monotone) column sequence, for the x-reduction below: k in (column of x-1, column of x] start at this pixel
+        const int xl_lo_ = max(0, (int)src_coord(g.half, g.sx, x0) - 1);
+        const int nlive = min(256, g.W - x0);
+        const int nxl_ = min(g.w - 1, (int)src_coord(g.half, g.sx, x0 + nlive - 1) + 2) - xl_lo_ + 1;
+        if (live && nxl_ <= XR_MAX) {
+          int prev = xl_lo_ - 1;
+          if (tid) { prev = (int)src_coord(g.half, g.sx, x - 1); if (prev > g.w - 1) prev = g.w - 1; }
+          for (int k = prev - xl_lo_ + 1; k <= i0 - xl_lo_; ++k) sStart[k] = tid;
+          if (tid == nlive - 1)
+            for (int k = i0 - xl_lo_ + 1; k <= nxl_; ++k) sStart[k] = nlive;
+        }
       }
       float fm = 0.f;
       int fa = 0;
@@ -688,6 +701,30 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
     const int xl_lo = max(0, (int)src_coord(g.half, g.sx, x0) - 1);
     const int xl_hi = min(g.w - 1, (int)src_coord(g.half, g.sx, xend - 1) + 2);
     const int nxl = xl_hi - xl_lo + 1;
+    if (nxl <= XR_MAX) {
+      // pixels whose left tap is column xl form one run of the chunk ([sStart[xr], sStart[xr+1])), the ones whose right tap is xl the
+      // run before it: two short weighted sums instead of a scan over every pixel that could touch the column
+      for (int idx = tid; idx < 2 * nxl * Q; idx += 256) {
+        const int hd = idx / (nxl * Q);
+        const int r = idx - hd * nxl * Q;
+        const int xr = r / Q, j = r - xr * Q;
+        const int xl = xl_lo + xr;
+        const int a0 = sStart[xr], a1 = sStart[xr + 1], b0 = xr ? sStart[xr - 1] : a0;
+        const float* G = sG + hd * 256 * GP + j;
+        const bool edge = xl == g.w - 1;          // the right tap of the last column is the column itself
+        float s = 0.f;
+        for (int p = b0; p < a0; ++p) {
+          const float wgt = sL1[p];
+          if (wgt != 0.f) s += wgt * G[p * GP];           // (a zero weight skips the term, as in the scanning form)
+        }
+        for (int p = a0; p < a1; ++p) {
+          const float l1 = sL1[p];
+          const float wgt = edge ? (1.f - l1) + l1 : 1.f - l1;
+          if (wgt != 0.f) s += wgt * G[p * GP];
+        }
+        sAcc[(hd * g.w + xl) * Q + j] += s;
+      }
+    } else
     for (int idx = tid; idx < 2 * nxl * Q; idx += 256) {
       int hd = idx / (nxl * Q);
       int r = idx - hd * nxl * Q;
@@ -757,7 +794,7 @@ static size_t pass1_lds(int Q, int C) {
 }
 static size_t pass2_lds(int Q, int C, int w) {
   size_t QC = (size_t)Q * C;
-  return (2 * QC + 2 * 256 * (size_t)(Q + 1) + 2 * (size_t)w * Q + 512) * 4;
+  return (2 * QC + 2 * 256 * (size_t)(Q + 1) + 2 * (size_t)w * Q + 512 + XR_MAX + 1) * 4;
 }
 
 static int fill_args(const simt_head_desc* d, HeadArgs& a) {
