@@ -4,7 +4,7 @@ set -e
 cd /root/repo/simt_amd/csrc
 bash build.sh >/dev/null
 FILE=$1; MACRO=$2; TAG=$3; shift 3
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -Xclang -target-feature -Xclang -packed-fp32-ops"
 for n in "$@"; do
   ( /opt/rocm/bin/hipcc $FLAGS -D$MACRO=$n -c $FILE.hip -o /root/repo/scratch/${TAG}_$n.o 2>/dev/null
     objs=$(ls ../_build/*.o | grep -v /$FILE.o)

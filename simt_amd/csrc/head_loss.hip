@@ -20,6 +20,10 @@
 #include <math.h>
 
 #define QMAX 40
+#ifndef SIMT_HEAD_ABL
+#define SIMT_HEAD_ABL 0      // timing ablations (results meaningless): 1 no dT partials, 2 no anchors, 4 no x-reduction, 8 no gradient terms,
+                             // 16 no run sums, 32 no gradient staging
+#endif
 #define NSCAL 12
 #define XR_MAX 287   // low-res columns one 256-pixel chunk may touch on the run-based x-reduction of pass 2 (more: the scanning form)
 
@@ -396,7 +400,9 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
       acc[11] += 1.f;
     }
     // dL_y/dT partials: per wave, one label value at a time (labels are spatially coherent -> few rounds)
-    {
+    // (tried and measured slower, round 2: staging q / r per wave as [pixel][j] and letting lane j walk the pixels -- with a register
+    // run sum and scalar branches at label changes 455 us against 330, with one LDS float add per pixel 755: ds_add_f32 is slow)
+    if (!(SIMT_HEAD_ABL & 1)) {
       unsigned long long todo = __ballot(lab_ok);
       const float ir1 = lab_ok ? 1.0f / r1 : 0.f, ir2 = lab_ok ? 1.0f / r2 : 0.f;
       while (todo) {
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
       }
     }
     // ---- anchors: arg-max over all pixels of each channel's upsampled logit (first index), Exist masks (:375-384)
-    if (a.mode == 0) {
+    if (a.mode == 0 && !(SIMT_HEAD_ABL & 2)) {
       unsigned long long ex1 = live ? (1ull << e1.arg) : 0ull, ex2 = live ? (1ull << e2.arg) : 0ull;
       ex1 = wave_or_u64(ex1);
       ex2 = wave_or_u64(ex2);
@@ -427,14 +433,20 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
       // A channel's block-wide best so far (upper half of its key in LDS) is read once per group: lane t holds channel t of both heads.  A wave only reduces a channel when one of its pixels reaches that value (>=: ties go through the key,
       // whose low half prefers the smaller pixel index) -- after the first groups that is rare, and the 2 x Q wave reductions per 64
       // pixels were a fifth of this kernel.  A stale (lower) best only makes a wave do the reduction needlessly.
-      unsigned bestv1 = 0u, bestv2 = 0u;
-      if (lane < Q) { bestv1 = (unsigned)(sKey[lane] >> 32); bestv2 = (unsigned)(sKey[QMAX + lane] >> 32); }
+      // (compared as floats: one v_cmp against a scalar per channel; -0.0 >= +0.0 only sends a wave through the reduction needlessly)
+      float bestf1 = -INFINITY, bestf2 = -INFINITY;
+      if (lane < Q) {
+        const unsigned b1 = (unsigned)(sKey[lane] >> 32), b2 = (unsigned)(sKey[QMAX + lane] >> 32);
+        if (b1) bestf1 = f32_unord(b1);
+        if (b2) bestf2 = f32_unord(b2);
+      }
 #pragma unroll
       for (int j = 0; j < QM; ++j)
         if (j < Q) {
-          float a1 = live ? v1[j] : -INFINITY, a2 = live ? v2[j] : -INFINITY;
-          const unsigned best1 = (unsigned)__builtin_amdgcn_readlane((int)bestv1, j), best2 = (unsigned)__builtin_amdgcn_readlane((int)bestv2, j);
-          if (__ballot(live && f32_ord(a1) >= best1)) {
+          const float best1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bestf1), j));
+          const float best2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bestf2), j));
+          if (__ballot(live && v1[j] >= best1)) {
+            const float a1 = live ? v1[j] : -INFINITY;
             float m1 = wave_max_f(a1);
             unsigned long long b1 = __ballot(live && a1 == m1);
             if (lane == 0 && b1) {
@@ -443,7 +455,8 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
               atomicMax(&sKey[j], key);
             }
           }
-          if (__ballot(live && f32_ord(a2) >= best2)) {
+          if (__ballot(live && v2[j] >= best2)) {
+            const float a2 = live ? v2[j] : -INFINITY;
             float m2 = wave_max_f(a2);
             unsigned long long b2 = __ballot(live && a2 == m2);
             if (lane == 0 && b2) {
@@ -572,6 +585,26 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(HeadArgs a, int nblk
   }
 }
 
+// Weighted sum of up to 4*NB terms of one run [lo, hi) of a chunk's pixels, in pixel order, every LDS read requested before the first
+// use.  mode 0: right-tap weights l1;  1: left-tap weights 1 - l1;  2: last column, whose right tap is the column itself.
+template <int NB>
+__device__ __forceinline__ float run_sum(const float* G, int GP, const float* sL1, int lo, int hi, int mode, float s) {
+  if (SIMT_HEAD_ABL & 16) return s;
+  float wv[NB * 4], gv[NB * 4];
+#pragma unroll
+  for (int u = 0; u < NB * 4; ++u) {
+    const int pp = max(min(lo + u, hi - 1), 0);
+    const float l1 = sL1[pp];
+    const float w = mode == 0 ? l1 : mode == 2 ? (1.f - l1) + l1 : 1.f - l1;
+    wv[u] = lo + u < hi ? w : 0.f;
+    gv[u] = G[pp * GP];
+  }
+#pragma unroll
+  for (int u = 0; u < NB * 4; ++u)
+    if (wv[u] != 0.f) s += wv[u] * gv[u];           // (a zero weight skips the term, as in the scanning form)
+  return s;
+}
+
 // --------------------------------------------------------------------------------------------------------
 // pass 2: gradient w.r.t. the upsampled logits, reduced along x inside the block.  One block per (b, y) row.
 // --------------------------------------------------------------------------------------------------------
@@ -671,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
         if (j < Q) {
           float q1 = exp_le0(v1[j] - e1.vmax) * inv1, q2 = exp_le0(v2[j] - e2.vmax) * inv2;
           float G1 = 0.f, G2 = 0.f;
-          if (live) {
+          if (live && !(SIMT_HEAD_ABL & 8)) {
             if (conf != 255) {
               float oh = (j == conf) ? 1.f : 0.f;
               G1 += gp1 * (q1 - oh);
@@ -690,8 +723,10 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
               G2 += gy2 * (q2 - q2 * sT[QC + j * C + labi] * ir2);
             }
           }
+          if (!(SIMT_HEAD_ABL & 32)) {
           sG[(0 * 256 + tid) * GP + j] = G1;
           sG[(1 * 256 + tid) * GP + j] = G2;
+          } else { asm volatile("" :: "v"(G1), "v"(G2)); }
         }
     }
     __syncthreads();
@@ -701,28 +736,33 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
     const int xl_lo = max(0, (int)src_coord(g.half, g.sx, x0) - 1);
     const int xl_hi = min(g.w - 1, (int)src_coord(g.half, g.sx, xend - 1) + 2);
     const int nxl = xl_hi - xl_lo + 1;
-    if (nxl <= XR_MAX) {
-      // pixels whose left tap is column xl form one run of the chunk ([sStart[xr], sStart[xr+1])), the ones whose right tap is xl the
-      // run before it: two short weighted sums instead of a scan over every pixel that could touch the column
-      for (int idx = tid; idx < 2 * nxl * Q; idx += 256) {
-        const int hd = idx / (nxl * Q);
-        const int r = idx - hd * nxl * Q;
-        const int xr = r / Q, j = r - xr * Q;
+    if (SIMT_HEAD_ABL & 4) {
+    } else if (nxl <= XR_MAX) {
+      // Pixels whose left tap is column xl form one run of the chunk ([sStart[xr], sStart[xr+1])), the ones whose right tap is xl the
+      // run before it: two short weighted sums instead of a scan over every pixel that could touch the column.  A wave takes one
+      // column, its lanes the (head, channel) pairs: run bounds, clamps and masks are wave-uniform (scalar unit), the weights broadcast
+      // LDS reads, the gradient rows contiguous reads at immediate offsets, every term of a run requested before the first use.
+      // Same terms in the same order as the scanning form below (bit-identical).
+      const int wv_ = tid >> 6, ln = tid & 63;
+      for (int xr = wv_; xr < nxl; xr += 4) {
         const int xl = xl_lo + xr;
-        const int a0 = sStart[xr], a1 = sStart[xr + 1], b0 = xr ? sStart[xr - 1] : a0;
-        const float* G = sG + hd * 256 * GP + j;
+        const int a0 = __builtin_amdgcn_readfirstlane(sStart[xr]), a1 = __builtin_amdgcn_readfirstlane(sStart[xr + 1]);
+        const int b0 = xr ? __builtin_amdgcn_readfirstlane(sStart[xr - 1]) : a0;
         const bool edge = xl == g.w - 1;          // the right tap of the last column is the column itself
-        float s = 0.f;
-        for (int p = b0; p < a0; ++p) {
-          const float wgt = sL1[p];
-          if (wgt != 0.f) s += wgt * G[p * GP];           // (a zero weight skips the term, as in the scanning form)
+        const int rlen = max(a0 - b0, a1 - a0);
+        const int rb = rlen <= 8 ? 2 : rlen <= 12 ? 3 : 0;     // runs of at most 4 * rb pixels: every term requested at once (0: looped)
+        for (int L = ln; L < 2 * Q; L += 64) {
+          const int hd = L >= Q ? 1 : 0, j = L - hd * Q;
+          const float* G = sG + hd * 256 * GP + j;
+          float s = 0.f;
+          if (rb == 2) { s = run_sum<2>(G, GP, sL1, b0, a0, 0, s); s = run_sum<2>(G, GP, sL1, a0, a1, edge ? 2 : 1, s); }
+          else if (rb == 3) { s = run_sum<3>(G, GP, sL1, b0, a0, 0, s); s = run_sum<3>(G, GP, sL1, a0, a1, edge ? 2 : 1, s); }
+          else {
+            for (int p = b0; p < a0; p += 4) s = run_sum<1>(G, GP, sL1, p, a0, 0, s);
+            for (int p = a0; p < a1; p += 4) s = run_sum<1>(G, GP, sL1, p, a1, edge ? 2 : 1, s);
+          }
+          sAcc[(hd * g.w + xl) * Q + j] += s;
         }
-        for (int p = a0; p < a1; ++p) {
-          const float l1 = sL1[p];
-          const float wgt = edge ? (1.f - l1) + l1 : 1.f - l1;
-          if (wgt != 0.f) s += wgt * G[p * GP];
-        }
-        sAcc[(hd * g.w + xl) * Q + j] += s;
       }
     } else
     for (int idx = tid; idx < 2 * nxl * Q; idx += 256) {
@@ -845,6 +885,14 @@ extern "C" int simt_head_loss(const simt_head_desc* d, simt_stream_t stream) {
   const int nblk = simt_head_nblk(d->B, d->H, d->W);
   (void)hipMemsetAsync(d->keys, 0, (2 * QMAX + 2) * sizeof(unsigned long long), st);
   size_t lds1 = pass1_lds(d->Q, d->C);
+  SIMT_CHECK(lds1 <= 160 * 1024);
+  static size_t lds1_set = 0;
+  if (lds1 > lds1_set) {
+#define P1ATTR(QM, QT, CT) (void)hipFuncSetAttribute((const void*)head_pass1_kernel<QM, QT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)
+    P1ATTR(24, 22, 19); P1ATTR(28, 25, 19); P1ATTR(24, 0, 0); P1ATTR(QMAX, 0, 0);
+#undef P1ATTR
+    lds1_set = lds1;
+  }
 #define P1(QM, QT, CT) hipLaunchKernelGGL((head_pass1_kernel<QM, QT, CT>), dim3(nblk), dim3(256), lds1, st, a)
   if (d->Q == 22 && d->C == 19) P1(24, 22, 19);          // Cityscapes, K = 3 open classes (BASELINE configs[0..2], [4])
   else if (d->Q == 25 && d->C == 19) P1(28, 25, 19);     // K = 6 (configs[3])
