@@ -163,6 +163,8 @@ class SimTTrainer:
         # through layer2 / layer1 / the stem (whose gradients this stage computes but never applies), so SGD and the re-pack of the
         # updated weights run on the side stream from that point on instead of after the backward (0.7 ms of exclusive tail).
         applied = [n for n in self.sgd_names if self.plan.grad_ready.get(n, 0) > 0]
+        self._ev_post = None
+        self._post_side = os.environ.get("SIMT_POST_SIDE", "1") != "0"
         self._early_cut = max(self.plan.grad_ready[n] for n in applied) if applied else None
         self._early_sgd = (os.environ.get("SIMT_EARLY_SGD", "1") != "0" and self._early_cut is not None and process_group is None
                            and hp.iter_size == 1 and self._early_cut < len(self.plan.bwd_list.items))
@@ -253,8 +255,20 @@ class SimTTrainer:
             self._fwd_both.run()
         # 4. fused head + NTM regularisers + gradients of the low-res logits (every term scaled by 1 / iter_size, :427;
         #    the NTM gradients accumulate on top of the inner loop's leak and of earlier micro-batches)
+        #    The regularisers only feed the Adam step and the loss read-out: they run on the side stream (idle between the frozen forward
+        #    and the first weight gradients) beside the head's gradient pass instead of in front of it (a 100 us single-block kernel).
+        main = torch.cuda.current_stream()
+        side = side_stream(self.dev) if self._post_side else main
+        if self._ev_post is not None:
+            main.wait_event(self._ev_post)     # an earlier micro-batch's regularisers still read the head's outputs
         L.call("simt_head_loss", C.byref(self.head_desc), st)
-        L.call("simt_ntm_post", C.byref(self.post_desc), st)
+        ev_loss = torch.cuda.Event()
+        ev_loss.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev_loss)
+            L.call("simt_ntm_post", C.byref(self.post_desc), side.cuda_stream)
+            self._ev_post = torch.cuda.Event()
+            self._ev_post.record(side)
         L.call("simt_head_grad", C.byref(self.head_desc), st)
 
     def _interleaved_forwards(self):
@@ -383,6 +397,7 @@ class SimTTrainer:
         # 7. optimisers
         if not self._early_sgd:
             self._sgd(lr, st)
+        torch.cuda.current_stream().wait_event(self._ev_post)      # regularisers (side stream): NTM gradients and the losses are final
         for k in range(2):
             ops.adam_step(self.ntm[k], self.ntm_grad[k], self.ntm_m[k], self.ntm_v[k], lr=lr_T, step=self.it_done + 1)
         if not self._early_sgd:

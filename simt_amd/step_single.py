@@ -186,7 +186,13 @@ class SimTSingleTrainer:
         self._fwd.run()
         main.wait_event(ev_fix)
         L.call("simt_head_loss", C.byref(self.head_desc), st)
-        L.call("simt_ntm_post", C.byref(self.post_desc), st)
+        ev_loss = torch.cuda.Event()
+        ev_loss.record(main)
+        with torch.cuda.stream(side):          # the regularisers only feed Adam and the loss read-out: beside the head's gradient pass
+            side.wait_event(ev_loss)
+            L.call("simt_ntm_post", C.byref(self.post_desc), side.cuda_stream)
+            ev_post = torch.cuda.Event()
+            ev_post.record(side)
         L.call("simt_head_grad", C.byref(self.head_desc), st)
         if self.reducer is not None:
             self.reducer.start()
@@ -199,6 +205,7 @@ class SimTSingleTrainer:
         d.wd[0], d.wd[1] = hp.weight_decay, hp.weight_decay
         d.first_step = 1 if self.it_done == 0 else 0
         L.call("simt_sgd_multi", C.byref(d), st)
+        main.wait_event(ev_post)
         ops.adam_step(self.ntm, self.ntm_grad, self.ntm_m, self.ntm_v, lr=lr_T, step=self.it_done + 1)
         self.plan.repack()
         self.it_done += 1
