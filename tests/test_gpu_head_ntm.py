@@ -138,12 +138,21 @@ def test_head_against_reference_golden(dev, name):
     close(r["ntm_after"][1], d["ntm2_after"], 1e-5, "NTM2 after Adam")
 
 
-def test_head_bigger_than_one_block_vs_oracle(dev):
-    """B=2, 97x129 -> 776... pixels: several blocks per pass, W > 256 (two x-chunks in pass 2), non-square."""
+# (B, h, w, H, W): pass 2's x-reduction takes a different route per geometry -- runs of <= 8 pixels per low-res column (the production
+# 8x upsample: all terms of a run in flight), 9..12, longer (looped), and more low-res columns than a 256-pixel chunk's run table
+# holds (logits WIDER than the image: the scanning form)
+HEAD_GEOMS = {"up8_two_chunks": (2, 13, 37, 97, 289), "up10": (1, 3, 13, 16, 128), "up16_looped": (1, 3, 9, 16, 144),
+              "down_scanning": (1, 3, 330, 8, 272)}
+
+
+@pytest.mark.parametrize("geom", list(HEAD_GEOMS))
+def test_head_bigger_than_one_block_vs_oracle(dev, geom):
+    """Head kernels against the oracle on explicit low-res logits: several blocks per pass, W > 256 (two x-chunks in pass 2),
+    non-square, every route of the x-reduction."""
     K, Cn = 3, 19
     Q = Cn + K
     g = torch.Generator().manual_seed(5)
-    B, h, w, H, W = 2, 13, 37, 97, 289
+    B, h, w, H, W = HEAD_GEOMS[geom]
     p1 = torch.randn(B, Q, h, w, generator=g) * 3
     p2 = torch.randn(B, Q, h, w, generator=g) * 3
     f2 = torch.randn(B, Cn, h, w, generator=g) * 4
