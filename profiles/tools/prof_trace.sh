@@ -1,5 +1,5 @@
 set -u
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_t; rm -rf $OUT; mkdir -p $OUT
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_t2; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT/prod -- python3 $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extra-passes > $OUT/prod.log 2>&1
 cd $ROOT
@@ -39,6 +39,14 @@ for q in per:
     g = np.array([x[0] for x in gl])
     print("   gap us percentiles 10/50/90/99:", np.percentile(g, [10, 50, 90, 99]).round(1), " sum of gaps > 20 us: %.2f ms (%d)" % (g[g > 20].sum() / 1e3, (g > 20).sum()))
     for x in gl[-12:]: print("     gap %.0f us at %.2f ms: %s -> %s" % x)
+# sequence around the head
+hp=[r for r in sel if "head_pass1" in r["Kernel_Name"]]
+if hp:
+    c0=int(hp[0]["Start_Timestamp"])-400000; c1=c0+2600000
+    print("--- kernels around the head (ms from window start, dur us, queue, name)")
+    for r in sel:
+        st=int(r["Start_Timestamp"]); en=int(r["End_Timestamp"])
+        if c0<=st<c1: print("  %8.3f %7.1f q%s %s" % ((st-a)/1e6,(en-st)/1e3,r[key],r["Kernel_Name"].split("(")[0][-50:]))
 PY
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
-cat $OUT/summary.txt | head -70
+cat $OUT/summary.txt | tail -120
