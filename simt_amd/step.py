@@ -166,7 +166,7 @@ class SimTTrainer:
         self._ev_post = None
         self._post_side = os.environ.get("SIMT_POST_SIDE", "1") != "0"
         self._early_cut = max(self.plan.grad_ready[n] for n in applied) if applied else None
-        self._early_sgd = (os.environ.get("SIMT_EARLY_SGD", "1") != "0" and self._early_cut is not None and process_group is None
+        self._early_sgd = (os.environ.get("SIMT_EARLY_SGD", "1") != "0" and self._early_cut is not None
                            and hp.iter_size == 1 and self._early_cut < len(self.plan.bwd_list.items))
         self._pack_applied = self.plan.pack_subset(self.sgd_names) if self._early_sgd else None
         # ---- data parallel: bucketed mean all-reduce overlapped with backward
@@ -375,13 +375,14 @@ class SimTTrainer:
             last = mi == hp.iter_size - 1
             self._micro_batch(img, lab, st)
             # 5. trunk backward (+ 6. data-parallel mean of the gradients, bucket by bucket, on a side stream)
+            if self._early_sgd:            # (with a reducer: the exchange completes on the side stream too, ahead of its SGD)
+                self._backward_early_sgd(lr, st)
+                continue
             if self.reducer is not None and hp.iter_size == 1:
                 self.reducer.start()
                 self.plan.backward(hook=self.reducer.ready_upto)
+                torch.cuda.current_stream().wait_event(self._ev_post)      # the NTM gradients it exchanges last (side stream)
                 self.reducer.finish()
-                continue
-            if self._early_sgd:
-                self._backward_early_sgd(lr, st)
                 continue
             self.plan.backward()
             if hp.iter_size > 1:      # loss.backward() accumulates into .grad (:428): keep the running sum beside the plan's buffer
@@ -392,6 +393,7 @@ class SimTTrainer:
                 else:
                     L.call("simt_vec_acc", flat.data_ptr(), self._grad_acc.data_ptr(), flat.numel(), 1, st)
                     if self.reducer is not None:   # one exchange of the accumulated gradient (no overlap with backward)
+                        torch.cuda.current_stream().wait_event(self._ev_post)
                         self.reducer.start()
                         self.reducer.finish()
         # 7. optimisers
@@ -418,8 +420,13 @@ class SimTTrainer:
         layer3 read the packed weights the re-pack overwrites); the list's final join makes the main stream wait for all of it."""
         main, side = torch.cuda.current_stream(), side_stream(self.dev)
         done = [False]
+        red = self.reducer
+        if red is not None:
+            red.start()
 
         def hook(n, ev):
+            if red is not None and not done[0]:
+                red.ready_upto(n, ev)      # data parallel: the buckets whose gradients are final start their all-reduce
             if done[0] or n < self._early_cut:
                 return
             done[0] = True
@@ -427,6 +434,10 @@ class SimTTrainer:
             ev_main.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ev_main)
+                if red is not None:
+                    # last buckets + NTM gradients, then THIS stream waits for the exchange: the main stream keeps walking through
+                    # layer2 / layer1 / the stem (rank-local gradients) while the mean gradients arrive and are applied
+                    red.finish()
                 self._sgd(lr, side.cuda_stream)
                 self._pack_applied.run()
         self.plan.backward(hook=hook)

@@ -30,16 +30,25 @@ def _worker(rank, world, port, q):
         hp = Hyper(open_classes=K, lr=6e-4, lr_T=6e-3)
         tr = SimTTrainer(st, fst, so.ntm_init(19, K, 1), so.ntm_init(19, K, 2), hp, cd.numpy(), 2, 65, 65, dtype=torch.float32,
                          device=dev, layers=layers, process_group=dist.group.WORLD)
+        os.environ["SIMT_EARLY_SGD"] = "0"        # same exchange with the optimiser step after the whole backward: bit-identical replicas
+        late = SimTTrainer(st, fst, so.ntm_init(19, K, 1), so.ntm_init(19, K, 2), hp, cd.numpy(), 2, 65, 65, dtype=torch.float32,
+                           device=dev, layers=layers, process_group=dist.group.WORLD)
+        os.environ.pop("SIMT_EARLY_SGD")
+        assert tr._early_sgd and not late._early_sgd
         solo = SimTTrainer(st, fst, so.ntm_init(19, K, 1), so.ntm_init(19, K, 2), hp, cd.numpy(), 2, 65, 65, dtype=torch.float32,
                            device=dev, layers=layers) if rank == 0 else None
         for it in range(2):
             img, lab = so.synthetic_batch(2, 65, 65, cd.numpy(), seed=100 + 10 * rank + it, block=8)
             tr.step(img.to(dev), lab.to(dev), it)
+            late.step(img.to(dev), lab.to(dev), it)
             if solo is not None:
                 solo.step(img.to(dev), lab.to(dev), it)
         torch.cuda.synchronize()
         vec = torch.cat([tr.params[k].flatten() for k in sorted(tr.params) if tr.params[k].dtype != torch.long and "running" not in k]
                         + [tr.ntm[0].flatten(), tr.ntm[1].flatten(), tr.wraw[0].flatten()]).cpu()
+        lvec = torch.cat([late.params[k].flatten() for k in sorted(late.params) if late.params[k].dtype != torch.long and "running" not in k]
+                         + [late.ntm[0].flatten(), late.ntm[1].flatten(), late.wraw[0].flatten()]).cpu()
+        assert torch.equal(vec, lvec), "early (side-stream) and late optimiser step give different replicas"
         gathered = [torch.zeros_like(vec) for _ in range(world)]
         dist.all_gather(gathered, vec)
         same = all(torch.equal(gathered[0], g) for g in gathered[1:])
