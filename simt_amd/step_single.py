@@ -197,6 +197,7 @@ class SimTSingleTrainer:
         if self.reducer is not None:
             self.reducer.start()
             self._bwd.run()
+            main.wait_event(ev_post)           # the NTM gradients it exchanges (side stream)
             self.reducer.finish()
         else:
             self._bwd.run()
