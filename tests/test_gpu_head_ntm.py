@@ -143,13 +143,16 @@ def test_head_against_reference_golden(dev, name):
 # holds (logits WIDER than the image: the scanning form)
 HEAD_GEOMS = {"up8_two_chunks": (2, 13, 37, 97, 289), "up10": (1, 3, 13, 16, 128), "up16_looped": (1, 3, 9, 16, 144),
               "down_scanning": (1, 3, 330, 8, 272)}
+# K = 3 and 6 run the builds with compile-time channel counts (Q = 22, 25); K = 4 the run-time-count build of the same width (Q = 23),
+# K = 15 the wide one (Q = 34)
+HEAD_KS = [("up8_two_chunks", 3), ("up10", 3), ("up16_looped", 3), ("down_scanning", 3), ("up8_two_chunks", 4), ("up10", 6), ("up10", 15)]
 
 
-@pytest.mark.parametrize("geom", list(HEAD_GEOMS))
-def test_head_bigger_than_one_block_vs_oracle(dev, geom):
+@pytest.mark.parametrize("geom,K", HEAD_KS)
+def test_head_bigger_than_one_block_vs_oracle(dev, geom, K):
     """Head kernels against the oracle on explicit low-res logits: several blocks per pass, W > 256 (two x-chunks in pass 2),
-    non-square, every route of the x-reduction."""
-    K, Cn = 3, 19
+    non-square, every route of the x-reduction, every instantiation of the kernels."""
+    Cn = 19
     Q = Cn + K
     g = torch.Generator().manual_seed(5)
     B, h, w, H, W = HEAD_GEOMS[geom]
