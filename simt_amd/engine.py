@@ -628,7 +628,7 @@ class TrunkPlan:
         Ktot = len(taps) * Cin
         nsplit = ops.wgrad_nsplit(M, Cd, Ktot, self.dtype)
         assert nsplit * Cd * Ktot <= self._slab_cap
-        slab = self.buf("wgrad.slab", self._slab_cap, dtype=torch.float32)
+        slab = self.buf("wgrad.slab" if stream == 1 else "wgrad.slab.main", self._slab_cap, dtype=torch.float32)    # (one per stream: in-order reuse)
         d = ops.make_wgrad_desc(dy, x, slab, B=Bn, H=Hi, W=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cd=Cd, taps=taps, stride=stride,
                                 nsplit=nsplit, ldd=ldd)
         alg_cd = sum(pt[3] for pt in parts) // max(1, len({pt[2] for pt in parts}))
@@ -842,9 +842,13 @@ class TrunkPlan:
               ops.dt_code(dt))
         dy0 = self.buf("g.dy0", M0, 64)
         self._bn_bwd(b, dz=da0, y=self.saved["stem.y"], bname="bn1", dy=dy0, M=M0, Cn=64, mask_mode=2)
-        b.wait(b.record(0), 1)
+        # the very last weight gradient runs on the main stream (which has nothing else left) beside the side stream's backlog of
+        # layer1 weight gradients instead of behind it
+        stem_stream = 0 if os.environ.get("SIMT_STEM_WGRAD_MAIN", "1") != "0" else 1
+        if stem_stream == 1:
+            b.wait(b.record(0), 1)
         self._wgrad(b, dy0, self.saved["stem.A"], None, Bn=1, Hi=1, Wi=M0, Cin=192, Ho=1, Wo=M0, Cd=64, ldd=64,
-                    taps=[(0, 0)], stride=1, parts=[("conv1.weight", 0, 0, 64, 1, 147)])
+                    taps=[(0, 0)], stride=1, parts=[("conv1.weight", 0, 0, 64, 1, 147)], stream=stem_stream)
         b.wait(b.record(1), 0)        # join: the optimiser (stream 0) sees every gradient
 
     def _build_head_bwd(self, hd, dz_prev, Mo, c4, bi, bnr=None):
