@@ -608,9 +608,10 @@ __device__ __forceinline__ float run_sum(const float* G, int GP, const float* sL
 // --------------------------------------------------------------------------------------------------------
 // pass 2: gradient w.r.t. the upsampled logits, reduced along x inside the block.  One block per (b, y) row.
 // --------------------------------------------------------------------------------------------------------
-// launch bounds: 2 waves per SIMD for every QM.  With 3 (170 VGPRs) the QM = 24 build spilled 272 B per lane to scratch -- the
-// 256 MB of HBM traffic per launch that round 1's PMC pass showed against ~30 MB algorithmic; without the spill 1 016 -> 826 us on
-// cold operands at 4 x 768 x 768 (pass 1 is the other way round: 630 us with its 104-byte spill at 3 waves, 802 us without at 2).
+// launch bounds: at most 2 waves per SIMD are asked for.  The run-time-count builds need it (at 3 the QM = 24 build spilled 272 B per lane to
+// scratch: round 1's "256 MB of HBM traffic per launch" against ~30 MB algorithmic); the compile-time-count builds come out at ~160
+// VGPRs without spills.  At 4 x 768 x 768 on cold operands, pass 2 + y-reduction: 1 016 us (round 1) -> 826 (no spill) -> 680 (compile-time
+// counts, one-instruction exp) -> 432 (run-based x-reduction).  Pass 1 keeps 3 waves per SIMD with a small spill (faster than 2 without).
 template <int QM, int QT, int CT>
 __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
   const HeadGeom g = a.g;
