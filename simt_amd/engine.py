@@ -341,6 +341,12 @@ class TrunkPlan:
         """alg_k: algorithmic reduction length per output element (defaults to ntaps*Cin; the K-padded head dgrad and
         the stem pass their true value) -> algorithmic FLOPs = 2 * M * Cout * alg_k."""
         wp, tile, npad = wp_info
+        # Few pixels (DeepLabv3's stride-16 maps: M = 8 192 at 512 x 1024): 128-row x 256-column tiles are 64 workgroups on 256 CUs, each
+        # streaming the whole weight panel through its LDS.  Narrower column tiles fill the chip and cut the staged bytes per workgroup
+        # (same packed operand: Npad is a multiple of every tile width).
+        if x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and os.environ.get("SIMT_SMALL_M_TILES", "1") != "0":
+            while tile > 64 and ((Bn * Ho * Wo + 127) // 128) * (npad // tile) < 256 and npad % (tile // 2) == 0:
+                tile //= 2
         d = ops.make_conv_desc(x, wp, y, B=Bn, H=Hi, W=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, taps=taps, stride=stride,
                                bias=bias, res=res, stats=stats, relu=relu, Npad=npad, tile_n=tile, ldy=ldy,
                                Nstore=Nstore, mask=mask, res_bits=res_bits, bnr=bnr)
