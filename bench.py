@@ -215,7 +215,17 @@ def main():
             yield img, lab
 
     tr = make_trainer(False)
+    red = getattr(tr, "reducer", None)
+    if red is not None:
+        red.measure = True
     dt, med = timed(tr, resident(1234 + rank), a.steps, a.warmup)
+    comm = None
+    if red is not None:
+        comm = red.report()              # the exchange of the timed steps (plus warm-up): bytes, buckets, exposed wait
+        comm["what"] = ("mean all-reduce of the applied prefix of the flat gradient buffer + the NTM gradients over "
+                        + ("RCCL/xGMI" if backend == "nccl" else backend) + ", bucketed, on a side HIP stream under the backward; "
+                        "exposed_wait = time the optimiser-step stream sat waiting for it in BucketReducer.finish()")
+        red.measure = False
     ms_step = dt / a.steps * 1e3
     value = a.batch * world * a.steps / dt
 
@@ -308,6 +318,8 @@ def main():
                            "step_tflops_conv_algorithmic": round(value * flop_img / 1e12, 1),
                            "frac_of_conv_roofline": round(value * flop_img / 1e12 / (world * MFMA_PEAK_TFLOPS[a.dtype]), 4)},
                 "roofline": roof, "cpu_baseline": cpu}
+        if comm is not None:
+            line["comm"] = comm
         line.update(extra)
         print(json.dumps(line))
     if world > 1:

@@ -193,6 +193,8 @@ typedef struct {
                           * 1: F.interpolate(bilinear), align_corners=False, the in-model upsample of model/deeplabv3.py:137 fused here */
   int32_t fix_logits;   /* 1: fixp holds the frozen model's low-res LOGITS; posterior = softmax(upsample(logits)) -- what
                          * trainV2_simt.py:354 computes for a model that upsamples inside.  0: fixp = low-res probabilities */
+  uint8_t* conf_out;    /* optional (may be NULL): [B][H][W] the per-pixel `Conf_label_target` of trainV2_simt.py:357-362,387-393
+                         * as simt_head_loss decided it: class index 0..Q-1, 255 = no confidence label (mode 1: the label itself) */
 } simt_head_desc;
 int simt_head_nblk(int B, int H, int W);
 int simt_head_part_floats(int Q, int C);

@@ -92,6 +92,19 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float rcp, int& q, int
   if (r >= d) { q++; r -= d; }
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: a process that drives several devices (or sets a
+// larger size later) needs it once per (device, size).  `cache` is one zero-initialised static per call site; the racy update is benign
+// (the attribute call is idempotent).
+#define SIMT_MAX_DEVICES 16
+struct SimtLdsAttrCache { size_t set[SIMT_MAX_DEVICES]; };
+static inline bool simt_lds_attr_needed(SimtLdsAttrCache* c, size_t lds) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SIMT_MAX_DEVICES) return true;
+  if (lds <= c->set[dev]) return false;
+  c->set[dev] = lds;
+  return true;
+}
+
 const void* simt_zero_page(void);  // 4 KB of device zeros (conv_igemm.hip)
 
 #define SIMT_CHECK(cond)                                                        \

@@ -647,11 +647,9 @@ int launch_rows(Conv2KArgs k, int npad, hipStream_t st) {
   const int nwg = k.ntiles_m * k.ntiles_n;
   const int cap = NCW == 8 ? 256 : 512;                        // persistent: one or two (NCW = 4: 384 threads) workgroups per CU
   const int G = nwg < cap ? nwg : cap;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SimtLdsAttrCache attr_cache;
+  if (simt_lds_attr_needed(&attr_cache, g::LDS))
     (void)hipFuncSetAttribute((const void*)conv1x1_rows_kernel<KS, TM, D, FL, NSW, NCW, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, g::LDS);
-    attr_set = true;
-  }
   hipLaunchKernelGGL((conv1x1_rows_kernel<KS, TM, D, FL, NSW, NCW, TN>), dim3(G), dim3(g::NT), g::LDS, st, k, G);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;

@@ -356,11 +356,9 @@ int simt_conv_stream_launch(Conv2KArgs k, int npad, hipStream_t st) {
   k.ntiles_m = (k.M + BM - 1) / BM;
   const int nwg = k.ntiles_m * k.ntiles_n;
   const int G = nwg < 256 ? nwg : 256;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SimtLdsAttrCache attr_cache;
+  if (simt_lds_attr_needed(&attr_cache, LDS_BYTES))
     (void)hipFuncSetAttribute((const void*)conv1x1_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
-  }
   hipLaunchKernelGGL(conv1x1_stream_kernel, dim3(G), dim3(NT), LDS_BYTES, st, k, G);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;

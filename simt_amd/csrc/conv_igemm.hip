@@ -267,11 +267,9 @@ static int launch_conv(const ConvKArgs& k, hipStream_t st) {
   size_t stage_bytes = 2 * (128 * 128 + BN * 128);
   size_t epi_bytes = (size_t)128 * (BN + 4) * 4 + 2 * 256 * 4;
   size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SimtLdsAttrCache attr_cache;
+  if (simt_lds_attr_needed(&attr_cache, lds))
     (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, TO, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
   int nwg = k.ntiles_m * k.ntiles_n;
   hipLaunchKernelGGL((conv_igemm_kernel<T, TO, BN>), dim3(nwg), dim3(256), lds, st, k);
   SIMT_LAUNCH_CHECK();

@@ -504,11 +504,9 @@ static int launch_conv2m(const Conv2KArgs& k, hipStream_t st) {
   const size_t ring = NST * (size_t)(BM * 128 + BN * 128);
   const size_t epi = (size_t)BM * (BN * 2 + 8) + (size_t)(512 / (BN / 8)) * 2 * BN * 4;
   const size_t lds = ring > epi ? ring : epi;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SimtLdsAttrCache attr_cache;
+  if (simt_lds_attr_needed(&attr_cache, lds))
     (void)hipFuncSetAttribute((const void*)conv_igemm2_kernel<BN, TM, NST, MODE, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
   hipLaunchKernelGGL((conv_igemm2_kernel<BN, TM, NST, MODE, LW>), dim3(k.ntiles_m * k.ntiles_n), dim3(512 + LW * 64), lds, st, k);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;

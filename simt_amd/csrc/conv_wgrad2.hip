@@ -96,7 +96,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
   // before the loop instead of two fast_divmod per row and stage (the issue phase is what the partner wave's MFMA shadow has to hide).
   int r_oy[2], r_ox[2];
   unsigned r_xo[2], r_do[2];                                   // running byte offsets of the row's pixel in x / dy
-  const int adv_y = BP / a.Wo, adv_x = BP % a.Wo;
+  // one stage = BP pixels further in the (wrapping) per-image raster: on maps of fewer than BP pixels a stage crosses several images,
+  // so the advance is taken modulo Ho*Wo (then adv_y < Ho and ONE conditional subtraction below is exact for any map size)
+  const int adv_r = BP % HoWo;
+  const int adv_y = adv_r / a.Wo, adv_x = adv_r % a.Wo;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m_begin + i * 32 + row_in_iter;
@@ -265,11 +268,9 @@ int simt_conv_wgrad_bf16_v2(const simt_wgrad_desc* d, simt_stream_t stream) {
   k.rcpHoWo = 1.0f / (float)(d->Ho * d->Wo);
   for (int i = 0; i < SIMT_MAX_TAPS; ++i) { k.tdy[i] = d->dy_[i]; k.tdx[i] = d->dx_[i]; }
   const int lds = 3 * 3 * 64 * 256;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static SimtLdsAttrCache attr_cache;
+  if (simt_lds_attr_needed(&attr_cache, lds))
     (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
   const int grid = k.cotiles * k.ktiles * k.nsplit;
 #ifdef SIMT_ABLATION     // timing ablations (loads only / MFMA only: MEANINGLESS outputs), never in the product library
   static const int mode = getenv("SIMT_WGRAD2_MODE") ? atoi(getenv("SIMT_WGRAD2_MODE")) : 0;

@@ -235,6 +235,7 @@ struct HeadArgs {
   int QP;
   float gscale;
   int mode;                    // 0 = SimT loss block; 1 = warm-up stage: plain CE of both heads against `label`
+  unsigned char* conf_out;     // optional [B][H][W]: the confidence label decided per pixel (255 = none)
 };
 
 // Full-wave sum with DPP row operations (no LDS crossbar): result valid in lane 63.
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
     }
 
     if (live) {
+      if (a.conf_out) a.conf_out[p] = (unsigned char)conf;
       if (conf != 255) {
         float l1 = 0.f, l2 = 0.f;
 #pragma unroll
@@ -861,6 +863,7 @@ static int fill_args(const simt_head_desc* d, HeadArgs& a) {
   a.part = d->part; a.keys = (unsigned long long*)d->keys; a.hout = d->hout; a.g1 = d->g1; a.QP = d->QP;
   a.gscale = d->gscale;
   a.mode = d->mode;
+  a.conf_out = d->conf_out;
   SIMT_CHECK(d->mode == 0 || d->mode == 1);
   return SIMT_OK;
 }
@@ -887,12 +890,11 @@ extern "C" int simt_head_loss(const simt_head_desc* d, simt_stream_t stream) {
   (void)hipMemsetAsync(d->keys, 0, (2 * QMAX + 2) * sizeof(unsigned long long), st);
   size_t lds1 = pass1_lds(d->Q, d->C);
   SIMT_CHECK(lds1 <= 160 * 1024);
-  static size_t lds1_set = 0;
-  if (lds1 > lds1_set) {
+  static SimtLdsAttrCache lds1_cache;
+  if (simt_lds_attr_needed(&lds1_cache, lds1)) {
 #define P1ATTR(QM, QT, CT) (void)hipFuncSetAttribute((const void*)head_pass1_kernel<QM, QT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)
     P1ATTR(24, 22, 19); P1ATTR(28, 25, 19); P1ATTR(24, 0, 0); P1ATTR(QMAX, 0, 0);
 #undef P1ATTR
-    lds1_set = lds1;
   }
 #define P1(QM, QT, CT) hipLaunchKernelGGL((head_pass1_kernel<QM, QT, CT>), dim3(nblk), dim3(256), lds1, st, a)
   if (d->Q == 22 && d->C == 19) P1(24, 22, 19);          // Cityscapes, K = 3 open classes (BASELINE configs[0..2], [4])
@@ -921,12 +923,11 @@ extern "C" int simt_head_grad(const simt_head_desc* d, simt_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   size_t lds2 = pass2_lds(d->Q, d->C, d->w);
   SIMT_CHECK(lds2 <= 160 * 1024);
-  static size_t lds2_set = 0;
-  if (lds2 > lds2_set) {
+  static SimtLdsAttrCache lds2_cache;
+  if (simt_lds_attr_needed(&lds2_cache, lds2)) {
 #define P2ATTR(QM, QT, CT) (void)hipFuncSetAttribute((const void*)head_pass2_kernel<QM, QT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)
     P2ATTR(24, 22, 19); P2ATTR(28, 25, 19); P2ATTR(24, 0, 0); P2ATTR(QMAX, 0, 0);
 #undef P2ATTR
-    lds2_set = lds2;
   }
 #define P2(QM, QT, CT) hipLaunchKernelGGL((head_pass2_kernel<QM, QT, CT>), dim3(d->B * d->H), dim3(256), lds2, st, a)
   if (d->Q == 22 && d->C == 19) P2(24, 22, 19);

@@ -88,11 +88,19 @@ class DevicePrefetcher:
 
     source: iterator of (rgb u8 [B,Hs,Ws,3], label u8 [B,Hs,Ws] or None, meta) host arrays / tensors (numpy or torch; pinned
     tensors are uploaded in place, anything else is staged through this object's pinned buffers).
-    Each __next__ returns (image f32 [B,3,h,w], label i64 [B,h,w] | None, meta) resident in HBM; the tensors stay valid until the
-    next-but-one call (two slots)."""
+    Each __next__ returns (image f32 [B,3,h,w], label i64 [B,h,w] | None, meta) resident in HBM.
 
-    def __init__(self, source, prep, mirror_fn=None, depth=2):
+    Slot life time: the consumer may HOLD `hold` batches at once (gradient accumulation pulls `iter_size` micro-batches before the step
+    that reads them is enqueued: tools/trainV2_simt.py `mb = [next(data) for _ in range(iter_size)]`).  The tensors returned by call k
+    stay valid until call k + hold: only then is the slot's `free` event recorded on the consumer's stream (everything enqueued on
+    that stream up to that point -- the step that consumed batch k included -- precedes the refill), and the copy stream waits for
+    it.  2*hold slots, so the next group of `hold` batches is uploaded while the current one is being consumed."""
+
+    def __init__(self, source, prep, mirror_fn=None, hold=1, depth=None):
         self.src, self.prep, self.mirror_fn = iter(source), prep, mirror_fn
+        self.hold = max(1, int(hold))
+        depth = 2 * self.hold if depth is None else depth
+        assert depth > self.hold, "the consumer holds `hold` slots: at least one more is needed to hand out"
         dev, B = prep.dev, prep.B
         self.copy_stream = torch.cuda.Stream(device=dev)
         self.slots = []
@@ -108,6 +116,7 @@ class DevicePrefetcher:
             self.slots.append(s)
         self.head = 0          # next slot to hand out
         self.filled = 0
+        self.calls = 0
         self.done = False
         for i in range(depth):
             self._fill(i)
@@ -162,10 +171,12 @@ class DevicePrefetcher:
         cur.wait_event(s["ready"])
         out = (s["x"], s["lab"] if s["has_lab"] else None, s["meta"])
         self.filled -= 1
+        self.calls += 1
         self.head = (i + 1) % len(self.slots)
-        # refill the slot handed out one call ago: everything the consumer enqueued on it so far precedes this event
-        prev = (i - 1) % len(self.slots)
-        if len(self.slots) > 1 and self._handed(prev):
+        # release + refill the slot handed out `hold` calls ago: the consumer no longer holds it, and everything it enqueued on this
+        # stream so far (the step that read it) precedes the event the copy stream will wait for
+        prev = (i - self.hold) % len(self.slots)
+        if self.calls > self.hold and self._handed(prev):
             ev = torch.cuda.Event()
             ev.record(cur)
             self.slots[prev]["free"] = ev
@@ -185,8 +196,10 @@ class GpuLoader:
     reference's batches (`images, labels, _, _ = batch`), already on the device.  Incomplete last batches are dropped (the
     reference repeats the list to max_iters, so it never sees one)."""
 
-    def __init__(self, dataset, batch_size, shuffle=True, num_workers=4, device="cuda:0", seed=1234, rank=0, world=1, epochs=None):
+    def __init__(self, dataset, batch_size, shuffle=True, num_workers=4, device="cuda:0", seed=1234, rank=0, world=1, epochs=None,
+                 hold=1):
         self.ds, self.B, self.shuffle, self.workers = dataset, batch_size, shuffle, max(1, num_workers)
+        self.hold = hold            # batches the consumer keeps at once (= --iter-size): see DevicePrefetcher
         self.dev, self.seed, self.rank, self.world, self.epochs = torch.device(device), seed, rank, world, epochs
         self._prep = None
         self._rng = np.random.default_rng(seed + 7919 * rank)
@@ -233,5 +246,5 @@ class GpuLoader:
             yield from gen
         # `flip = np.random.choice(2) * 2 - 1` per item (cityscapes_dataset.py:109)
         mirror_fn = (lambda n: (self._rng.integers(0, 2, n) == 0).tolist()) if getattr(self.ds, "is_mirror", False) else None
-        pf = DevicePrefetcher(chain(), self._prep, mirror_fn=mirror_fn)
+        pf = DevicePrefetcher(chain(), self._prep, mirror_fn=mirror_fn, hold=self.hold)
         return ((x, lab, meta[0], meta[1]) for (x, lab, meta) in pf)

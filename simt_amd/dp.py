@@ -9,6 +9,8 @@ as soon as the launch that completes its last tensor has been enqueued -- the ex
 backward of layer3.  Buckets are sized for xGMI rings (7 links x ~153 GB/s per GPU, per-link bound): few, large
 messages (default 32 MB) rather than NVSwitch-style small ones.
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -44,6 +46,26 @@ class BucketReducer:
         self.avg = backend == "nccl"
         self.handles = []
         self.next = 0
+        # self-diagnosis of a multi-GPU run (bench.py "comm"): per finish() an event pair around the wait of the calling stream
+        self.measure = False
+        self._waits = []          # [(event before the wait, event after it, host seconds spent in handle.wait())]
+
+    def bytes_per_step(self):
+        """Bytes this rank hands to the all-reduce per step (payload, not wire traffic: a ring moves 2 (N-1)/N of it per GPU)."""
+        return sum((e - s) for s, e, _ in self.buckets) * self.flat.element_size() + sum(t.numel() * t.element_size() for t in self.extra)
+
+    def report(self):
+        """-> dict for bench.py's "comm" object.  Synchronises.  exposed_wait = time the stream that called finish() (the side stream
+        of the early optimiser step, or the main stream) sat waiting for the exchange: the part of the all-reduce NOT hidden under
+        the backward.  SURVEY 8e: >= 6.5x at 8 GPUs needs this to stay under ~2 ms."""
+        if self.cuda:
+            torch.cuda.synchronize()
+        ms = sorted((a.elapsed_time(b) if a is not None else 0.0) + h * 1e3 for a, b, h in self._waits)
+        return {"bytes_per_step": int(self.bytes_per_step()), "buckets": len(self.buckets),
+                "bucket_bytes": [int((e - s) * self.flat.element_size()) for s, e, _ in self.buckets],
+                "extra_tensors": len(self.extra), "world": self.world, "op": "AVG" if self.avg else "SUM+div",
+                "exposed_wait_ms_median": round(ms[len(ms) // 2], 4) if ms else None,
+                "exposed_wait_ms_max": round(ms[-1], 4) if ms else None, "steps_measured": len(ms)}
 
     def start(self):
         self.handles, self.next = [], 0
@@ -90,13 +112,26 @@ class BucketReducer:
         else:
             for t in self.extra:
                 self._reduce(t)
+        e0 = e1 = None
+        if self.measure and self.cuda:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
+        t0 = time.perf_counter()
         for h in self.handles:
             if isinstance(h, tuple):
                 h[0].wait()
                 h[1].div_(self.world)
             else:
                 h.wait()
+        host = time.perf_counter() - t0 if not self.avg else 0.0      # RCCL: wait() only orders streams; gloo: blocks the host
         if self.cuda:
             done = torch.cuda.Event()
             done.record(self.comm)
             torch.cuda.current_stream().wait_event(done)
+        if self.measure:
+            if self.cuda:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(torch.cuda.current_stream())
+            self._waits.append((e0, e1, host))
+            if len(self._waits) > 256:
+                self._waits.pop(0)

@@ -140,6 +140,9 @@ class SimTTrainer:
         hd.grad_dtype = ops.dt_code(dtype)
         hd.th_high, hd.th_low, hd.lambda_seg, hd.lambda_place = hp.th_high, hp.th_low, hp.lambda_seg, hp.lambda_place
         hd.gscale = 1.0 / hp.iter_size
+        # per-pixel Conf_label_target of the last (micro-)batch (trainV2_simt.py:357-362,387-393), 255 = none: 1 byte per pixel
+        self.conf_label = torch.full((B, H, W), 255, device=dev, dtype=torch.uint8)
+        hd.conf_out = self.conf_label.data_ptr()
         self.head_desc = hd
         # ---- NTM descriptors
         ni = L.NtmInnerDesc()
@@ -166,6 +169,15 @@ class SimTTrainer:
         self._ev_post = None
         self._post_side = os.environ.get("SIMT_POST_SIDE", "1") != "0"
         self._early_cut = max(self.plan.grad_ready[n] for n in applied) if applied else None
+        if self._early_cut is not None:
+            # The block that produced the last applied weight gradient lists its wgrads BEFORE its input-gradient convs
+            # (engine._build_backward), and those convs read the packed operands of conv1 / downsample that the early re-pack
+            # overwrites: fire at the first hook point at or after the END of that block, so that the event the side stream waits
+            # for covers them (WAR).  If the block has no input gradient (nothing below it is differentiated) the cut stands.
+            blk = min((m for m in self.plan.bwd_marks.values() if m[1] >= self._early_cut), key=lambda m: m[1], default=None)
+            if blk is not None and blk[3] is not None:
+                later = [c for c in sorted(set(self.plan.grad_ready.values())) if c >= blk[1]]
+                self._early_cut = later[0] if later else None
         self._early_sgd = (os.environ.get("SIMT_EARLY_SGD", "1") != "0" and self._early_cut is not None
                            and hp.iter_size == 1 and self._early_cut < len(self.plan.bwd_list.items))
         self._pack_applied = self.plan.pack_subset(self.sgd_names) if self._early_sgd else None
@@ -415,9 +427,10 @@ class SimTTrainer:
         L.call("simt_sgd_multi", C.byref(d), st)
 
     def _backward_early_sgd(self, lr, st):
-        """Backward with the SGD step and the re-pack of the updated layers enqueued on the side stream as soon as the last applied
-        gradient has been enqueued.  The side stream first waits for the main stream's launches up to that point (the dgrad convs of
-        layer3 read the packed weights the re-pack overwrites); the list's final join makes the main stream wait for all of it."""
+        """Backward with the SGD step and the re-pack of the updated layers enqueued on the side stream once the block that produced
+        the last applied gradient has been enqueued COMPLETELY (its input-gradient convs read the packed weights the re-pack
+        overwrites; `_early_cut` is the first hook point at or after that block's end).  The side stream first waits for the main
+        stream's launches up to that point; the list's final join makes the main stream wait for all of it."""
         main, side = torch.cuda.current_stream(), side_stream(self.dev)
         done = [False]
         red = self.reducer

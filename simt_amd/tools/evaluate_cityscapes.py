@@ -55,11 +55,7 @@ class Evaluator:
             for k, v in plan.p.items():
                 if k in state and v.dtype != torch.long:
                     v.copy_(state[k])
-        seen = set()
-        for plan in self.plans:
-            if id(plan.p) in seen:
-                pass
-            seen.add(id(plan.p))
+        for plan in self.plans:                   # packed / folded operands are per plan (per input size), also when plans share `p`
             plan.repack()
         self.hist.zero_()
 

@@ -115,7 +115,8 @@ def batches(args, B, H, W, cd, rank, world, dev):
     from simt_amd.data.pipeline import IMG_MEAN, GpuLoader
     from simt_amd.dataset.cityscapes_dataset import cityscapesPseudo
     ds = cityscapesPseudo(args.data_dir_target, args.data_list_target, crop_size=(W, H), scale=False, mirror=args.random_mirror, mean=IMG_MEAN)
-    loader = GpuLoader(ds, B, shuffle=True, num_workers=args.num_workers, device=dev, seed=args.random_seed, rank=rank, world=world)
+    loader = GpuLoader(ds, B, shuffle=True, num_workers=args.num_workers, device=dev, seed=args.random_seed, rank=rank, world=world,
+                       hold=max(1, getattr(args, "iter_size", 1)))     # the loop keeps iter_size micro-batches alive per step
     return ((img, lab) for (img, lab, _sizes, _names) in loader)
 
 
@@ -189,6 +190,14 @@ def main(argv=None):
                     print("Saving model with mIoU: ", mIoU)
                     torch.save(tr.state_dict(), osp.join(args.snapshot_dir, "GTA5_iter" + str(i_iter) + "_mIoU" + str(mIoU) + ".pth"))
                     best_mIoU, best_iter = mIoU, i_iter
+        elif i_iter % args.save_pred_every == 0 and i_iter != 0 and rank == 0:
+            # no validation set given (the reference hard-codes one, :452-464): without an evaluation there is no best-mIoU snapshot,
+            # so keep a rolling periodic one -- a crash must not lose the run
+            old_file = osp.join(args.snapshot_dir, "GTA5_iter" + str(best_iter) + ".pth")
+            if best_iter and os.path.exists(old_file):
+                os.remove(old_file)
+            torch.save(tr.state_dict(), osp.join(args.snapshot_dir, "GTA5_iter" + str(i_iter) + ".pth"))
+            best_iter = i_iter
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

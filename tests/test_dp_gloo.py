@@ -38,10 +38,14 @@ def _worker(rank, world, port, q):
         extra = torch.randn(2, 22, 19, generator=g)
         mine, mine_extra = flat.clone(), extra.clone()
         red = BucketReducer(flat, make_buckets(order, sizes, ready, bucket_elems=2000), group=dist.group.WORLD, extra=[extra])
+        red.measure = True                             # bench.py's "comm" object comes from this report
         red.start()
         for launches in (5, 10, 30, 35, 70):          # the backward replay reports progress at its cut points
             red.ready_upto(launches)
         red.finish()
+        rep = red.report()
+        assert rep["bytes_per_step"] == (total + extra.numel()) * 4 and rep["buckets"] == len(red.buckets) and rep["world"] == world
+        assert sum(rep["bucket_bytes"]) == total * 4 and rep["steps_measured"] == 1 and rep["exposed_wait_ms_median"] >= 0.0
         # expected: mean over ranks
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)

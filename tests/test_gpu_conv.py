@@ -21,6 +21,10 @@ CASES = [
     (1, 19, 19, 64, 192, 3, 4, 1),
     (2, 21, 21, 256, 128, 1, 1, 2),
     (3, 9, 9, 64, 24, 3, 2, 1),
+    # maps of fewer than 64 pixels: one 64-pixel wgrad stage crosses several images (conv_wgrad2 incremental (oy, ox))
+    (24, 4, 4, 64, 64, 3, 1, 1),
+    (11, 7, 7, 128, 64, 3, 2, 1),
+    (9, 4, 8, 64, 128, 1, 1, 1),
 ]
 
 

@@ -79,6 +79,8 @@ def run_head(dev, d, pred1, pred2, fixed2, label, ntm, *, steps=10, lr_T=None):
     hd.ldp, hd.ldf, hd.QP, hd.ld_f32, hd.ld_t, hd.grad_dtype = ldp, 32, QP, ldp, 0, L.SIMT_F32
     hd.th_high, hd.th_low = float(d["th"][0]), float(d["th"][1])
     hd.lambda_seg, hd.lambda_place, hd.gscale = float(d["lambda_seg"]), float(d["lambda_place"]), 1.0
+    conf = torch.full((B, H, W), 77, dtype=torch.uint8, device=dev)       # per-pixel Conf_label_target (optional export)
+    hd.conf_out = conf.data_ptr()
     L.call("simt_head_loss", C.byref(hd), st)
     npd = L.NtmPostDesc()
     for k in range(2):
@@ -99,7 +101,7 @@ def run_head(dev, d, pred1, pred2, fixed2, label, ntm, *, steps=10, lr_T=None):
 
     def back(g):  # [B*h*w, ldp] -> [B,Q,h,w]
         return g.cpu()[:, :Q].reshape(B, h, w, Q).permute(0, 3, 1, 2)
-    return dict(lout=lout.cpu(), hout=hout.cpu(), dpred1=back(dp1), dpred2=back(dp2), dp1_raw=dp1.cpu(),
+    return dict(lout=lout.cpu(), hout=hout.cpu(), dpred1=back(dp1), dpred2=back(dp2), dp1_raw=dp1.cpu(), conf=conf.cpu().long(),
                 ntm_grad=[g.cpu() for g in ngrad], w=[x.cpu() for x in wraw], wm=[x.cpu() for x in wm],
                 wv=[x.cpu() for x in wv], T=[x.cpu() for x in T], ntm_after=[x.cpu() for x in ntm_after])
 
@@ -124,6 +126,8 @@ def test_head_against_reference_golden(dev, name):
         close(lo[idx], d[key], 1e-4, key)
     # number of pixels with a confidence label: integer-exact
     assert int(r["hout"][6]) == int((d["conf"] != 255).sum())
+    # ... and the label itself, pixel by pixel (trainV2_simt.py:357-362,387-393): bit-exact against the reference's Conf_label_target
+    assert torch.equal(r["conf"], t("conf").long()), f"{int((r['conf'] != t('conf')).sum())} confidence labels differ"
     close(r["dpred1"], d["dpred1"], 1e-5, "dpred1")
     close(r["dpred2"], d["dpred2"], 1e-5, "dpred2")
     Q = 19 + int(d["K"])
@@ -179,6 +183,7 @@ def test_head_bigger_than_one_block_vs_oracle(dev, geom, K):
                      (6, "convex"), (7, "volume"), (8, "anchor")]:
         close(lo[idx], out[key].detach(), 1e-4, key)
     assert int(r["hout"][6]) == int((out["conf"] != 255).sum())
+    assert torch.equal(r["conf"], out["conf"].long().view_as(r["conf"])), f"{int((r['conf'] != out['conf'].view_as(r['conf'])).sum())} labels differ"
     close(r["dpred1"], q1.grad, 1e-5, "dpred1")
     close(r["dpred2"], q2.grad, 1e-5, "dpred2")
     close(r["ntm_grad"][0], n[0].grad, 2e-5, "ntm grad")

@@ -69,6 +69,33 @@ def test_prefetcher_order_and_content(dev):
             assert np.array_equal(x[b].cpu().numpy(), img) and np.array_equal(lo[b].cpu().numpy().astype(np.float32), lb)
 
 
+@pytest.mark.parametrize("hold", [2, 3])
+def test_prefetcher_gradient_accumulation_hold(dev, hold):
+    """--iter-size > 1 (trainV2_simt.py:341-432): the training loop pulls `iter_size` micro-batches BEFORE it enqueues the step that reads
+    them.  With hold=iter_size none of them may be refilled before that step has run: the consumer here delays its reads behind ~20 ms
+    of GPU work enqueued after the pulls (round 2's prefetcher overwrote the first micro-batch with batch hold+1 in this pattern)."""
+    B, H, W = 2, 24, 40
+    rng = np.random.default_rng(11)
+    n = 4 * hold
+    batches = [(rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8), rng.integers(0, 19, (B, H, W), dtype=np.uint8), k) for k in range(n)]
+    prep = InputPrep(B, (H, W), (20, 12), dev, mean=pr.IMG_MEAN)
+    pf = DevicePrefetcher(iter(batches), prep, hold=hold)
+    busy = torch.zeros(64 << 20, device=dev)
+    got = []
+    for _step in range(n // hold):
+        mb = [next(pf) for _ in range(hold)]
+        for _ in range(40):
+            busy.add_(1.0)                              # the step's kernels are enqueued AFTER all pulls and take a while
+        for x, lab, meta in mb:
+            got.append((x.clone(), lab.clone(), meta))
+    torch.cuda.synchronize()
+    assert [g[2] for g in got] == list(range(n))
+    for (rgb, lab, _k), (x, lo, _m) in zip(batches, got):
+        for b in range(B):
+            img, lb = pr.cityscapes_pseudo_item(rgb[b], lab[b], 20, 12)
+            assert np.array_equal(x[b].cpu().numpy(), img) and np.array_equal(lo[b].cpu().numpy().astype(np.float32), lb)
+
+
 def test_gpu_loader_end_to_end(dev, tmp_path):
     Image = pytest.importorskip("PIL.Image")
     from simt_amd.dataset.cityscapes_dataset import cityscapesPseudo
