@@ -63,8 +63,19 @@ typedef struct {
   const unsigned char* bnr_bits;
   float* bnr_part;
   int32_t bnr_mode, bnr_ld;
+  const void* w_frag;  /* optional (may be NULL): the SAME weights as `w` in MFMA-fragment order (simt_pack_weight with
+                        * SIMT_PACK_FRAG(Npad / 16) in `mode`): [K / 64][Npad / 16][2][64 lanes][8] bf16, i.e. element (row, kcol) of the
+                        * K-contiguous matrix sits at ((((kcol / 64) * (Npad / 16) + row / 16) * 2 + (kcol / 32) % 2) * 64 +
+                        * (row % 16) + 16 * ((kcol / 8) % 4)) * 8 + kcol % 8.  When present and simt_conv_wants_frag(d) != 0 the wide
+                        * bf16 kernel loads its weight operand straight into registers (1 KB contiguous per wave-instruction)
+                        * instead of staging it through LDS; results are bit-identical either way */
 } simt_conv_desc;
 int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);
+/* 1 if the launch for d would use d->w_frag when given (conv_igemm2_kernel<256, *, 3>: Npad tiles of 256, long reductions) */
+int simt_conv_wants_frag(const simt_conv_desc* d);
+/* `mode` of simt_pack_weight / PackJob: low byte = layout mode 0 / 1 / 2 below; SIMT_PACK_FRAG(nt16) additionally stores the
+ * destination in MFMA-fragment order (see simt_conv_desc.w_frag) with nt16 = Npad / 16 row blocks */
+#define SIMT_PACK_FRAG(nt16) ((int)(nt16) << 8)
 /* which kernel instantiation simt_conv_fprop runs for d (profiling / reporting / tests that must hit a given instantiation):
  * returns 0 (conv_igemm_kernel, fp32 parity + narrow outputs), 2 (conv_igemm2_kernel<bn, tm, nst>, the bf16 throughput kernel),
  * 4 (conv1x1_stream_kernel) or 5 (conv1x1_rows_kernel): the short-reduction / wide-output 1x1 shapes */

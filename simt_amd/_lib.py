@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
                 ("relu", i32), ("dtype_in", i32), ("dtype_out", i32), ("tile_n", i32),
                 ("dy", C.c_int16 * MAX_TAPS), ("dx", C.c_int16 * MAX_TAPS), ("mask", c_p), ("ldm", i32),
                 ("res_bits", c_p), ("bnr_y", c_p), ("bnr_mean", c_p), ("bnr_rstd", c_p), ("bnr_scale", c_p), ("bnr_shift", c_p),
-                ("bnr_bits", c_p), ("bnr_part", c_p), ("bnr_mode", i32), ("bnr_ld", i32)]
+                ("bnr_bits", c_p), ("bnr_part", c_p), ("bnr_mode", i32), ("bnr_ld", i32), ("w_frag", c_p)]
 
 
 class WgradDesc(C.Structure):
@@ -85,6 +85,7 @@ SIGNATURES = {
     "simt_abi_version": (_I, []),
     "simt_conv_fprop": (_I, [C.POINTER(ConvDesc), c_p]),
     "simt_conv_mtiles": (_I, [C.POINTER(ConvDesc)]),
+    "simt_conv_wants_frag": (_I, [C.POINTER(ConvDesc)]),
     "simt_conv_variant": (_I, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "simt_conv_wgrad": (_I, [C.POINTER(WgradDesc), c_p]),
     "simt_wgrad_reduce": (_I, [c_p, c_p, _I, _I, _I, _I, _I, _I, _I, _I, _I, c_p]),

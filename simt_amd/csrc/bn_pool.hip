@@ -542,7 +542,14 @@ extern "C" int simt_maxpool_bwd(const void* dp, const unsigned char* idx, void* 
 //   mode 1 (dgrad): dst[ci*ldk + (tap_off+t)*Ck + row_off + co]  = w[co][ci][t]
 //   mode 2 (tap-expanded fprop, one output column per (tap, cout)): dst[((tap_off+t)*Ck + row_off + co)*ldk + ci] = w[co][ci][t]
 // Padding entries are never written (the buffer is zeroed once at allocation).
+// `mode` bits 8.. = nt16 > 0 (SIMT_PACK_FRAG): the K-contiguous offset o = row * ldk + kcol is re-mapped to MFMA-fragment order
+// (simt_conv_desc.w_frag): the weight operand of v_mfma_f32_16x16x32_bf16 for 16 rows x 32 k as 64 lanes x 16 B, contiguous.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long frag_offset(long long row, long long kcol, int nt16) {
+  const long long kt = kcol >> 6, s = (kcol >> 5) & 1, kq = (kcol >> 3) & 3, e = kcol & 7;
+  const long long lane = (row & 15) | (kq << 4);
+  return ((((kt * nt16 + (row >> 4)) * 2 + s) * 64 + lane) << 3) + e;
+}
 template <typename T>
 __global__ void pack_weight_kernel(const float* w, T* dst, int Cout, int Cin, int RS, int row_off, int tap_off, long ldk,
                                    int Ck, int mode, const float* cscale, long total) {
@@ -553,9 +560,10 @@ __global__ void pack_weight_kernel(const float* w, T* dst, int Cout, int Cin, in
     int co = (int)(r / Cin);
     float v = w[i];
     if (cscale) v *= cscale[co];
-    long o = mode == 0 ? (long)(row_off + co) * ldk + (long)(tap_off + t) * Cin + ci
-           : mode == 1 ? (long)ci * ldk + (long)(tap_off + t) * Ck + row_off + co
-                       : ((long)(tap_off + t) * Ck + row_off + co) * ldk + ci;
+    const int lm = mode & 0xff, nt16 = mode >> 8;
+    const long row = lm == 0 ? (long)(row_off + co) : lm == 1 ? (long)ci : (long)(tap_off + t) * Ck + row_off + co;
+    const long kcol = lm == 0 ? (long)(tap_off + t) * Cin + ci : lm == 1 ? (long)(tap_off + t) * Ck + row_off + co : (long)ci;
+    const long o = nt16 ? (long)frag_offset(row, kcol, nt16) : row * ldk + kcol;
     Elem<T>::st(dst + o, v);
   }
 }
@@ -612,13 +620,14 @@ __device__ __forceinline__ void pack_tile(const PackJob& j, int tidx, float* til
     for (int e = threadIdx.x; e < nt * 32 * 32; e += 256) {
       const int t = e >> 10;
       int co_l, ci_l;
-      if (j.mode == 1) { co_l = e & 31; ci_l = (e >> 5) & 31; } else { ci_l = e & 31; co_l = (e >> 5) & 31; }
+      const int lm = j.mode & 0xff, nt16 = j.mode >> 8;
+      if (lm == 1) { co_l = e & 31; ci_l = (e >> 5) & 31; } else { ci_l = e & 31; co_l = (e >> 5) & 31; }
       if (co_l >= nco || ci_l >= nci) continue;
       const float v = tile[(t * 32 + co_l) * 33 + ci_l];
       const int co = co0 + co_l, ci = ci0 + ci_l, tt = j.tap_off + tb + t;
-      const long long o = j.mode == 0 ? (long long)(j.row_off + co) * j.ldk + (long long)tt * j.Cin + ci
-                        : j.mode == 1 ? (long long)ci * j.ldk + (long long)tt * j.Ck + j.row_off + co
-                                      : ((long long)tt * j.Ck + j.row_off + co) * j.ldk + ci;
+      const long long row = lm == 0 ? (long long)(j.row_off + co) : lm == 1 ? (long long)ci : (long long)tt * j.Ck + j.row_off + co;
+      const long long kcol = lm == 0 ? (long long)tt * j.Cin + ci : lm == 1 ? (long long)tt * j.Ck + j.row_off + co : (long long)ci;
+      const long long o = nt16 ? frag_offset(row, kcol, nt16) : row * j.ldk + kcol;
       if (j.dtype == SIMT_BF16) ((bf16_t*)j.dst)[o] = f2bf(v); else ((float*)j.dst)[o] = v;
     }
   }

@@ -5,6 +5,8 @@
 struct Conv2KArgs {
   const char* x;
   const char* w;
+  const char* wf;                      // weights in MFMA-fragment order (simt_conv_desc.w_frag) or NULL
+  int nt16;                            // Npad / 16: 16-row blocks per 64-deep K stage of wf
   bf16_t* y;
   const float* bias;
   const bf16_t* res;

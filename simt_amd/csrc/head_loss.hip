@@ -24,7 +24,7 @@
 #define SIMT_HEAD_ABL 0      // timing ablations (results meaningless): 1 no dT partials, 2 no anchors, 4 no x-reduction, 8 no gradient terms,
                              // 16 no run sums, 32 no gradient staging
 #endif
-#define NSCAL 12
+#define NSCAL 13
 #define XR_MAX 287   // low-res columns one 256-pixel chunk may touch on the run-based x-reduction of pass 2 (more: the scanning form)
 
 struct HeadGeom {
@@ -342,6 +342,9 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
     long long lab = live ? a.label[p] : 255;
     bool lab_ok = live && lab >= 0 && lab != 255 && lab < C;
     const int labi = lab_ok ? (int)lab : 0;
+    // a label outside [0, C) that is not the ignore value: the reference's nll_loss / CrossEntropyLoss raise ("Target out of bounds");
+    // a kernel cannot, so the pixel is skipped and COUNTED (hout[15]): the host side raises when it reads the losses
+    if (live && !lab_ok && lab != 255) acc[12] += 1.f;
     if (a.mode == 1) {
       // warm-up stage (tools/trainV1_warmup.py:217-224): CrossEntropyLoss(ignore_index=255) of both heads against the
       // label itself; no placeholder, noise-posterior or anchor terms
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(HeadArgs a, int nblk
     o[6] = (float)Np; o[7] = (float)Nk1; o[8] = (float)Nk2; o[9] = (float)Ny;
     o[10] = k1; o[11] = k2; o[12] = u1; o[13] = u2;
     o[14] = o[1] + a.lambda_seg * o[0];      // warm-up total: loss_seg2 + lambda_seg * loss_seg1 (trainV1_warmup.py:224)
-    o[15] = 0.f;
+    o[15] = (float)sc[12];                   // pixels whose label is out of range (neither a class nor 255): the reference raises
   }
   // dTy: -(1/Ny) * sum_p [label=c] q_j / r
   float* dTy = o + 16 + 2 * QC + 4 * QMAX;

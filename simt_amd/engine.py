@@ -331,6 +331,25 @@ class TrunkPlan:
                            ops.dt_code(self.dtype))
         return wt, tile, npad, ck
 
+    def _frag_twin(self, wp, npad):
+        """Fragment-ordered copy of the packed operand `wp` (simt_conv_desc.w_frag), kept fresh by twin pack jobs: every
+        simt_pack_weight entry that writes `wp` gets a second entry with the same source and SIMT_PACK_FRAG in `mode`."""
+        if not hasattr(self, "_frag"):
+            self._frag = {}
+        key = wp.data_ptr()
+        if key not in self._frag:
+            lib = L.load()
+            wf = self.new(*wp.shape, zero=True)
+            jobs = [it for it in self.pack_list.items if it.fn is lib.simt_pack_weight and it.args[1] == key]
+            assert jobs, "a conv asked for fragment-ordered weights before its pack job was planned"
+            for it in jobs:
+                a = list(it.args)
+                a[1] = wf.data_ptr()
+                a[9] = a[9] | ops.PACK_FRAG(npad)
+                self.pack_list.add("simt_pack_weight", *a)
+            self._frag[key] = wf
+        return self._frag[key]
+
     def repack(self):
         """Refresh every packed operand from the fp32 master weights (after an optimiser step / load_state_dict)."""
         self.pack_list.run()
@@ -355,7 +374,12 @@ class TrunkPlan:
         tn = {torch.bfloat16: "bf16", torch.float32: "f32"}
         bn_, tm_, nst_ = C.c_int(), C.c_int(), C.c_int()
         gen = L.load().simt_conv_variant(C.byref(d), C.byref(bn_), C.byref(tm_), C.byref(nst_))
-        tag = (f"conv_igemm2_kernel<{bn_.value}, {tm_.value}, {nst_.value}, 0, 0>" if gen == 2 else
+        wd = 0
+        if gen == 2 and ops.conv_wants_frag(d):
+            # the wide kernel takes its weight operand straight into registers from a fragment-ordered copy (csrc/conv_igemm2.hip, WD)
+            d.w_frag = self._frag_twin(wp, npad).data_ptr()
+            wd = 1
+        tag = (f"conv_igemm2_kernel<{bn_.value}, {tm_.value}, {nst_.value}, 0, 0, {wd}>" if gen == 2 else
                "conv1x1_stream_kernel" if gen == 4 else "conv1x1_rows_kernel" if gen == 5 else
                f"conv_igemm_kernel<{tn[x.dtype]}, {tn[y.dtype]}, {tile}>")
         nbytes = (Bn * Hi * Wi * Cin + npad * len(taps) * Cin) * x.element_size() + M * Cout * y.element_size()

@@ -65,8 +65,9 @@ def packed_rows(cout, tile_n=None, dtype=None):
 
 
 def make_conv_desc(x, w, y, *, B, H, W, Cin, Ho, Wo, Cout, taps, stride=1, bias=None, res=None, stats=None, relu=False,
-                   Npad=None, Nstore=None, ldy=None, ldr=None, tile_n=None, mask=None, ldm=None, res_bits=None, bnr=None):
-    """bnr: fused first pass of the BatchNorm backward -- dict(y, mean, rstd, part, mode (2 | 3), scale, shift | bits)."""
+                   Npad=None, Nstore=None, ldy=None, ldr=None, tile_n=None, mask=None, ldm=None, res_bits=None, bnr=None, w_frag=None):
+    """bnr: fused first pass of the BatchNorm backward -- dict(y, mean, rstd, part, mode (2 | 3), scale, shift | bits).
+    w_frag: the same weights in MFMA-fragment order (simt_conv_desc.w_frag; `frag_order(w)` or a pack with PACK_FRAG) or None."""
     d = L.ConvDesc()
     tile_n = tile_n or pick_tile_n(Cout, x.dtype if x.dtype == y.dtype else None)
     d.x, d.w, d.y = _p(x), _p(w), _p(y)
@@ -82,11 +83,30 @@ def make_conv_desc(x, w, y, *, B, H, W, Cin, Ho, Wo, Cout, taps, stride=1, bias=
     d.mask = _p(mask)
     d.ldm = ldm if ldm is not None else (mask.shape[-1] if mask is not None else 0)
     d.res_bits = _p(res_bits)
+    d.w_frag = _p(w_frag)
     if bnr:
         d.bnr_y, d.bnr_mean, d.bnr_rstd, d.bnr_part = _p(bnr["y"]), _p(bnr["mean"]), _p(bnr["rstd"]), _p(bnr["part"])
         d.bnr_scale, d.bnr_shift, d.bnr_bits = _p(bnr.get("scale")), _p(bnr.get("shift")), _p(bnr.get("bits"))
         d.bnr_mode, d.bnr_ld = bnr["mode"], bnr["y"].shape[-1]
     return d
+
+
+def PACK_FRAG(npad):
+    """`mode` flag of pack_weight: store the operand in MFMA-fragment order (include/simt_hip.h SIMT_PACK_FRAG(Npad / 16))."""
+    assert npad % 16 == 0
+    return (npad // 16) << 8
+
+
+def frag_order(wp):
+    """K-contiguous packed operand [Npad][Ktot] -> the same elements in MFMA-fragment order (simt_conv_desc.w_frag):
+    [Ktot/64][Npad/16][2][lane = (k/8)%4 * 16 + row%16][8].  Host-side restatement of csrc/bn_pool.hip frag_offset (tests, A/B tools)."""
+    npad, kt = wp.shape
+    assert npad % 16 == 0 and kt % 64 == 0
+    return wp.view(npad // 16, 16, kt // 64, 2, 4, 8).permute(2, 0, 3, 4, 1, 5).contiguous().view(npad, kt)
+
+
+def conv_wants_frag(d):
+    return bool(L.load().simt_conv_wants_frag(C.byref(d)))
 
 
 def conv_fprop_desc(d):

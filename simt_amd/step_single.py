@@ -219,5 +219,8 @@ class SimTSingleTrainer:
 
     def losses(self):
         v = self.lout.cpu().tolist()
+        bad = int(self.hout[15].item())
+        if bad:          # the reference's nll_loss raises on such a target; the kernels skip the pixel and count it
+            raise ValueError(f"{bad} label value(s) outside [0, {self.hp.num_classes}) that are not the ignore value 255")
         return {"total": v[0], "loss_p": v[2], "loss_y": v[4], "place": v[5], "convex": v[6], "volume": v[7], "anchor": v[8],
                 "vol_ok": v[9]}

@@ -318,3 +318,21 @@ def test_early_sgd_and_schedule_switches_same_trajectory(dev, monkeypatch):
         assert all(torch.equal(p0[k], p1[k]) for k in p0)
         assert all(torch.equal(m0[k], m1[k]) for k in m0)
         assert all(torch.equal(a, b) for a, b in zip(n0, n1))
+
+
+def test_out_of_range_label_is_reported(dev):
+    """A noisy label that is neither a class nor the ignore value: the reference's nll_loss raises "Target out of bounds"
+    (utils/loss.py:36-40 via F.nll_loss; trainV2_simt.py:408).  The kernels skip the pixel and count it; reading the losses raises."""
+    layers, K = (1, 1, 1, 1), 3
+    st = so.recipe_state(so.state_shapes(19, K, True, layers=layers), seed=11, head_scale=8.0)
+    fst = so.recipe_state(so.state_shapes(19, 0, False, layers=layers), seed=12, head_scale=8.0)
+    tr = SimTTrainer(st, fst, so.ntm_init(19, K, 1), so.ntm_init(19, K, 2), Hyper(open_classes=K), CD.numpy(), 1, 65, 65,
+                     dtype=torch.float32, device=dev, layers=layers)
+    img, lab = so.synthetic_batch(1, 65, 65, CD.numpy(), seed=5, block=8)
+    tr.step(img.to(dev), lab.to(dev), 0)
+    assert np.isfinite(tr.losses()["total"])
+    lab[0, 3, 4] = 19
+    lab[0, 7, 7] = 200
+    tr.step(img.to(dev), lab.to(dev), 1)
+    with pytest.raises(ValueError, match="2 label value"):
+        tr.losses()
