@@ -35,7 +35,8 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense, /opt/skills/guides/MI355X_MICROARCH.md
 FLOP_PER_IMAGE_768 = 3.33e12                            # conv MACs x2, fixed fwd + fwd + bwd
-PMC_FILES = ("r02_pmc_traffic.json", "r01h_pmc_traffic.json")
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01h_pmc_traffic.json")
+PMC_MFMA_FILES = ("r03_pmc_mfma.json",)
 
 
 def parse():
@@ -229,7 +230,7 @@ def main():
     ms_step = dt / a.steps * 1e3
     value = a.batch * world * a.steps / dt
 
-    roof = None
+    roof, aspp = None, None
     if not a.no_roofline:
         acc, shp = {}, {}
         for _ in range(2):
@@ -254,8 +255,46 @@ def main():
                 for kname, v in json.load(open(pmc))["kernels"].items():
                     if kname.replace("void ", "").strip() == dom:
                         traffic, tsrc = v["hbm_bytes_per_launch_corrected"], "profiles/" + fn
+        mfma_busy, msrc = None, None
+        for fn in PMC_MFMA_FILES:            # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs), own rocprofv3 --pmc pass (profiles/pmc_mfma.py)
+            pmc = os.path.join(ROOT, "profiles", fn)
+            if mfma_busy is None and os.path.exists(pmc):
+                for kname, v in json.load(open(pmc))["kernels"].items():
+                    if kname.replace("void ", "").strip() == dom:
+                        mfma_busy, msrc = v["mfma_util"], "profiles/" + fn
+        # ---- the step north_star puts a number on: ASPP (the tap-expanded classifier GEMMs of both nets, forward and backward) + T-matrix
+        # (the fused head: softmax x T contraction, losses and their gradients).  Algorithmic FLOPs / event time of those launches.
+        aspp = None
+        if a.model == "v2":
+            hg = [(k2, v) for k2, v in shp.items() if "(tap-expanded head)" in k2[1]]
+            g_ms, g_fl, g_n = sum(v[0] for _, v in hg), sum(v[1] for _, v in hg), sum(v[3] for _, v in hg)
+            aux = sum(v[0] for k2, v in acc.items() if k2 in ("simt_tap_gather_sum", "simt_tap_scatter"))
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            import ctypes
+            from simt_amd import _lib as simt_lib
+            cur = torch.cuda.current_stream().cuda_stream
+            for _ in range(2):               # the fused head of the resident batch, alone on the stream (its position in the step: exclusive)
+                evs[0].record()
+                simt_lib.call("simt_head_loss", ctypes.byref(tr.head_desc), cur)
+                evs[1].record()
+                simt_lib.call("simt_head_grad", ctypes.byref(tr.head_desc), cur)
+                evs[2].record()
+                torch.cuda.synchronize()
+            P = a.batch * H * W
+            Q = 19 + K
+            t_fl = 2 * 2.0 * P * Q * 19 * 2        # logits x T forward + its two gradient contractions, both heads (2 P Q C each)
+            aspp = {"gemm_launches": g_n, "gemm_ms": round(g_ms, 4), "gemm_alg_gflop": round(g_fl / 1e9, 2),
+                    "gemm_tflops": round(g_fl / (g_ms * 1e-3) / 1e12, 1) if g_ms else None,
+                    "gemm_frac_of_peak": round(g_fl / (g_ms * 1e-3) / 1e12 / peak, 4) if g_ms else None,
+                    "gemm_by_shape": {k2[1]: {"us": round(v[0] / v[3] * 1e3, 1), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1), "n": v[3]} for k2, v in hg},
+                    "tap_gather_scatter_ms": round(aux, 4),
+                    "head_loss_ms": round(evs[0].elapsed_time(evs[1]), 4), "head_grad_ms": round(evs[1].elapsed_time(evs[2]), 4),
+                    "logitsT_alg_gflop": round(t_fl / 1e9, 2),
+                    "what": "tap-expanded ASPP classifier GEMMs (3 forward: two trainable heads + the frozen main head; 2 dgrad; wgrads are in "
+                            "conv_wgrad) as launched in the step, plus the fused head kernels (upsample, softmax, logits x T, the nine losses and "
+                            "their gradients: VALU per lane, 22 x 19 mat-vec, SURVEY allows) timed alone; target north_star: >= 0.5 of MFMA peak"}
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc, "mfma_busy": mfma_busy, "mfma_busy_source": msrc,
                 "alg_bytes_per_launch": int(by / n), "launches_per_step": n,
                 "avg_launch_us": round(ms_k / n * 1e3, 2), "alg_gflop_per_launch": round(fl / n / 1e9, 3),
                 "share_of_step_kernel_time": round(ms_k / tot_ms, 3),
@@ -318,6 +357,8 @@ def main():
                            "step_tflops_conv_algorithmic": round(value * flop_img / 1e12, 1),
                            "frac_of_conv_roofline": round(value * flop_img / 1e12 / (world * MFMA_PEAK_TFLOPS[a.dtype]), 4)},
                 "roofline": roof, "cpu_baseline": cpu}
+        if roof is not None and aspp is not None:
+            line["aspp_t_step"] = aspp
         if comm is not None:
             line["comm"] = comm
         line.update(extra)

@@ -83,7 +83,7 @@ def main():
     for img, _lab in batches:
         with torch.no_grad():
             _, f2 = fixed(img)
-            p = torch.softmax(ns["interp_target"](f2), 1).max(1)[0]
+            p = ns["interp_target"](torch.softmax(f2, 1)).max(1)[0]         # :354-355: soft-max at low resolution, THEN the upsample
         margins.append(float(torch.minimum((p - args.Threshold_high).abs(), (p - args.Threshold_low).abs()).min()))
         pmaxs.append(p.numpy().astype(np.float32).copy())
     traces = gg.run_reference_iterations(train, ns, N_IT, cap)

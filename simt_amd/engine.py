@@ -356,7 +356,7 @@ class TrunkPlan:
 
     # ------------------------------------------------------------------ forward construction
     def _conv(self, lst, x, wp_info, y, *, Bn, Hi, Wi, Cin, Ho, Wo, Cout, taps, stride=1, bias=None, res=None, stats=None,
-              relu=False, ldy=None, Nstore=None, alg_k=None, alg_flops=None, mask=None, res_bits=None, bnr=None):
+              relu=False, ldy=None, Nstore=None, alg_k=None, alg_flops=None, mask=None, res_bits=None, bnr=None, note=""):
         """alg_k: algorithmic reduction length per output element (defaults to ntaps*Cin; the K-padded head dgrad and
         the stem pass their true value) -> algorithmic FLOPs = 2 * M * Cout * alg_k."""
         wp, tile, npad = wp_info
@@ -385,7 +385,7 @@ class TrunkPlan:
         nbytes = (Bn * Hi * Wi * Cin + npad * len(taps) * Cin) * x.element_size() + M * Cout * y.element_size()
         lst.add_desc("simt_conv_fprop", d, tag=tag, flops=alg_flops if alg_flops is not None else 2.0 * M * Cout * k,
                      nbytes=float(nbytes),
-                     shape=f"M{M} N{Cout} K{len(taps) * Cin} taps{len(taps)} s{stride}")
+                     shape=f"M{M} N{Cout} K{len(taps) * Cin} taps{len(taps)} s{stride}{note}")
         return d
 
     def _bn_train(self, lst, bname, y, M, Cn):
@@ -596,7 +596,7 @@ class TrunkPlan:
         P = self.new(Mh, nexp, dtype=torch.float32)
         hd.QP, hd.nexp = QP, nexp
         self._conv(f, feat, (wexp, 256, npe), P, Bn=B, Hi=h, Wi=w, Cin=cin, Ho=h, Wo=w, Cout=nexp, taps=[(0, 0)], ldy=nexp,
-                   Nstore=nexp, alg_flops=2.0 * Mh * Q * nt * cin)
+                   Nstore=nexp, alg_flops=2.0 * Mh * Q * nt * cin, note=" (tap-expanded head)")
         td = L.TapDesc()
         td.src, td.bias, td.dst = P.data_ptr(), bias.data_ptr(), logits.data_ptr()
         td.B, td.H, td.W, td.Q, td.QP, td.lds, td.ldd, td.ntaps = B, h, w, Q, QP, nexp, ldp, nt
@@ -967,7 +967,8 @@ class TrunkPlan:
         if getattr(hd, "mask", None) is not None:
             bnr = None
         dsc = self._conv(b, G, (wt, tile, npad), dfeat, Bn=B, Hi=hd.h, Wi=hd.w, Cin=kexp, Ho=hd.h, Wo=hd.w, Cout=hd.cin,
-                         taps=[(0, 0)], res=dz_prev, alg_k=nt * hd.Q, mask=getattr(hd, "mask", None), bnr=bnr)
+                         taps=[(0, 0)], res=dz_prev, alg_k=nt * hd.Q, mask=getattr(hd, "mask", None), bnr=bnr,
+                         note=" (tap-expanded head)")
         self._head_bnr_nblk = self._fused_nblk(dsc, bnr)
         return dfeat
 
