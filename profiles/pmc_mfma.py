@@ -21,6 +21,20 @@ SIMDS = 256 * 4
 NAMES = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")
 
 
+def kernel_name(full):
+    """'void conv_igemm2_kernel<256, 5, 3, 0, 0, 0>(Conv2KArgs)' -> 'void conv_igemm2_kernel<256, 5, 3, 0, 0, 0>': cut at the first '('
+    outside template brackets ('(anonymous namespace)' prefixes and function-pointer template arguments contain parentheses too)."""
+    depth = 0
+    for i, ch in enumerate(full):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0 and i > 0 and not full[:i].rstrip().endswith("void"):
+            return full[:i].strip()
+    return full.strip()
+
+
 def main():
     d = sys.argv[1]
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -32,7 +46,7 @@ def main():
             c = r.get("Counter_Name")
             if c not in NAMES:
                 continue
-            k = r["Kernel_Name"].split("(")[0].strip()
+            k = kernel_name(r["Kernel_Name"])
             acc[k][c] += float(r["Counter_Value"])
             disp[k].add(r.get("Dispatch_Id"))
     out = {"note": "rocprofv3 --kernel-trace --pmc " + " ".join(NAMES) + " over `bench.py --steps 2 --warmup 1` (own pass); per-dispatch averages "

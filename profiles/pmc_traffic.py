@@ -31,6 +31,20 @@ def load(d, counter):
     return acc
 
 
+def kernel_name(full):
+    """'void conv_igemm2_kernel<256, 5, 3, 0, 0, 0>(Conv2KArgs)' -> 'void conv_igemm2_kernel<256, 5, 3, 0, 0, 0>': cut at the first '('
+    outside template brackets ('(anonymous namespace)' prefixes and function-pointer template arguments contain parentheses too)."""
+    depth = 0
+    for i, ch in enumerate(full):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0 and i > 0 and not full[:i].rstrip().endswith("void"):
+            return full[:i].strip()
+    return full.strip()
+
+
 def main():
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) over `bench.py --steps 2 "
@@ -41,7 +55,7 @@ def main():
         f, w = fetch.get(k, [0.0, 0]), write.get(k, [0.0, 0])
         fa = f[0] / f[1] if f[1] else 0.0
         wa = w[0] / w[1] if w[1] else 0.0
-        name = k.split("(")[0].strip()
+        name = kernel_name(k)
         out["kernels"][name] = {"dispatches": max(f[1], w[1]), "FETCH_SIZE_KB_avg": round(fa, 1), "WRITE_SIZE_KB_avg": round(wa, 1),
                                 "hbm_bytes_per_launch_corrected": int((2 * fa + wa) * 1024)}
     json.dump(out, sys.stdout, indent=1)
