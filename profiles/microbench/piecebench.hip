@@ -133,6 +133,102 @@ static float run(const Args& a) {
   return ts[ts.size() / 2];
 }
 
+
+// Role split: waves 0-3 (one per SIMD) only multiply -- MF v_mfma per stage (80 = the whole stage's matrix work of a SIMD) and R fragment
+// reads -- waves 4-7 only issue LDS-DMA pieces, P each per stage (13 = all 52 pieces of the product stage).  Does a piece issued by ANOTHER
+// wave of the SIMD cost the multiplying wave anything?
+template <int P, int PAT, int R, int MF>
+__global__ __launch_bounds__(NT, 2) void role_kernel(Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int STAGE = (P > 0 ? P : 1) * 4 * 1024;
+  const int nk = a.nstage;
+  if (wave >= 4) {
+    const int lw = wave - 4;
+    int ld = 0;
+    auto issue = [&](int slot) {
+      char* sb = smem + slot * STAGE;
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        const char* s;
+        const int pat = PAT <= 2 ? PAT : (i < 5 ? 1 : 2);      // PAT 3: the product stage: 5 pixel pieces + 8 weight pieces per loader wave
+        if (pat == 0) s = a.src + (size_t)(((ld & 15) * 64 + lw * 16 + i) * 1024 + lane * 16);
+        else if (pat == 1) { const int r = (((ld & 3) * 64 + lw * 16 + i) * 8 + (lane >> 3)); s = a.src + (size_t)r * 512 + (size_t)((ld >> 2) & 3) * 128 + (size_t)(lane & 7) * 16; }
+        else { const int r = ((lw * 8 + i) & 31) * 8 + (lane >> 3); s = a.src + (size_t)(4u << 20) + (size_t)r * 4608 + (size_t)(ld % 36) * 128 + (size_t)(lane & 7) * 16; }
+        __builtin_amdgcn_global_load_lds(GPTR(s), LPTR(sb + (i * 256 + lw * 64) * 16), 16, 0, 0);
+      }
+      ++ld;
+    };
+    if (P > 0) { issue(0); issue(1); }
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (P > 0) { if (kt + 1 < nk) wait_vmcnt<(P > 16 ? 16 : P)>(); else wait_vmcnt<0>(); }
+      __builtin_amdgcn_s_barrier();
+      if (P > 0 && kt + 2 < nk) issue(buf >= 1 ? buf - 1 : 2);
+      buf = (buf + 1 == 3) ? 0 : buf + 1;
+    }
+    return;
+  }
+  f32x4 acc[20];
+#pragma unroll
+  for (int i = 0; i < 20; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 fx[10], fw[8];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) fx[i] = (bf16x8){1, 2, 3, 4, 5, 6, 7, (short)lane};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) fw[i] = (bf16x8){8, 7, 6, 5, 4, 3, 2, (short)(lane + i)};
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if constexpr (R > 0) {
+      const int sw = (lane >> 1) & 7, kq = lane >> 4;
+      const char* px = smem + (P > 0 ? buf * STAGE : 0) + (lane & 15) * 128;
+      constexpr int NROWBLK = (STAGE / 2048) > 0 ? (STAGE / 2048) : 1;
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const int s = i & 1, blk = (i >> 1) % NROWBLK;
+        const bf16x8 v = *(const bf16x8*)(px + blk * 2048 + (((4 * s + kq) ^ sw) << 4));
+        if (i < 10) fx[i] = v; else fw[(i - 10) & 7] = v;
+      }
+    }
+#pragma unroll
+    for (int rep = 0; rep < MF / 40; ++rep)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 5; ++i)
+            acc[j * 5 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[s * 4 + j], fx[s * 5 + i], acc[j * 5 + i], 0, 0, 0);
+    buf = (buf + 1 == 3) ? 0 : buf + 1;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 20; ++i) s += acc[i][0] + acc[i][3];
+  if (a.sink && s == 123.456f) a.sink[blockIdx.x] = 1;
+}
+
+template <int P, int PAT, int R, int MF>
+static float run_role(const Args& a) {
+  const int lds = 3 * (P > 0 ? P : 1) * 4 * 1024 > 65536 ? 3 * P * 4 * 1024 : 65536;
+  hipFuncSetAttribute((const void*)role_kernel<P, PAT, R, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  std::vector<float> ts;
+  for (int r = 0; r < 9; ++r) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((role_kernel<P, PAT, R, MF>), dim3(255), dim3(NT), lds, 0, a);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (r >= 2) ts.push_back(ms * 1e3f);
+  }
+  std::sort(ts.begin(), ts.end());
+  return ts[ts.size() / 2];
+}
+
 int main() {
   char* src; unsigned* sink;
   const size_t bytes = 64u << 20;
@@ -152,5 +248,15 @@ int main() {
   printf("product mix, 6 pieces (2 pixel rows512 + 4 weight pieces) + 18 reads:  weights K-contiguous rows %.1f   weights contiguous (stage-major) %.1f\n",
          run<6, 3, 18, 1>(a), run<6, 4, 18, 1>(a));
   printf("(us per 288 stages)\n");
+  // warm the clocks, then the role-split runs
+  for (int i = 0; i < 3; ++i) run_role<0, 0, 0, 80>(a);
+  printf("\nrole split (waves 0-3: 80 MFMA per stage = 1 280 pipe cycles; waves 4-7: P LDS-DMA pieces each), us per 288 stages:\n");
+  printf("  MFMA only %.1f   + 36 fragment reads %.1f\n", run_role<0, 0, 0, 80>(a), run_role<0, 0, 36, 80>(a));
+  printf("  P=4:  contig %.1f  rows512 %.1f  rows4k6 %.1f\n", run_role<4, 0, 0, 80>(a), run_role<4, 1, 0, 80>(a), run_role<4, 2, 0, 80>(a));
+  printf("  P=8:  contig %.1f  rows512 %.1f  rows4k6 %.1f\n", run_role<8, 0, 0, 80>(a), run_role<8, 1, 0, 80>(a), run_role<8, 2, 0, 80>(a));
+  printf("  P=13: contig %.1f  rows512 %.1f  rows4k6 %.1f  product mix %.1f\n", run_role<13, 0, 0, 80>(a), run_role<13, 1, 0, 80>(a), run_role<13, 2, 0, 80>(a), run_role<13, 3, 0, 80>(a));
+  printf("  P=13 + 36 reads: contig %.1f  product mix %.1f     P=13 pieces, NO MFMA (loaders alone): contig %.1f  product mix %.1f\n",
+         run_role<13, 0, 36, 80>(a), run_role<13, 3, 36, 80>(a), run_role<13, 0, 0, 0>(a), run_role<13, 3, 0, 0>(a));
+
   return 0;
 }

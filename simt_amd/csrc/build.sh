@@ -14,7 +14,7 @@ pids=()
 for f in *.hip; do
   o=../_build/${f%.hip}.o
   objs+=("$o")
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv2_common.h -nt "$o" ] || [ ../../include/simt_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv2_common.h -nt "$o" ] || [ conv2_epilogue.h -nt "$o" ] || [ ../../include/simt_hip.h -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi
