@@ -85,7 +85,16 @@ def test_evaluator_end_to_end_small(dev, K):
            F.interpolate(o2[:, :19], size=(H, W), mode="bilinear", align_corners=True).numpy())
     pred = np.argmax(out.transpose(0, 2, 3, 1), axis=3)
     got = ev.pred.cpu().numpy()
-    assert (got != pred).mean() < 2e-3          # logits carry 1e-5-level conv noise: near-ties may flip
+    # "arg-max bit-exact" (north_star), stated with its margin: the summed logits carry the fp32 conv parity error (2e-5 of max|logit|
+    # per layer, tests/test_gpu_conv.py), so a pixel may differ ONLY where the reference's own top-2 gap is below that error budget;
+    # everywhere else the label map is bit-exact.  Margin = 1e-4 * max|summed logit| (the measured logit error is ~3e-5 of it).
+    top2 = np.sort(out.transpose(0, 2, 3, 1), axis=3)[..., -2:]
+    gap = top2[..., 1] - top2[..., 0]
+    margin = 1e-4 * np.abs(out).max()
+    diff = got != pred
+    print(f"K={K}: {int(diff.sum())} of {diff.size} labels differ; {int((gap < margin).sum())} pixels with a top-2 gap below {margin:.2e}")
+    assert not np.any(diff & (gap >= margin)), f"{int((diff & (gap >= margin)).sum())} labels differ outside the rounding margin"
+    assert (gap < margin).mean() < 5e-3          # the statement is not vacuous: fewer than 0.5 % of the pixels are exempt
     h = fast_hist(gt.numpy().flatten(), got.flatten().astype(np.int64), 19)
     assert np.array_equal(ev.hist.cpu().numpy().reshape(19, 19), h)
     assert miou == round(float(np.nanmean(per_class_iu(h))) * 100, 2)

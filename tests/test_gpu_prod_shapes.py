@@ -389,7 +389,16 @@ def test_full_depth_r101_bf16_forward_b4_768(dev):
     r1, r2 = _rel(e1, m1), _rel(e2, m2)
     print(f"eval bf16 vs storage model: x1 {r1:.2e} x2 {r2:.2e}")
     assert r1 < 1e-2 and r2 < 1e-2
-    assert (e2.argmax(1) != m2.argmax(1)).float().mean().item() < 2e-3          # arg-max of the logits: only near-ties may differ
+    # arg-max of the logits, margin-aware: the logits agree to r2 * max|logit| (asserted above), so two labels may only differ where the
+    # model's own top-2 gap is below twice that error; elsewhere the label maps are identical.  Flip rate reported.
+    t2 = m2.topk(2, dim=1).values
+    gap = (t2[:, 0] - t2[:, 1])
+    flips = e2.argmax(1) != m2.argmax(1)
+    bound = 2.0 * max(r2, 1e-3) * m2.abs().max().item()
+    print(f"eval arg-max: {int(flips.sum())} of {flips.numel()} positions differ ({flips.float().mean().item():.2e}); "
+          f"{int((gap < bound).sum())} positions with a top-2 gap below {bound:.3f}")
+    assert not bool((flips & (gap >= bound)).any()), "arg-max differs where the top-2 logit gap exceeds the measured logit error"
+    assert flips.float().mean().item() < 2e-3
     tr = TrunkPlan(p, B, H, W, multi_heads(19, K, True), dtype=BF, train=True)
     tags = {it.tag for it in tr.fwd_list.items}
     assert any(t.startswith("conv_igemm2_kernel<256, 5, 3, 0, 0") for t in tags) and "conv1x1_stream_kernel" in tags
