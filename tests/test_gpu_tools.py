@@ -67,3 +67,59 @@ def test_train_tool_refuses_missing_data_and_checkpoint(dev, tmp_path):
         tool.main(base + ["--synthetic" if False else "--data-dir-target", str(tmp_path / "nope"), "--restore-from", str(tmp_path / "no.pth")])
     with pytest.raises(SystemExit):
         tool.main(base + ["--data-dir-target", str(tmp_path / "nope"), "--from-scratch"])
+
+
+def test_gpu_loader_iter_size2_equals_resident_batches(dev, tmp_path):
+    """--iter-size 2 with REAL files: the training loop pulls two micro-batches from the GpuLoader before it enqueues the step
+    that reads them.  A trainer fed that way must follow bit for bit the trainer fed with resident copies of the same batches (round 2's
+    prefetcher refilled the first micro-batch's slot before the step had read it: batch 1 lost or torn, batch 3 trained twice)."""
+    Image = pytest.importorskip("PIL.Image")
+    from oracle import simt_oracle as so
+    from simt_amd.data.pipeline import IMG_MEAN, GpuLoader
+    from simt_amd.dataset.cityscapes_dataset import cityscapesPseudo
+    from simt_amd.step import Hyper, SimTTrainer
+    _make_dataset(tmp_path, Image)
+    rng = np.random.default_rng(3)
+    lines = open(tmp_path / "pseudo.lst").read().split()
+    for i in range(4, 8):                                       # 8 training frames: 4 steps x 2 micro-batches of 1
+        Image.fromarray(rng.integers(0, 256, (96, 192, 3), dtype=np.uint8)).save(tmp_path / "train_img" / f"t{i}.png")
+        lab = rng.integers(0, 19, (96, 192), dtype=np.uint8)
+        Image.fromarray(lab).save(tmp_path / "train_lab" / f"t{i}.png")
+    (tmp_path / "pseudo.lst").write_text("".join(f"train_img/t{i}.png train_lab/t{i}.png\n" for i in range(8)))
+    ds = cityscapesPseudo(str(tmp_path), str(tmp_path / "pseudo.lst"), crop_size=(129, 65), scale=False, mirror=False, mean=IMG_MEAN)
+    layers, K, its = (1, 1, 1, 1), 3, 2
+    CD = so.load_class_dist()
+    st = so.recipe_state(so.state_shapes(19, K, True, layers=layers), seed=11, head_scale=8.0)
+    fst = so.recipe_state(so.state_shapes(19, 0, False, layers=layers), seed=12, head_scale=8.0)
+    kw = dict(open_classes=K, lr=6e-4, lr_T=6e-3, iter_size=its)
+
+    def trainer():
+        return SimTTrainer(st, fst, so.ntm_init(19, K, 1), so.ntm_init(19, K, 2), Hyper(**kw), CD.numpy(), 1, 65, 129,
+                           dtype=torch.float32, device=dev, layers=layers)
+    # reference run: every batch copied to resident tensors (synchronised) before anything is trained
+    batches = []
+    for img, lab, _s, _n in GpuLoader(ds, 1, shuffle=True, num_workers=2, device=dev, seed=5, epochs=1):
+        torch.cuda.synchronize()
+        batches.append((img.clone(), lab.clone()))
+    assert len(batches) == 8
+    ta = trainer()
+    ref = []
+    for s_ in range(4):
+        ta.step([batches[2 * s_][0], batches[2 * s_ + 1][0]], [batches[2 * s_][1], batches[2 * s_ + 1][1]], s_)
+        ref.append(ta.lout.clone())
+    # the tool's pattern: pull `iter_size` micro-batches, then step, no synchronisation anywhere
+    tb = trainer()
+    busy = torch.zeros(32 << 20, device=dev)
+    data = iter(GpuLoader(ds, 1, shuffle=True, num_workers=2, device=dev, seed=5, epochs=1, hold=its))
+    got = []
+    for s_ in range(4):
+        mb = [next(data) for _ in range(its)]
+        for _ in range(20):
+            busy.add_(1.0)                                      # the step's kernels queue up behind other work
+        tb.step([m[0] for m in mb], [m[1] for m in mb], s_)
+        got.append(tb.lout.clone())
+    torch.cuda.synchronize()
+    for s_ in range(4):
+        assert torch.equal(ref[s_], got[s_]), f"step {s_}: {ref[s_][:9].tolist()} vs {got[s_][:9].tolist()}"
+    for n in ("layer3.0.conv1.weight", "layer6.conv2d_list.0.weight"):
+        assert torch.equal(ta.params[n], tb.params[n])
