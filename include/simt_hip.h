@@ -97,6 +97,31 @@ typedef struct {
 int simt_conv_wgrad(const simt_wgrad_desc* d, simt_stream_t stream);
 int simt_wgrad_reduce(const float* slab, float* dst, int nsplit, int Cd, int Ktot, int Cin, int co_off, int tap_off,
                       int Cout, int RS, int accumulate, simt_stream_t stream);
+/* Grouped launch: n <= SIMT_WGRAD_MULTI_MAX problems with the SAME nsplit (the convs of one Bottleneck: the same pixels) as one tile list,
+ * so that a much coarser pixel split fills the chip (fewer, longer slabs; one launch).  Each problem keeps its own slab and its own
+ * simt_wgrad_reduce; results equal simt_conv_wgrad's with that nsplit bit for bit.  The per-problem arguments live in a DEVICE table
+ * the caller owns: simt_conv_wgrad_multi_prepare fills its host image (n * simt_conv_wgrad_multi_bytes() bytes) and returns the grid;
+ * the caller copies it to device memory once and passes that to simt_conv_wgrad_multi.  simt_conv_wgrad_multi_ok: does the problem
+ * qualify (the problems simt_conv_wgrad runs on its 128x256-tile bf16 kernel)? */
+#define SIMT_WGRAD_MULTI_MAX 8
+int simt_conv_wgrad_multi_ok(const simt_wgrad_desc* d);
+int simt_conv_wgrad_multi_bytes(void);
+int simt_conv_wgrad_multi_prepare(const simt_wgrad_desc* d, int n, void* table_host, int* grid, int* tile_co);
+int simt_conv_wgrad_multi(const void* table_dev, int n, int grid, int nsplit, int tile_co, simt_stream_t stream);
+/* dY channels per output tile of the bf16 kernel for this problem: 256 (Cd a multiple of 256 and enough pixels: conv_wgrad3, 256 x 256 tile, half the
+ * staged bytes per MAC) or 128; a grouped launch takes 256 only if every problem does (returned by _prepare in *tile_co).  The split
+ * count that fills the chip depends on it: tiles = ceil(Cd / tile_co) * ceil(ntaps * Cin / 256). */
+#define SIMT_WGRAD3_MIN_PIXELS 16384   /* the 256-row tile needs B * Ho * Wo >= this (fewer pixels: the extra splits cost more than they save) */
+int simt_conv_wgrad_tile_co(const simt_wgrad_desc* d);
+/* The reduces of a grouped launch as ONE launch: a device table of n <= 16 jobs (the arguments of simt_wgrad_reduce; needs Cin % 4 == 0,
+ * Ktot % 4 == 0, 16-byte aligned slab and dst).  Job j owns blocks [block0, block0 + ceil(Cout * RS * Cin / 4 / 256)); `blocks` = their
+ * total.  Per element the same sum in the same order as simt_wgrad_reduce: bitwise the same gradients. */
+typedef struct {
+  const float* slab;
+  float* dst;
+  int32_t nsplit, Cd, Ktot, Cin, co_off, tap_off, Cout, RS, accumulate, block0;
+} simt_wgrad_reduce_job;
+int simt_wgrad_reduce_multi(const simt_wgrad_reduce_job* jobs_dev, int n, int blocks, simt_stream_t stream);
 
 /* ---- tap-expanded ASPP classifier (bf16 throughput path; model/deeplab_multi.py:104-119) -------------------------
  * The N = Q = 22 dilated conv is re-associated into a plain GEMM with one output column per (tap, class) plus a

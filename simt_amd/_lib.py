@@ -35,6 +35,12 @@ class WgradDesc(C.Structure):
                 ("dy_", C.c_int16 * MAX_TAPS), ("dx_", C.c_int16 * MAX_TAPS)]
 
 
+class WgradReduceJob(C.Structure):
+    """simt_wgrad_reduce_job (include/simt_hip.h)."""
+    _fields_ = [("slab", c_p), ("dst", c_p), ("nsplit", i32), ("Cd", i32), ("Ktot", i32), ("Cin", i32), ("co_off", i32),
+                ("tap_off", i32), ("Cout", i32), ("RS", i32), ("accumulate", i32), ("block0", i32)]
+
+
 class BnBwdDesc(C.Structure):
     _fields_ = [("dz", c_p), ("z", c_p), ("y", c_p), ("mean", c_p), ("rstd", c_p), ("scale", c_p), ("shift", c_p),
                 ("y2", c_p), ("mean2", c_p), ("rstd2", c_p), ("scale2", c_p), ("part", c_p), ("coef", c_p),
@@ -89,6 +95,12 @@ SIGNATURES = {
     "simt_conv_variant": (_I, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "simt_conv_wgrad": (_I, [C.POINTER(WgradDesc), c_p]),
     "simt_wgrad_reduce": (_I, [c_p, c_p, _I, _I, _I, _I, _I, _I, _I, _I, _I, c_p]),
+    "simt_conv_wgrad_multi_ok": (_I, [C.POINTER(WgradDesc)]),
+    "simt_conv_wgrad_multi_bytes": (_I, []),
+    "simt_conv_wgrad_multi_prepare": (_I, [C.POINTER(WgradDesc), _I, c_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "simt_conv_wgrad_multi": (_I, [c_p, _I, _I, _I, _I, c_p]),
+    "simt_conv_wgrad_tile_co": (_I, [C.POINTER(WgradDesc)]),
+    "simt_wgrad_reduce_multi": (_I, [c_p, _I, _I, c_p]),
     "simt_pack_weight": (_I, [c_p, c_p, _I, _I, _I, _I, _I, _L, _I, _I, c_p, _I, c_p]),
     "simt_pack_weight_multi": (_I, [c_p, c_p, _I, _I, c_p]),
     "simt_bn_fold": (_I, [c_p, c_p, c_p, c_p, f32, c_p, c_p, _I, c_p]),

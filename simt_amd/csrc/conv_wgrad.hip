@@ -229,7 +229,60 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* slab, f
   }
 }
 
+// Several reduces in one launch (the slabs of a grouped weight-gradient launch): job j owns blocks [block0_j, block0_{j+1}); per element
+// the same sum in the same order as wgrad_reduce4_kernel.
+__global__ __launch_bounds__(256) void wgrad_reduce4_multi_kernel(const simt_wgrad_reduce_job* __restrict__ jobs, int njobs) {
+  int j = 0;
+  for (int i = 1; i < njobs; ++i) if ((int)blockIdx.x >= jobs[i].block0) j = i;
+  const simt_wgrad_reduce_job& a = jobs[j];
+  const int Cin = a.Cin, RS = a.RS, Ktot = a.Ktot, nsplit = a.nsplit;
+  const long idx = (long)((int)blockIdx.x - a.block0) * 256 + threadIdx.x;
+  const int c4 = Cin >> 2;
+  if (idx >= (long)a.Cout * RS * c4) return;
+  const int ci = (int)(idx % c4) << 2;
+  const long r = idx / c4;
+  const int t = (int)(r % RS);
+  const int co = (int)(r / RS);
+  const float* p = a.slab + (long)(a.co_off + co) * Ktot + (long)(a.tap_off + t) * Cin + ci;
+  const long sstride = (long)a.Cd * Ktot;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int k = 0; k < nsplit; ++k) {
+    const float4 v = *(const float4*)(p + k * sstride);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float* dst = a.dst;
+  const long d = ((long)co * Cin + ci) * RS + t;
+  if (RS == 1) {
+    float4* q = (float4*)(dst + d);
+    if (a.accumulate) { const float4 o = *q; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+    *q = s;
+  } else {
+    const float e[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) dst[d + (long)jj * RS] = a.accumulate ? dst[d + (long)jj * RS] + e[jj] : e[jj];
+  }
+}
+
+extern "C" int simt_wgrad_reduce_multi(const simt_wgrad_reduce_job* jobs_dev, int n, int blocks, simt_stream_t stream) {
+  SIMT_CHECK(jobs_dev && n >= 1 && n <= 2 * SIMT_WGRAD_MULTI_MAX && blocks >= 1);
+  hipLaunchKernelGGL(wgrad_reduce4_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, n);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
 int simt_conv_wgrad_bf16_v2(const simt_wgrad_desc* d, simt_stream_t stream);  // conv_wgrad2.hip
+
+// Which problems run on the 128x256-tile kernel (conv_wgrad2.hip; also the condition for a grouped launch, simt_conv_wgrad_multi)
+bool simt_conv_wgrad_v2_eligible(const simt_wgrad_desc* d) {
+  static int min_cd = -1, min_k = 0;
+  if (min_cd < 0) {
+    const char* e = getenv("SIMT_WGRAD2_MIN");          // "cd,k" thresholds of the 128x256-tile kernel (experiments)
+    min_cd = 64; min_k = 64;     // partial tiles are zero-filled; even at Cd = K = 64 it beats the 128x128 kernel (44 vs 59 us)
+    if (e) sscanf(e, "%d,%d", &min_cd, &min_k);
+  }
+  return d->dtype == SIMT_BF16 && d->Cd >= min_cd && d->ntaps * d->Cin >= min_k && (d->stride != 1 || (d->H == d->Ho && d->W == d->Wo));
+}
 
 extern "C" int simt_conv_wgrad(const simt_wgrad_desc* d, simt_stream_t stream) {
   SIMT_CHECK(d && d->dy && d->x && d->slab);
@@ -238,16 +291,7 @@ extern "C" int simt_conv_wgrad(const simt_wgrad_desc* d, simt_stream_t stream) {
   const int epc = 16 / esz;
   SIMT_CHECK(d->Cin % epc == 0 && d->Cd % epc == 0 && d->ldd % epc == 0 && d->Cd <= d->ldd);
   SIMT_CHECK(d->nsplit >= 1);
-  {
-    static int min_cd = -1, min_k = 0;
-    if (min_cd < 0) {
-      const char* e = getenv("SIMT_WGRAD2_MIN");          // "cd,k" thresholds of the 128x256-tile kernel (experiments)
-      min_cd = 64; min_k = 64;     // partial tiles are zero-filled; even at Cd = K = 64 it beats the 128x128 kernel (44 vs 59 us)
-      if (e) sscanf(e, "%d,%d", &min_cd, &min_k);
-    }
-    if (d->dtype == SIMT_BF16 && d->Cd >= min_cd && d->ntaps * d->Cin >= min_k && (d->stride != 1 || (d->H == d->Ho && d->W == d->Wo)))
-      return simt_conv_wgrad_bf16_v2(d, stream);
-  }
+  if (simt_conv_wgrad_v2_eligible(d)) return simt_conv_wgrad_bf16_v2(d, stream);
   WgradKArgs k;
   k.dy = (const char*)d->dy; k.x = (const char*)d->x; k.slab = d->slab; k.zero = (const char*)simt_zero_page();
   k.B = d->B; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Ho = d->Ho; k.Wo = d->Wo; k.Cd = d->Cd; k.ldd = d->ldd;

@@ -20,6 +20,7 @@ struct Wgrad2KArgs {
   const char* zero;
   int H, W, Cin, Ho, Wo, Cd, ldd, stride, ntaps, M, Ktot;
   int nsplit, pix_per_split, cotiles, ktiles;
+  int tile0;                                 // grouped launch: first tile of this problem in the group's tile list (0 otherwise)
   float rcpWo, rcpHoWo;
   short tdy[SIMT_MAX_TAPS], tdx[SIMT_MAX_TAPS];
 };
@@ -35,8 +36,10 @@ template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
 // incremental pixel coordinates in the issue phase -> 57 us (loads-only 42, MFMA-only 43), XCD-aware block order: 1x1 1024<-256
 // 44 -> 35 us and 233 -> 124 MB of HBM traffic per launch.  A ninth wave prefetching one dword per 128-B line four stages ahead made
 // the 1x1 shapes slower (62-67 us): it doubles the line requests.
+// `a`: the problem (kernel argument, or one entry of a grouped launch's table in device memory -- uniform per workgroup either way);
+// (split, tix): the pixel split and the output tile of this workgroup.
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
+__device__ __forceinline__ void conv_wgrad2_body(const Wgrad2KArgs& a, const int split, const int tix) {
   constexpr int NT = 512, NST = 3, BP = 64;
   constexpr int ROWB = 256;                  // bytes per LDS row (128 channels)
   constexpr int SUB = BP * ROWB;             // 16 KB image
@@ -52,10 +55,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
   // XCD), so the tiles of one pixel split run on one XCD (two at a chunk boundary): its dY / X rows are fetched from HBM once or twice
   // per launch and re-read by the other tiles from that XCD's L2.  (Round 1's order put the tiles of a split on eight XCDs: rocprofv3
   // FETCH_SIZE 233 MB per launch against 96-115 MB algorithmic.)
-  const int tiles = a.cotiles * a.ktiles;
-  const int lin = xcd_remap(blockIdx.x, tiles * a.nsplit);
-  const int split = lin / tiles;
-  const int tix = lin - split * tiles;
   const int kt_ = tix % a.ktiles, ct = tix / a.ktiles;
   const int co0 = ct * 128, k0 = kt_ * 256;
 
@@ -250,9 +249,253 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
     }
 }
 
-// Called by simt_conv_wgrad (conv_wgrad.hip) for bf16 problems with Cd >= 128.
-int simt_conv_wgrad_bf16_v2(const simt_wgrad_desc* d, simt_stream_t stream) {
-  Wgrad2KArgs k;
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// 256 (dY channels) x 256 (tap*cin columns) tile, 32 pixels per stage, 4-slot ring.
+// The 128 x 256 tile above stages 48 KB per 64 pixels for 128 x 256 x 64 MACs; a CU takes in ~70 GB/s through its L2 -> LDS path
+// (profiles/microbench/fillbench.hip, MI355X_MICROARCH.md "ring-gemm"), so its stage cannot go under 0.69 us while the MFMAs need
+// 0.49 us: fill-bound (measured ~1.0 us).  Here a stage is 32 pixels of FOUR [32 px][128 ch] images (dY 0-127, dY 128-255, X 0-127,
+// X 128-255) = 32 KB for 256 x 256 x 32 MACs: half the staged bytes per MAC, the same 32 MFMAs per wave and barrier, and a 4-slot
+// ring keeps three stages (96 KB) in flight.  Each wave owns 128 channels x 64 columns: 32 accumulator quads (128 VGPRs), 12
+// fragments per stage (8 dY + 4 X, one 32-pixel k-step).  Same swizzle, same transposed reads, same early / late wave stagger.
+// Needs Cd % 256 == 0 to pay (layer 3 / 4 of the ResNets); everything else stays on the 128-row tile.
+template <int MODE>
+__device__ __forceinline__ void conv_wgrad3_body(const Wgrad2KArgs& a, const int split, const int tix) {
+  constexpr int NST = 4, BP = 32;
+  constexpr int ROWB = 256;                  // bytes per LDS row (128 channels)
+  constexpr int SUB = BP * ROWB;             // 8 KB image
+  constexpr int STAGE = 4 * SUB;             // dY[0:128) | dY[128:256) | X[0:128) | X[128:256)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;   // 2 x 4 waves, 128 channels x 64 columns each
+
+  const int kt_ = tix % a.ktiles, ct = tix / a.ktiles;
+  const int co0 = ct * 256, k0 = kt_ * 256;
+
+  // one 16-byte chunk of every image per thread and stage: row = tid >> 4 (pixel), position tid & 15
+  const int c_pos = tid & 15;
+  const int row = tid >> 4;
+  const int h = ((row & 3) | (((row >> 3) & 1) << 2)) << 1;
+  const int cg = c_pos ^ h;
+  int dch[2], xoff[2], tdy[2], tdx[2];
+  bool d_ok[2], k_ok[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    dch[s] = co0 + s * 128 + cg * 8;
+    d_ok[s] = dch[s] < a.Cd;
+    const int kk = k0 + s * 128 + cg * 8;
+    k_ok[s] = kk < a.Ktot;
+    int tap = 0, ci = 0;
+    if (k_ok[s]) { tap = kk / a.Cin; ci = kk - tap * a.Cin; }
+    tdy[s] = a.tdy[tap];
+    tdx[s] = a.tdx[tap];
+    xoff[s] = ((tdy[s] * a.W + tdx[s]) * a.Cin + ci) * 2;
+  }
+  const int pix_bytes = a.Cin * 2;
+  const int ldd_bytes = a.ldd * 2;
+  const int HoWo = a.Ho * a.Wo;
+  const bool s1 = a.stride == 1;
+
+  const int m_begin = split * a.pix_per_split;
+  int m_end = m_begin + a.pix_per_split;
+  if (m_end > a.M) m_end = a.M;
+  const int nk = (m_end > m_begin) ? (m_end - m_begin + BP - 1) / BP : 0;
+  const char* zsrc = a.zero + c_pos * 16;
+
+  int ld_m = m_begin;
+  int r_oy, r_ox;
+  unsigned r_xo, r_do;
+  const int adv_r = BP % HoWo;
+  const int adv_y = adv_r / a.Wo, adv_x = adv_r % a.Wo;
+  {
+    const int m = m_begin + row;
+    int b, r;
+    fast_divmod(m < a.M ? m : 0, HoWo, a.rcpHoWo, b, r);
+    fast_divmod(r, a.Wo, a.rcpWo, r_oy, r_ox);
+    r_xo = (unsigned)m * (unsigned)pix_bytes;
+    r_do = (unsigned)m * (unsigned)ldd_bytes;
+  }
+  const unsigned x_step = (unsigned)BP * (unsigned)pix_bytes, d_step = (unsigned)BP * (unsigned)ldd_bytes;
+  auto issue = [&](int buf) {
+    char* sbase = smem + buf * STAGE + wave * 1024;          // LDS-DMA: wave-uniform base, the hardware adds lane * 16
+    const int m = ld_m + row;
+    const bool mok = m < m_end;
+    const char* srcd[2];
+    const char* srcx[2];
+    if (s1) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        srcd[s] = (mok && d_ok[s]) ? a.dy + (r_do + (unsigned)(dch[s] * 2)) : zsrc;
+        const bool in = (unsigned)(r_oy + tdy[s]) < (unsigned)a.H && (unsigned)(r_ox + tdx[s]) < (unsigned)a.W;
+        srcx[s] = (mok && k_ok[s] && in) ? a.x + (r_xo + (unsigned)xoff[s]) : zsrc;
+      }
+      r_do += d_step; r_xo += x_step;
+      r_oy += adv_y; r_ox += adv_x;
+      if (r_ox >= a.Wo) { r_ox -= a.Wo; r_oy += 1; }
+      if (r_oy >= a.Ho) r_oy -= a.Ho;
+    } else {
+      int b, r, oy, ox;
+      fast_divmod(m, HoWo, a.rcpHoWo, b, r);
+      fast_divmod(r, a.Wo, a.rcpWo, oy, ox);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        srcd[s] = (mok && d_ok[s]) ? a.dy + ((unsigned)m * (unsigned)ldd_bytes + (unsigned)(dch[s] * 2)) : zsrc;
+        srcx[s] = zsrc;
+        const int iy = oy * a.stride + tdy[s], ix = ox * a.stride + tdx[s];
+        if (mok && k_ok[s] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+          srcx[s] = a.x + ((unsigned)((b * a.H + iy) * a.W + ix) * (unsigned)pix_bytes + (unsigned)(xoff[s] - (tdy[s] * a.W + tdx[s]) * pix_bytes));
+      }
+    }
+    if (MODE != 2) {
+      __builtin_amdgcn_global_load_lds(GPTR(srcd[0]), LPTR(sbase), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GPTR(srcd[1]), LPTR(sbase + SUB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GPTR(srcx[0]), LPTR(sbase + 2 * SUB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GPTR(srcx[1]), LPTR(sbase + 3 * SUB), 16, 0, 0);
+    }
+    ld_m += BP;
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // transposed fragment addressing (as above): lane l: g = l>>4 (k group), q = (l&15)>>2 (row in 4-row block), pp = l&3
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int hh = (q | ((g & 1) << 2)) << 1;
+  const unsigned rowpart = (unsigned)((8 * g + q) * ROWB + (pp & 1) * 8);
+  unsigned offa[8], offb[4];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) offa[t] = (unsigned)(wm * SUB) + rowpart + (unsigned)((((t * 2) + (pp >> 1)) ^ hh) << 4);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) offb[t] = (unsigned)((2 + (wn >> 1)) * SUB) + rowpart + (unsigned)((((((wn & 1) * 64 + t * 16) >> 3) + (pp >> 1)) ^ hh) << 4);
+  bf16x8 af[8], bfr[4];
+  auto trd = [](unsigned addr, auto off) {
+    bf16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(decltype(off)::value));
+    return r;
+  };
+  auto load_frags = [&](int buf) {
+    const unsigned base = (unsigned)(size_t)LPTR(smem + buf * STAGE);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bf16x4 b0 = trd(base + offb[t], std::integral_constant<int, 0>{}), b1 = trd(base + offb[t], std::integral_constant<int, 4 * ROWB>{});
+      bfr[t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const bf16x4 a0 = trd(base + offa[t], std::integral_constant<int, 0>{}), a1 = trd(base + offa[t], std::integral_constant<int, 4 * ROWB>{});
+      af[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  auto frags_landed = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]));
+    asm volatile("" : "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]), "+v"(bfr[3]));
+  };
+  auto mma = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // D = [k][co]
+  };
+  // stage kt has landed (this wave's pieces): up to NST - 2 younger stages (4 loads each) may still be in flight
+  auto wait_stage = [&](int kt) {
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) if (s < nk) issue(s);
+  int buf = 0;
+  if (wave < 4) {
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_stage(kt);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (MODE != 1) load_frags(buf);
+      if (kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
+      if (MODE != 1) { frags_landed(); mma(); }
+      buf = (buf + 1 == NST) ? 0 : buf + 1;
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_stage(kt);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (MODE != 1 && kt > 0) { frags_landed(); mma(); }
+      if (kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
+      if (MODE != 1) load_frags(buf);
+      buf = (buf + 1 == NST) ? 0 : buf + 1;
+    }
+    if (MODE != 1 && nk > 0) { frags_landed(); mma(); }
+  }
+
+  float* out = a.slab + (long)split * a.Cd * a.Ktot;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = co0 + wm * 128 + i * 16 + (lane & 15);
+      const int k = k0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      if (co < a.Cd && k < a.Ktot) *(f32x4*)(out + (long)co * a.Ktot + k) = acc[i][j];
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void conv_wgrad2_kernel(Wgrad2KArgs a) {
+  const int tiles = a.cotiles * a.ktiles;
+  const int lin = xcd_remap(blockIdx.x, tiles * a.nsplit);
+  const int split = lin / tiles;
+  conv_wgrad2_body<MODE>(a, split, lin - split * tiles);
+}
+
+// Grouped launch: n problems (the convs of one Bottleneck: same pixels, same split count) as ONE tile list.  Per problem the output has
+// only 4-18 tiles, so alone it needs 14-31 pixel splits to fill 256 CUs -- 14-31 fp32 slabs written and re-read, and ~15 us of
+// launch-shaped time for 20-40 stages of work.  Together the three convs of a layer-3 block have 34 tiles: 7 splits fill the chip, each
+// workgroup runs 84 stages, and the slabs shrink to a third.  Split-major order as above: the tiles of one split (of every problem)
+// share an XCD.
+__global__ __launch_bounds__(512, 2) void conv_wgrad2_multi_kernel(const Wgrad2KArgs* __restrict__ jobs, int njobs, int tiles) {
+  const int lin = xcd_remap(blockIdx.x, (int)gridDim.x);
+  const int split = lin / tiles;
+  const int t = lin - split * tiles;
+  int j = 0;
+  for (int i = 1; i < njobs; ++i) if (t >= jobs[i].tile0) j = i;
+  conv_wgrad2_body<0>(jobs[j], split, t - jobs[j].tile0);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void conv_wgrad3_kernel(Wgrad2KArgs a) {
+  const int tiles = a.cotiles * a.ktiles;
+  const int lin = xcd_remap(blockIdx.x, tiles * a.nsplit);
+  const int split = lin / tiles;
+  conv_wgrad3_body<MODE>(a, split, lin - split * tiles);
+}
+__global__ __launch_bounds__(512, 2) void conv_wgrad3_multi_kernel(const Wgrad2KArgs* __restrict__ jobs, int njobs, int tiles) {
+  const int lin = xcd_remap(blockIdx.x, (int)gridDim.x);
+  const int split = lin / tiles;
+  const int t = lin - split * tiles;
+  int j = 0;
+  for (int i = 1; i < njobs; ++i) if (t >= jobs[i].tile0) j = i;
+  conv_wgrad3_body<0>(jobs[j], split, t - jobs[j].tile0);
+}
+
+// Rows of dY channels per output tile: 256 (conv_wgrad3_body) when the problem has whole 256-channel tiles, else 128.
+extern "C" int simt_conv_wgrad_tile_co(const simt_wgrad_desc* d) {
+  static const int off = getenv("SIMT_WGRAD3") ? atoi(getenv("SIMT_WGRAD3")) == 0 : 0;         // SIMT_WGRAD3=0: the 128-row tile everywhere (A/B)
+  // few pixels (DeepLabv3's stride-16 maps, M = 8 580): half the tiles means twice the splits to fill the chip -- twice the slab bytes for
+  // a handful of stages per workgroup; measured 517 -> 505 images/s there, against 558 -> 582 on VGG16 at M = 33 800
+  const long M = (long)d->B * d->Ho * d->Wo;
+  return (!off && M >= SIMT_WGRAD3_MIN_PIXELS && d->Cd % 256 == 0 && (d->ntaps * d->Cin) % 4 == 0) ? 256 : 128;
+}
+
+static int wgrad2_fill_args(const simt_wgrad_desc* d, Wgrad2KArgs& k, int tile_co = 128) {
   k.dy = (const char*)d->dy; k.x = (const char*)d->x; k.slab = d->slab; k.zero = (const char*)simt_zero_page();
   k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Ho = d->Ho; k.Wo = d->Wo; k.Cd = d->Cd; k.ldd = d->ldd;
   k.stride = d->stride; k.ntaps = d->ntaps; k.M = d->B * d->Ho * d->Wo; k.Ktot = d->ntaps * d->Cin;
@@ -262,12 +505,90 @@ int simt_conv_wgrad_bf16_v2(const simt_wgrad_desc* d, simt_stream_t stream) {
   k.nsplit = d->nsplit;
   const int pps = (k.M + k.nsplit - 1) / k.nsplit;
   k.pix_per_split = ((pps + 63) / 64) * 64;
-  k.cotiles = (d->Cd + 127) / 128;
+  k.cotiles = (d->Cd + tile_co - 1) / tile_co;
   k.ktiles = (k.Ktot + 255) / 256;
+  k.tile0 = 0;
   k.rcpWo = 1.0f / (float)d->Wo;
   k.rcpHoWo = 1.0f / (float)(d->Ho * d->Wo);
   for (int i = 0; i < SIMT_MAX_TAPS; ++i) { k.tdy[i] = d->dy_[i]; k.tdx[i] = d->dx_[i]; }
-  const int lds = 3 * 3 * 64 * 256;
+  return SIMT_OK;
+}
+
+static const int WGRAD2_LDS = 3 * 3 * 64 * 256;
+static const int WGRAD3_LDS = 4 * 4 * 32 * 256;
+
+bool simt_conv_wgrad_v2_eligible(const simt_wgrad_desc* d);     // conv_wgrad.hip: the dispatch rule of simt_conv_wgrad
+
+extern "C" int simt_conv_wgrad_multi_ok(const simt_wgrad_desc* d) { return d && simt_conv_wgrad_v2_eligible(d) ? 1 : 0; }
+extern "C" int simt_conv_wgrad_multi_bytes(void) { return (int)sizeof(Wgrad2KArgs); }
+
+extern "C" int simt_conv_wgrad_multi_prepare(const simt_wgrad_desc* d, int n, void* table_host, int* grid, int* tile_co) {
+  SIMT_CHECK(d && table_host && grid && tile_co && n >= 1 && n <= SIMT_WGRAD_MULTI_MAX);
+  Wgrad2KArgs* k = (Wgrad2KArgs*)table_host;
+  int tiles = 0, tco = 256;
+  for (int i = 0; i < n; ++i) if (simt_conv_wgrad_tile_co(&d[i]) != 256) tco = 128;       // one kernel per launch: the 256-row tile only if every problem takes it
+  *tile_co = tco;
+  for (int i = 0; i < n; ++i) {
+    SIMT_CHECK(d[i].dy && d[i].x && d[i].slab && d[i].ntaps >= 1 && d[i].ntaps <= SIMT_MAX_TAPS);
+    SIMT_CHECK(d[i].Cin % 8 == 0 && d[i].Cd % 8 == 0 && d[i].ldd % 8 == 0 && d[i].Cd <= d[i].ldd);
+    SIMT_CHECK(simt_conv_wgrad_v2_eligible(&d[i]) && d[i].nsplit == d[0].nsplit && d[i].nsplit >= 1);
+    const int rc = wgrad2_fill_args(&d[i], k[i], tco);
+    if (rc != SIMT_OK) return rc;
+    k[i].tile0 = tiles;
+    tiles += k[i].cotiles * k[i].ktiles;
+  }
+  *grid = tiles * d[0].nsplit;
+  return SIMT_OK;
+}
+
+extern "C" int simt_conv_wgrad_multi(const void* table_dev, int n, int grid, int nsplit, int tile_co, simt_stream_t stream) {
+  SIMT_CHECK(table_dev && n >= 1 && n <= SIMT_WGRAD_MULTI_MAX && nsplit >= 1 && grid >= nsplit && grid % nsplit == 0);
+  SIMT_CHECK(tile_co == 128 || tile_co == 256);
+  if (tile_co == 256) {
+    static SimtLdsAttrCache attr_cache3;
+    if (simt_lds_attr_needed(&attr_cache3, WGRAD3_LDS))
+      (void)hipFuncSetAttribute((const void*)conv_wgrad3_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD3_LDS);
+    hipLaunchKernelGGL(conv_wgrad3_multi_kernel, dim3(grid), dim3(512), WGRAD3_LDS, (hipStream_t)stream, (const Wgrad2KArgs*)table_dev, n,
+                       grid / nsplit);
+    SIMT_LAUNCH_CHECK();
+    return SIMT_OK;
+  }
+  static SimtLdsAttrCache attr_cache;
+  if (simt_lds_attr_needed(&attr_cache, WGRAD2_LDS))
+    (void)hipFuncSetAttribute((const void*)conv_wgrad2_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD2_LDS);
+  hipLaunchKernelGGL(conv_wgrad2_multi_kernel, dim3(grid), dim3(512), WGRAD2_LDS, (hipStream_t)stream, (const Wgrad2KArgs*)table_dev, n,
+                     grid / nsplit);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+// Called by simt_conv_wgrad (conv_wgrad.hip) for bf16 problems with Cd >= 64.
+int simt_conv_wgrad_bf16_v2(const simt_wgrad_desc* d, simt_stream_t stream) {
+  Wgrad2KArgs k;
+  const int tco = simt_conv_wgrad_tile_co(d);
+  { const int rc = wgrad2_fill_args(d, k, tco); if (rc != SIMT_OK) return rc; }
+  if (tco == 256) {
+    static SimtLdsAttrCache attr_cache3;
+    if (simt_lds_attr_needed(&attr_cache3, WGRAD3_LDS))
+      (void)hipFuncSetAttribute((const void*)conv_wgrad3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD3_LDS);
+#ifdef SIMT_ABLATION     // timing ablations (loads only / fragment reads + MFMA only: MEANINGLESS outputs), never in the product library
+    {
+      static const int mode3 = getenv("SIMT_WGRAD2_MODE") ? atoi(getenv("SIMT_WGRAD2_MODE")) : 0;
+      if (mode3 == 1 || mode3 == 2) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD3_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD3_LDS);
+        if (mode3 == 1) hipLaunchKernelGGL(conv_wgrad3_kernel<1>, dim3(k.cotiles * k.ktiles * k.nsplit), dim3(512), WGRAD3_LDS, (hipStream_t)stream, k);
+        else hipLaunchKernelGGL(conv_wgrad3_kernel<2>, dim3(k.cotiles * k.ktiles * k.nsplit), dim3(512), WGRAD3_LDS, (hipStream_t)stream, k);
+        SIMT_LAUNCH_CHECK();
+        return SIMT_OK;
+      }
+    }
+#endif
+    hipLaunchKernelGGL(conv_wgrad3_kernel<0>, dim3(k.cotiles * k.ktiles * k.nsplit), dim3(512), WGRAD3_LDS, (hipStream_t)stream, k);
+    SIMT_LAUNCH_CHECK();
+    return SIMT_OK;
+  }
+  const int lds = WGRAD2_LDS;
   static SimtLdsAttrCache attr_cache;
   if (simt_lds_attr_needed(&attr_cache, lds))
     (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -671,6 +671,54 @@ class TrunkPlan:
                     tap_off, cout, rs, 0, stream=stream)
             self.grad_ready[pname] = len(lst)
 
+    def _wgrad_grouped(self):
+        """Group the weight-gradient GEMMs of a Bottleneck into one launch (simt_conv_wgrad_multi)?  bf16 plans; SIMT_WGRAD_GROUP=0: one
+        launch per conv, each behind its own event (the round-2 schedule)."""
+        return self.dtype == torch.bfloat16 and os.environ.get("SIMT_WGRAD_GROUP", "1") != "0"
+
+    def _wgrad_group(self, lst, jobs, stream=1):
+        """jobs: keyword dicts of _wgrad (dy, x, Bn, Hi, Wi, Cin, Ho, Wo, Cd, ldd, taps, stride, parts), all over the same output pixels.
+        One grouped launch with a shared pixel split count, then each problem's fixed-order slab reduce."""
+        M = jobs[0]["Bn"] * jobs[0]["Ho"] * jobs[0]["Wo"]
+        assert all(j["Bn"] * j["Ho"] * j["Wo"] == M for j in jobs)
+        kt = [len(j["taps"]) * j["Cin"] for j in jobs]
+        tco = ops.wgrad_group_tile_co(M, [(j["Cd"], k) for j, k in zip(jobs, kt)])
+        tiles = sum(ops.wgrad_tiles(M, j["Cd"], k, tco) for j, k in zip(jobs, kt))
+        ns = ops.wgrad_group_nsplit(M, tiles)
+        total = sum(ns * j["Cd"] * k for j, k in zip(jobs, kt))
+        assert total <= self._slab_cap
+        slab = self.buf("wgrad.slab" if stream == 1 else "wgrad.slab.main", self._slab_cap, dtype=torch.float32)
+        descs, slabs, off = [], [], 0
+        for j, k in zip(jobs, kt):
+            sl = slab[off:off + ns * j["Cd"] * k]
+            off += ns * j["Cd"] * k
+            slabs.append(sl)
+            descs.append(ops.make_wgrad_desc(j["dy"], j["x"], sl, B=j["Bn"], H=j["Hi"], W=j["Wi"], Cin=j["Cin"], Ho=j["Ho"], Wo=j["Wo"],
+                                             Cd=j["Cd"], taps=j["taps"], stride=j["stride"], nsplit=ns, ldd=j["ldd"]))
+        if not all(ops.wgrad_multi_ok(d) for d in descs) or len(descs) > 8:
+            for j in jobs:
+                self._wgrad(lst, j["dy"], j["x"], None, **{k: v for k, v in j.items() if k not in ("dy", "x")}, stream=stream)
+            return
+        table, grid, tco_c = ops.wgrad_multi_table(descs, self.dev)
+        assert tco_c == tco and grid == tiles * ns
+        flops = sum(2.0 * M * j["Cd"] * k for j, k in zip(jobs, kt))
+        nbytes = sum((M * j["ldd"] + j["Bn"] * j["Hi"] * j["Wi"] * j["Cin"]) * self.esz + ns * j["Cd"] * k * 4 for j, k in zip(jobs, kt))
+        lst.add("simt_conv_wgrad_multi", table.data_ptr(), len(descs), grid, ns, tco, keep=(table, descs, slabs), tag="conv_wgrad<bf16>",
+                flops=flops, nbytes=float(nbytes),
+                shape=f"M{M} group{len(descs)} " + "+".join(f"Cd{j['Cd']}K{k}" for j, k in zip(jobs, kt)) + f" tile{tco} split{ns}",
+                stream=stream)
+        rjobs, names = [], []
+        for j, k, sl in zip(jobs, kt, slabs):
+            for (pname, co_off, tap_off, cout, rs, cin_dst) in j["parts"]:
+                rjobs.append(dict(slab=sl, dst=self.grads[pname], nsplit=ns, Cd=j["Cd"], Ktot=k, Cin=cin_dst, co_off=co_off, tap_off=tap_off,
+                                  Cout=cout, RS=rs))
+                names.append(pname)
+        rt, rn, rblocks = ops.wgrad_reduce_multi_table(rjobs, self.dev)
+        lst.add("simt_wgrad_reduce_multi", rt.data_ptr(), rn, rblocks, keep=(rt, rjobs), tag="simt_wgrad_reduce",
+                nbytes=float(sum(ns * r["Cout"] * r["RS"] * r["Cin"] * 4 for r in rjobs)), stream=stream)
+        for pname in names:
+            self.grad_ready[pname] = len(lst)
+
     def _bnr(self, bname, y, mode, bits=None):
         """Fused first pass of `bname`'s backward for the conv that produces its dz (bf16 v2 kernel; see simt_conv_desc.bnr_*).
         Returns None when the fusion does not apply (fp32 parity plans run the separate reduce kernel)."""
@@ -721,6 +769,11 @@ class TrunkPlan:
             for (cd, kt) in ((p, inpl), (p, 9 * p), (4 * p, p), (4 * p, inpl)):
                 ns = ops.wgrad_nsplit(Mo, cd, kt, dt)
                 self._slab_cap = max(self._slab_cap, ns * cd * kt)
+            if self._wgrad_grouped():
+                shp = [(p, inpl), (p, 9 * p), (4 * p, p)] + ([(4 * p, inpl)] if rec["down"] else [])
+                tco = ops.wgrad_group_tile_co(Mo, shp)
+                ns = ops.wgrad_group_nsplit(Mo, sum(ops.wgrad_tiles(Mo, cd, kt, tco) for cd, kt in shp))
+                self._slab_cap = max(self._slab_cap, ns * sum(cd * kt for cd, kt in shp))
             for cn in (p, 4 * p):
                 self._bnb_cap = max(self._bnb_cap, ops.bn_bwd_nblk(Mo, cn) * 3 * cn)
         M0 = B * self.H0 * self.W0
@@ -790,9 +843,13 @@ class TrunkPlan:
                          reduce_done_nblk=pending_bn3)
             pending_bn3 = 0
             # conv3
-            b.wait(b.record(0), 1)
-            self._wgrad(b, dy3, rec["a2"], None, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4, taps=[(0, 0)],
-                        stride=1, parts=[(f"{name}.conv3.weight", 0, 0, c4, 1, p)])
+            grouped = self._wgrad_grouped()
+            wjobs = [dict(dy=dy3, x=rec["a2"], Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4, taps=[(0, 0)], stride=1,
+                          parts=[(f"{name}.conv3.weight", 0, 0, c4, 1, p)])]
+            if not grouped:
+                b.wait(b.record(0), 1)
+                j = wjobs[0]
+                self._wgrad(b, j["dy"], j["x"], None, **{k: v for k, v in j.items() if k not in ("dy", "x")})
             wt3 = self._plan_pack_t(f"{name}.conv3", c4, p, 1)
             da2 = self.buf("g.da", Mo, p)
             bnr = self._bnr(f"{name}.bn2", rec["y2"], 2)
@@ -801,10 +858,13 @@ class TrunkPlan:
             self._bn_bwd(b, dz=da2, y=rec["y2"], bname=f"{name}.bn2", dy=dy2, M=Mo, Cn=p, mask_mode=2,
                          reduce_done_nblk=self._fused_nblk(dsc, bnr))
             # conv2 (3x3 dilated)
-            b.wait(b.record(0), 1)
             t3 = ops.conv_taps(3, 3, dil, dil)
-            self._wgrad(b, dy2, rec["a1"], None, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cd=p, ldd=p, taps=t3, stride=1,
-                        parts=[(f"{name}.conv2.weight", 0, 0, p, 9, p)])
+            wjobs.append(dict(dy=dy2, x=rec["a1"], Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cd=p, ldd=p, taps=t3, stride=1,
+                              parts=[(f"{name}.conv2.weight", 0, 0, p, 9, p)]))
+            if not grouped:
+                b.wait(b.record(0), 1)
+                j = wjobs[-1]
+                self._wgrad(b, j["dy"], j["x"], None, **{k: v for k, v in j.items() if k not in ("dy", "x")})
             wt2 = self._plan_pack_t(f"{name}.conv2", p, p, 3)
             da1 = self.buf("g.da", Mo, p)
             # dy2 has p channels; the dgrad operand is K-padded to ck >= p: equal here because p % kq == 0
@@ -817,11 +877,18 @@ class TrunkPlan:
                          reduce_done_nblk=self._fused_nblk(dsc, bnr))
             # conv1 (+ downsample) wgrads
             b.wait(b.record(0), 1)
-            self._wgrad(b, dy1, rec["x"], None, Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Ho, Wo=Wo, Cd=p, ldd=p, taps=[(0, 0)],
-                        stride=stride, parts=[(f"{name}.conv1.weight", 0, 0, p, 1, inpl)])
+            wjobs.append(dict(dy=dy1, x=rec["x"], Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Ho, Wo=Wo, Cd=p, ldd=p, taps=[(0, 0)], stride=stride,
+                              parts=[(f"{name}.conv1.weight", 0, 0, p, 1, inpl)]))
             if down:
-                self._wgrad(b, dyd, rec["x"], None, Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4,
-                            taps=[(0, 0)], stride=stride, parts=[(f"{name}.downsample.0.weight", 0, 0, c4, 1, inpl)])
+                wjobs.append(dict(dy=dyd, x=rec["x"], Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4, taps=[(0, 0)],
+                                  stride=stride, parts=[(f"{name}.downsample.0.weight", 0, 0, c4, 1, inpl)]))
+            if grouped:
+                # ONE launch for the block's weight gradients: 34 output tiles (layer 3) instead of 18 / 8 / 8, so 7 pixel splits fill the
+                # chip where the single launches need 14 / 31 / 31 (a third of the fp32 slabs, one launch-shaped overhead instead of three)
+                self._wgrad_group(b, wjobs)
+            else:
+                for j in wjobs[2:]:
+                    self._wgrad(b, j["dy"], j["x"], None, **{k: v for k, v in j.items() if k not in ("dy", "x")})
             last_side[par] = b.record(1)
             if first_needed:          # nothing below this block needs a gradient
                 self.bwd_marks[name] = (blk_start, len(b), dz, None)

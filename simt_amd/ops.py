@@ -131,7 +131,7 @@ def wgrad_nsplit(M, Cd, Ktot, dtype, target_wg=768):
     """Split factor over the pixel dimension.  bf16 / Cd >= 64 / Ktot >= 64 runs the 128x256-tile kernel with one
     workgroup per CU: aim at a whole number of 256-CU rounds; otherwise the 128x128 kernel at ~3 workgroups per CU."""
     if dtype == torch.bfloat16 and Cd >= 64 and Ktot >= 64:
-        tiles = ((Cd + 127) // 128) * ((Ktot + 255) // 256)
+        tiles = wgrad_tiles(M, Cd, Ktot)
         max_split = max(1, M // (64 * 8))
         best, best_cost = 1, None
         for ns in range(1, min(max_split, 256) + 1):     # one-tile problems (layer1, stem) need up to 256 splits to fill the chip
@@ -145,6 +145,82 @@ def wgrad_nsplit(M, Cd, Ktot, dtype, target_wg=768):
     bp = 64 if dtype == torch.bfloat16 else 32
     max_split = max(1, M // (bp * 4))
     return int(max(1, min(max_split, (target_wg + tiles - 1) // tiles, 64)))
+
+
+def wgrad_group_nsplit(M, tiles, max_cap=256):
+    """Pixel split count of a grouped weight-gradient launch with `tiles` output tiles in all (simt_conv_wgrad_multi): whole 256-CU
+    rounds, the same cost model as wgrad_nsplit."""
+    max_split = max(1, M // (64 * 8))
+    best, best_cost = 1, None
+    for ns in range(1, min(max_split, max_cap) + 1):
+        rounds = -(-tiles * ns // 256)
+        stages = -(-M // (ns * 64))
+        cost = rounds * (stages + 6)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = ns, cost
+    return best
+
+
+WGRAD3_MIN_PIXELS = 16384      # include/simt_hip.h SIMT_WGRAD3_MIN_PIXELS
+
+
+def wgrad_tile_co(M, Cd, Ktot):
+    """dY channels per output tile of the bf16 kernel (the rule of simt_conv_wgrad_tile_co): 256 when Cd has whole 256-channel tiles
+    and the problem has enough pixels."""
+    import os
+    return 256 if (M >= WGRAD3_MIN_PIXELS and Cd % 256 == 0 and Ktot % 4 == 0 and os.environ.get("SIMT_WGRAD3", "1") != "0") else 128
+
+
+def wgrad_tiles(M, Cd, Ktot, tile_co=None):
+    """Output tiles of one problem on the bf16 kernel (tile_co x 256)."""
+    tile_co = tile_co or wgrad_tile_co(M, Cd, Ktot)
+    return ((Cd + tile_co - 1) // tile_co) * ((Ktot + 255) // 256)
+
+
+def wgrad_multi_ok(d):
+    return bool(L.load().simt_conv_wgrad_multi_ok(C.byref(d)))
+
+
+def wgrad_multi_table(descs, device):
+    """Device argument table of a grouped launch (simt_conv_wgrad_multi_prepare) -> (uint8 tensor, grid)."""
+    lib = L.load()
+    n = len(descs)
+    arr = (L.WgradDesc * n)(*descs)
+    nb = lib.simt_conv_wgrad_multi_bytes() * n
+    host = (C.c_uint8 * nb)()
+    grid, tco = C.c_int(), C.c_int()
+    L.check(lib.simt_conv_wgrad_multi_prepare(arr, n, C.cast(host, C.c_void_p), C.byref(grid), C.byref(tco)))
+    t = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
+    return t, grid.value, tco.value
+
+
+def wgrad_group_tile_co(M, shapes):
+    """shapes: [(Cd, Ktot)] of a grouped launch over M pixels -> its tile height (256 only if every problem takes it)."""
+    return 256 if all(wgrad_tile_co(M, cd, kt) == 256 for cd, kt in shapes) else 128
+
+
+def wgrad_multi(table, n, grid, nsplit, tile_co):
+    L.call("simt_conv_wgrad_multi", _p(table), n, grid, nsplit, tile_co, stream_ptr())
+
+
+def wgrad_reduce_multi_table(jobs, device):
+    """jobs: dicts(slab, dst, nsplit, Cd, Ktot, Cin, co_off, tap_off, Cout, RS[, accumulate]) -> (device table, n, blocks) for
+    simt_wgrad_reduce_multi."""
+    arr = (L.WgradReduceJob * len(jobs))()
+    blocks = 0
+    for a, j in zip(arr, jobs):
+        assert j["Cin"] % 4 == 0 and j["Ktot"] % 4 == 0
+        a.slab, a.dst = _p(j["slab"]), _p(j["dst"])
+        a.nsplit, a.Cd, a.Ktot, a.Cin = j["nsplit"], j["Cd"], j["Ktot"], j["Cin"]
+        a.co_off, a.tap_off, a.Cout, a.RS = j["co_off"], j["tap_off"], j["Cout"], j["RS"]
+        a.accumulate, a.block0 = int(j.get("accumulate", False)), blocks
+        blocks += -(-(j["Cout"] * j["RS"] * j["Cin"] // 4) // 256)
+    t = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    return t, len(jobs), blocks
+
+
+def wgrad_reduce_multi(table, n, blocks):
+    L.call("simt_wgrad_reduce_multi", _p(table), n, blocks, stream_ptr())
 
 
 def wgrad_reduce(slab, dst, *, nsplit, Cd, Ktot, Cin, co_off, tap_off, Cout, RS, accumulate=False):

@@ -376,3 +376,61 @@ def test_weights_direct_kernel_is_bitwise_the_lds_kernel(dev, case):
         ref = ref.clamp_min(0)
     got = yb[:, :Cout].float().cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
     assert _rel(got, ref) < 1e-2
+
+
+@pytest.mark.parametrize("geom", [(2, 33, 33, 256, 2), (4, 65, 65, 256, 2), (1, 40, 24, 64, 1), (3, 17, 19, 128, 4)])
+def test_grouped_wgrad_launch_is_bitwise_the_single_launches(dev, geom):
+    """simt_conv_wgrad_multi: the three weight-gradient GEMMs of a Bottleneck (1x1 4p -> p, 3x3 p -> p dilated, 1x1 p -> 4p) as ONE
+    launch with a shared pixel split count == three simt_conv_wgrad launches with that split count, slab for slab, bit for bit
+    (reference: the gradients autograd computes at tools/trainV2_simt.py:428 for model/deeplab_multi.py:62,68,73); and the reduced
+    gradient against the torch CPU fp32 reference (oracle/ops_ref.py) at the bf16 tolerance of this file."""
+    B, H, W, p, dil = geom
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(31 + p + H)
+    M = B * H * W
+    probs = []   # (dy [M, Cd], x [B,H,W,Cin], taps, Cd, Cin)
+    for (cd, cin, k) in ((p, 4 * p, 1), (p, p, 3), (4 * p, p, 1)):
+        dy = torch.randn(M, cd, generator=g).to(dev, dt)
+        x = torch.randn(B, H, W, cin, generator=g).to(dev, dt)
+        taps = ops.conv_taps(k, k, dil if k == 3 else 1, dil * (k // 2) if k == 3 else 0)
+        probs.append((dy, x, taps, cd, cin))
+    tco = ops.wgrad_group_tile_co(M, [(cd, len(t) * cin) for (_, _, t, cd, cin) in probs])
+    assert tco == (256 if (p % 256 == 0 and M >= ops.WGRAD3_MIN_PIXELS) else 128)
+    tiles = sum(ops.wgrad_tiles(M, cd, len(t) * cin, tco) for (_, _, t, cd, cin) in probs)
+    ns = ops.wgrad_group_nsplit(M, tiles)
+    assert ns >= 1
+
+    def descs(slabs):
+        return [ops.make_wgrad_desc(dy, x, sl, B=B, H=H, W=W, Cin=cin, Ho=H, Wo=W, Cd=cd, taps=t, nsplit=ns)
+                for (dy, x, t, cd, cin), sl in zip(probs, slabs)]
+
+    s_single = [torch.full((ns, cd, len(t) * cin), float("nan"), device=dev) for (_, _, t, cd, cin) in probs]
+    s_multi = [torch.full((ns, cd, len(t) * cin), float("nan"), device=dev) for (_, _, t, cd, cin) in probs]
+    for d in descs(s_single):
+        assert ops.wgrad_multi_ok(d)
+        ops.conv_wgrad_desc(d)
+    dm = descs(s_multi)
+    table, grid, tco_c = ops.wgrad_multi_table(dm, dev)
+    assert grid == tiles * ns and tco_c == tco
+    ops.wgrad_multi(table, len(dm), grid, ns, tco)
+    torch.cuda.synchronize()
+    for a, b in zip(s_single, s_multi):
+        assert torch.isfinite(b).all()
+        assert torch.equal(a, b)
+    # the grouped reduce (simt_wgrad_reduce_multi) == the single reduces, bit for bit; then every gradient against the fp32 reference on
+    # the bf16-rounded operands
+    ks = [3 if len(t) == 9 else 1 for (_, _, t, _, _) in probs]
+    g_multi = [torch.full((cd, cin, k, k), float("nan"), device=dev) for (_, _, _, cd, cin), k in zip(probs, ks)]
+    rt, rn, rblocks = ops.wgrad_reduce_multi_table(
+        [dict(slab=sl, dst=gm, nsplit=ns, Cd=cd, Ktot=k * k * cin, Cin=cin, co_off=0, tap_off=0, Cout=cd, RS=k * k)
+         for (_, _, _, cd, cin), sl, gm, k in zip(probs, s_multi, g_multi, ks)], dev)
+    ops.wgrad_reduce_multi(rt, rn, rblocks)
+    for (dy, x, taps, cd, cin), sl, gm, k in zip(probs, s_multi, g_multi, ks):
+        got = torch.empty(cd, cin, k, k, device=dev)
+        ops.wgrad_reduce(sl, got, nsplit=ns, Cd=cd, Ktot=k * k * cin, Cin=cin, co_off=0, tap_off=0, Cout=cd, RS=k * k)
+        assert torch.equal(got, gm)
+        xr = x.float().cpu().permute(0, 3, 1, 2)
+        w = torch.zeros(cd, cin, k, k, requires_grad=True)
+        y = torch.nn.functional.conv2d(xr, w, padding=dil * (k // 2), dilation=dil if k == 3 else 1)
+        y.backward(dy.float().cpu().view(B, H, W, cd).permute(0, 3, 1, 2))
+        assert _rel(got.cpu(), w.grad) <= 1e-2

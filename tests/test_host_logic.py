@@ -41,7 +41,8 @@ def test_ctypes_struct_sizes_match_header():
     from simt_amd import _lib
     structs = {"simt_conv_desc": _lib.ConvDesc, "simt_wgrad_desc": _lib.WgradDesc, "simt_bn_bwd_desc": _lib.BnBwdDesc,
                "simt_head_desc": _lib.HeadDesc, "simt_ntm_inner_desc": _lib.NtmInnerDesc,
-               "simt_ntm_post_desc": _lib.NtmPostDesc, "simt_sgd_desc": _lib.SgdDesc, "simt_tap_desc": _lib.TapDesc}
+               "simt_ntm_post_desc": _lib.NtmPostDesc, "simt_sgd_desc": _lib.SgdDesc, "simt_tap_desc": _lib.TapDesc,
+               "simt_wgrad_reduce_job": _lib.WgradReduceJob}
     prog = '#include <stdio.h>\n#include "simt_hip.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in structs) + "return 0;}"
     with tempfile.TemporaryDirectory() as td:
