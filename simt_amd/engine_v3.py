@@ -287,6 +287,15 @@ class V3Plan(TrunkPlan):
             bns += [(rec["Mi"], p), (rec["Mo"], p), (rec["Mo"], 4 * p)]
         for (m, cd, kt) in shapes:
             self._slab_cap = max(self._slab_cap, ops.wgrad_nsplit(m, cd, kt, dt) * cd * kt)
+        if self._wgrad_grouped():       # one grouped launch per Bottleneck whose three (four) convs see the same pixels (engine._wgrad_group)
+            for rec in self.block_io:
+                if rec["Mi"] != rec["Mo"]:
+                    continue
+                p, inpl, m = rec["planes"], rec["inpl"], rec["Mo"]
+                shp = [(p, inpl), (p, 9 * p), (4 * p, p)] + ([(4 * p, inpl)] if rec["down"] else [])
+                tco = ops.wgrad_group_tile_co(m, shp)
+                ns = ops.wgrad_group_nsplit(m, sum(ops.wgrad_tiles(m, cd, kt, tco) for cd, kt in shp))
+                self._slab_cap = max(self._slab_cap, ns * sum(cd * kt for cd, kt in shp))
         for (m, cn) in bns:
             self._bnb_cap = max(self._bnb_cap, ops.bn_bwd_nblk(m, cn) * 3 * cn)
         self.grad_ready, self.bwd_marks = {}, {}
@@ -357,12 +366,23 @@ class V3Plan(TrunkPlan):
             dyd = self.new(Mo, c4) if down else None
             self._bnb(b, dz=dz, z=rec["zbits"], y=rec["y3"], bname=name + ".bn3", dy=dy3, M=Mo, Cn=c4, mask_mode=3, y2=rec.get("yd"),
                       bname2=name + ".downsample.1" if down else None, dy2=dyd)
-            b.wait(b.record(0), 1)
-            self._wgrad(b, dy3, rec["a2"], None, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4, taps=[(0, 0)], stride=1,
-                        parts=[(name + ".conv3.weight", 0, 0, c4, 1, p)])
+            # weight gradients: one grouped launch at the end of the block when its convs see the same pixels (stride 1), else one launch
+            # per conv behind its own event
+            grouped = self._wgrad_grouped() and Mi == Mo
+            wjobs = []
+
+            def wgrad(first, **job):
+                if grouped:
+                    wjobs.append(job)
+                    return
+                if first:
+                    b.wait(b.record(0), 1)
+                self._wgrad(b, job["dy"], job["x"], None, **{k: v for k, v in job.items() if k not in ("dy", "x")})
+            wgrad(True, dy=dy3, x=rec["a2"], Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4, taps=[(0, 0)], stride=1,
+                  parts=[(name + ".conv3.weight", 0, 0, c4, 1, p)])
             if down:
-                self._wgrad(b, dyd, rec["x"], None, Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4, taps=[(0, 0)],
-                            stride=stride, parts=[(name + ".downsample.0.weight", 0, 0, c4, 1, inpl)])
+                wgrad(False, dy=dyd, x=rec["x"], Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Ho, Wo=Wo, Cd=c4, ldd=c4, taps=[(0, 0)],
+                      stride=stride, parts=[(name + ".downsample.0.weight", 0, 0, c4, 1, inpl)])
             wt3 = self._plan_pack_t(name + ".conv3", c4, p, 1)
             da2 = self.new(Mo, p)
             bnr = self._bnr(name + ".bn2", rec["y2"], 2)       # first pass of bn2's backward inside the GEMM that produces da2
@@ -371,10 +391,9 @@ class V3Plan(TrunkPlan):
             self._bnb(b, dz=da2, y=rec["y2"], bname=name + ".bn2", dy=dy2, M=Mo, Cn=p, mask_mode=2,
                       reduce_done_nblk=self._fused_nblk(dsc, bnr))
             # conv2: 3x3, stride s.  dgrad of a strided conv = stride-1 correlation of the zero-inserted dY with mirrored taps
-            b.wait(b.record(0), 1)
             t3 = ops.conv_taps(3, 3, 1, 1)
-            self._wgrad(b, dy2, rec["a1"], None, Bn=B, Hi=Hi, Wi=Wi, Cin=p, Ho=Ho, Wo=Wo, Cd=p, ldd=p, taps=t3, stride=stride,
-                        parts=[(name + ".conv2.weight", 0, 0, p, 9, p)])
+            wgrad(True, dy=dy2, x=rec["a1"], Bn=B, Hi=Hi, Wi=Wi, Cin=p, Ho=Ho, Wo=Wo, Cd=p, ldd=p, taps=t3, stride=stride,
+                  parts=[(name + ".conv2.weight", 0, 0, p, 9, p)])
             wt2 = self._plan_pack_t(name + ".conv2", p, p, 3)
             assert wt2[3] == p and wt3[3] == c4
             src = dy2
@@ -388,9 +407,11 @@ class V3Plan(TrunkPlan):
             dy1 = self.new(Mi, p)
             self._bnb(b, dz=da1, y=rec["y1"], bname=name + ".bn1", dy=dy1, M=Mi, Cn=p, mask_mode=2,
                       reduce_done_nblk=self._fused_nblk(dsc, bnr))
-            b.wait(b.record(0), 1)
-            self._wgrad(b, dy1, rec["x"], None, Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Hi, Wo=Wi, Cd=p, ldd=p, taps=[(0, 0)], stride=1,
-                        parts=[(name + ".conv1.weight", 0, 0, p, 1, inpl)])
+            wgrad(True, dy=dy1, x=rec["x"], Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Hi, Wo=Wi, Cd=p, ldd=p, taps=[(0, 0)], stride=1,
+                  parts=[(name + ".conv1.weight", 0, 0, p, 1, inpl)])
+            if grouped:
+                b.wait(b.record(0), 1)
+                self._wgrad_group(b, wjobs)
             # shortcut gradient at the block input's resolution
             if down:
                 wtd = self._plan_pack_t(name + ".downsample.0", c4, inpl, 1)
