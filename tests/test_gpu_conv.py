@@ -25,6 +25,10 @@ CASES = [
     (24, 4, 4, 64, 64, 3, 1, 1),
     (11, 7, 7, 128, 64, 3, 2, 1),
     (9, 4, 8, 64, 128, 1, 1, 1),
+    # >= 16 384 output pixels and Cout % 256 == 0: the 256 x 256 weight-gradient tile (conv_wgrad3_body), strided (per-stage pixel
+    # decomposition) and with taps
+    (4, 130, 130, 64, 256, 1, 1, 2),
+    (4, 65, 65, 64, 256, 3, 2, 1),
 ]
 
 
@@ -85,6 +89,10 @@ def test_conv_fprop_dgrad_wgrad(dev, dtype, case):
         slab = torch.full((nsplit, Cd, Ktot), float("nan"), device=dev)
         wd = ops.make_wgrad_desc(dy_d, x_d, slab, B=B, H=H, W=W, Cin=Cin, Ho=Ho, Wo=Wo, Cd=Cd, taps=taps, stride=stride,
                                  nsplit=nsplit)
+        if dtype == torch.bfloat16:          # which tile the library takes for this problem is part of its contract (include/simt_hip.h)
+            from simt_amd import _lib
+            import ctypes
+            assert _lib.load().simt_conv_wgrad_tile_co(ctypes.byref(wd)) == ops.wgrad_tile_co(B * Ho * Wo, Cd, Ktot)
         ops.conv_wgrad_desc(wd)
         dw_d = torch.full((Cout, Cin, k, k), float("nan"), device=dev)
         ops.wgrad_reduce(slab, dw_d, nsplit=nsplit, Cd=Cd, Ktot=Ktot, Cin=Cin, co_off=0, tap_off=0, Cout=Cout, RS=k * k)
