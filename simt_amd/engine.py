@@ -769,13 +769,21 @@ class TrunkPlan:
             for (cd, kt) in ((p, inpl), (p, 9 * p), (4 * p, p), (4 * p, inpl)):
                 ns = ops.wgrad_nsplit(Mo, cd, kt, dt)
                 self._slab_cap = max(self._slab_cap, ns * cd * kt)
-            if self._wgrad_grouped():
-                shp = [(p, inpl), (p, 9 * p), (4 * p, p)] + ([(4 * p, inpl)] if rec["down"] else [])
+            for cn in (p, 4 * p):
+                self._bnb_cap = max(self._bnb_cap, ops.bn_bwd_nblk(Mo, cn) * 3 * cn)
+        if self._wgrad_grouped():
+            def blk_shapes(rec):
+                p, inpl = rec["planes"], rec["inpl"]
+                return [(p, inpl), (p, 9 * p), (4 * p, p)] + ([(4 * p, inpl)] if rec["down"] else [])
+            cands = [[r] for r in self.block_io] + [[a, c] for a, c in zip(self.block_io[1:], self.block_io[:-1])]
+            for grp in cands:
+                Mo = grp[0]["Mo"]
+                shp = sum((blk_shapes(r) for r in grp), [])
+                if any(r["Mo"] != Mo for r in grp) or len(shp) > 8:
+                    continue
                 tco = ops.wgrad_group_tile_co(Mo, shp)
                 ns = ops.wgrad_group_nsplit(Mo, sum(ops.wgrad_tiles(Mo, cd, kt, tco) for cd, kt in shp))
                 self._slab_cap = max(self._slab_cap, ns * sum(cd * kt for cd, kt in shp))
-            for cn in (p, 4 * p):
-                self._bnb_cap = max(self._bnb_cap, ops.bn_bwd_nblk(Mo, cn) * 3 * cn)
         M0 = B * self.H0 * self.W0
         self._slab_cap = max(self._slab_cap, ops.wgrad_nsplit(M0, 64, 192, dt) * 64 * 192)
         self._bnb_cap = max(self._bnb_cap, ops.bn_bwd_nblk(M0, 64) * 3 * 64)
@@ -810,6 +818,20 @@ class TrunkPlan:
         b.wait(e0, 1)
         npar = max(2, int(os.environ.get("SIMT_DY_BUFFERS", "4")))      # dY buffer sets: the dgrad chain may run this many blocks ahead of the weight gradients
         last_side = {i: None for i in range(npar)}
+        # Grouped weight gradients: the jobs of up to TWO consecutive Bottlenecks over the same pixels (and the same tile rule) go into one
+        # launch (SIMT_WGRAD_PAIR=0: one Bottleneck per launch): 34 tiles of 256 x 256 fill the chip with 7 pixel splits where one block's
+        # 17 need 15 -- half the slab bytes again.
+        pair_ok = os.environ.get("SIMT_WGRAD_PAIR", "1") != "0"
+        pend = {"jobs": [], "pars": [], "M": None, "tco": None, "blocks": 0}
+
+        def flush_wgrads():
+            if not pend["jobs"]:
+                return
+            self._wgrad_group(b, pend["jobs"])
+            ev = b.record(1)
+            for q in pend["pars"]:
+                last_side[q] = ev
+            pend.update(jobs=[], pars=[], M=None, tco=None, blocks=0)
         pending_bn3 = 0       # slots of bn3-backward partials the previous iteration's dx GEMM already reduced (0: none)
         for bi in range(n_blocks - 1, -1, -1):
             rec = self.block_io[bi]
@@ -885,11 +907,18 @@ class TrunkPlan:
             if grouped:
                 # ONE launch for the block's weight gradients: 34 output tiles (layer 3) instead of 18 / 8 / 8, so 7 pixel splits fill the
                 # chip where the single launches need 14 / 31 / 31 (a third of the fp32 slabs, one launch-shaped overhead instead of three)
-                self._wgrad_group(b, wjobs)
+                tco_b = ops.wgrad_group_tile_co(Mo, [(j["Cd"], len(j["taps"]) * j["Cin"]) for j in wjobs])
+                if pend["jobs"] and (pend["M"] != Mo or pend["tco"] != tco_b or len(pend["jobs"]) + len(wjobs) > 8):
+                    flush_wgrads()
+                pend["jobs"] += wjobs
+                pend["pars"].append(par)
+                pend.update(M=Mo, tco=tco_b, blocks=pend["blocks"] + 1)
+                if not pair_ok or pend["blocks"] == 2 or first_needed or bi == 0:
+                    flush_wgrads()
             else:
                 for j in wjobs[2:]:
                     self._wgrad(b, j["dy"], j["x"], None, **{k: v for k, v in j.items() if k not in ("dy", "x")})
-            last_side[par] = b.record(1)
+                last_side[par] = b.record(1)
             if first_needed:          # nothing below this block needs a gradient
                 self.bwd_marks[name] = (blk_start, len(b), dz, None)
                 continue
@@ -927,6 +956,7 @@ class TrunkPlan:
                 b.add("simt_scatter_stride", dxl.data_ptr(), dx.data_ptr(), B, Hi, Wi, inpl, Ho, Wo, stride, ops.dt_code(dt))
             self.bwd_marks[name] = (blk_start, len(b), dz, dx)
             dz = dx
+        flush_wgrads()
         if self.grads_from_layer > 0:
             for n in self.grads:                   # never written: final (zero) from the start, for the DP bucket schedule
                 self.grad_ready.setdefault(n, 0)

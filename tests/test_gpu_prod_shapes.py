@@ -421,8 +421,11 @@ def test_full_depth_r101_bf16_forward_b4_768(dev):
     print(f"train-mode bf16, 33 blocks at B=4 768x768: worst block-level error {worst:.2e}")
 
 
-def _bwd_setup(dev, B, fuse, monkeypatch, seed=99):
+def _bwd_setup(dev, B, fuse, monkeypatch, seed=99, pair=True):
     monkeypatch.setenv("SIMT_BN_FUSE", "1" if fuse else "0")
+    # pair=False: every Bottleneck's weight gradients in its OWN launch range (a per-block replay needs them there); the product plan
+    # groups two consecutive Bottlenecks into one launch, issued in the second one's range
+    monkeypatch.setenv("SIMT_WGRAD_PAIR", "1" if pair else "0")
     K, H, W = 3, 768, 768
     st = so.recipe_state(so.state_shapes(19, K, True), seed=1234, head_scale=8.0)
     img, _ = so.synthetic_batch(B, H, W, CD.numpy(), seed=seed)
@@ -433,7 +436,7 @@ def _bwd_setup(dev, B, fuse, monkeypatch, seed=99):
 
 
 def test_full_depth_r101_bf16_backward_blocks_b1_768(dev, monkeypatch):
-    """Full-depth bf16 BACKWARD, block by block (dgrad <256,*,3> / <128,4,2>, conv_wgrad2 + slab reduce, BatchNorm backward with bit masks)
+    """Full-depth bf16 BACKWARD, block by block (dgrad <256,*,3> / <128,4,2>, grouped conv_wgrad2 / conv_wgrad3 + slab reduce, BatchNorm backward with bit masks)
     at 1 x 768 x 768: every Bottleneck's backward launches are replayed on a seeded dz and compared with autograd through the float64
     bf16-storage model of that block evaluated on the GPU's own block input (roundings passed straight through; the backward's own bf16
     storage of dY is not modelled): input gradient and all 3-4 weight gradients cos > 0.999 and relative L2 < 3e-2.  The fused
@@ -442,7 +445,7 @@ def test_full_depth_r101_bf16_backward_blocks_b1_768(dev, monkeypatch):
     from simt_amd.engine import LaunchList
     _threads()
     B = 1
-    st, tr = _bwd_setup(dev, B, False, monkeypatch)
+    st, tr = _bwd_setup(dev, B, False, monkeypatch, pair=False)
     g = torch.Generator().manual_seed(8)
     worst_cos, worst_l2 = 1.0, 0.0
     for rec in tr.block_io:
