@@ -103,7 +103,7 @@ int simt_wgrad_reduce(const float* slab, float* dst, int nsplit, int Cd, int Kto
  * the caller owns: simt_conv_wgrad_multi_prepare fills its host image (n * simt_conv_wgrad_multi_bytes() bytes) and returns the grid;
  * the caller copies it to device memory once and passes that to simt_conv_wgrad_multi.  simt_conv_wgrad_multi_ok: does the problem
  * qualify (the problems simt_conv_wgrad runs on its 128x256-tile bf16 kernel)? */
-#define SIMT_WGRAD_MULTI_MAX 8
+#define SIMT_WGRAD_MULTI_MAX 16
 int simt_conv_wgrad_multi_ok(const simt_wgrad_desc* d);
 int simt_conv_wgrad_multi_bytes(void);
 int simt_conv_wgrad_multi_prepare(const simt_wgrad_desc* d, int n, void* table_host, int* grid, int* tile_co);
@@ -113,7 +113,7 @@ int simt_conv_wgrad_multi(const void* table_dev, int n, int grid, int nsplit, in
  * count that fills the chip depends on it: tiles = ceil(Cd / tile_co) * ceil(ntaps * Cin / 256). */
 #define SIMT_WGRAD3_MIN_PIXELS 16384   /* the 256-row tile needs B * Ho * Wo >= this (fewer pixels: the extra splits cost more than they save) */
 int simt_conv_wgrad_tile_co(const simt_wgrad_desc* d);
-/* The reduces of a grouped launch as ONE launch: a device table of n <= 16 jobs (the arguments of simt_wgrad_reduce; needs Cin % 4 == 0,
+/* The reduces of a grouped launch as ONE launch: a device table of n <= 2 * SIMT_WGRAD_MULTI_MAX jobs (the arguments of simt_wgrad_reduce; needs Cin % 4 == 0,
  * Ktot % 4 == 0, 16-byte aligned slab and dst).  Job j owns blocks [block0, block0 + ceil(Cout * RS * Cin / 4 / 256)); `blocks` = their
  * total.  Per element the same sum in the same order as simt_wgrad_reduce: bitwise the same gradients. */
 typedef struct {

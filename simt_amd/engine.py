@@ -695,7 +695,7 @@ class TrunkPlan:
             slabs.append(sl)
             descs.append(ops.make_wgrad_desc(j["dy"], j["x"], sl, B=j["Bn"], H=j["Hi"], W=j["Wi"], Cin=j["Cin"], Ho=j["Ho"], Wo=j["Wo"],
                                              Cd=j["Cd"], taps=j["taps"], stride=j["stride"], nsplit=ns, ldd=j["ldd"]))
-        if not all(ops.wgrad_multi_ok(d) for d in descs) or len(descs) > 8:
+        if not all(ops.wgrad_multi_ok(d) for d in descs) or len(descs) > 16:
             for j in jobs:
                 self._wgrad(lst, j["dy"], j["x"], None, **{k: v for k, v in j.items() if k not in ("dy", "x")}, stream=stream)
             return
@@ -775,11 +775,12 @@ class TrunkPlan:
             def blk_shapes(rec):
                 p, inpl = rec["planes"], rec["inpl"]
                 return [(p, inpl), (p, 9 * p), (4 * p, p)] + ([(4 * p, inpl)] if rec["down"] else [])
-            cands = [[r] for r in self.block_io] + [[a, c] for a, c in zip(self.block_io[1:], self.block_io[:-1])]
+            nb = len(self.block_io)
+            cands = [self.block_io[i:i + n] for n in range(1, 6) for i in range(nb - n + 1)]       # every run of up to 5 consecutive blocks
             for grp in cands:
                 Mo = grp[0]["Mo"]
                 shp = sum((blk_shapes(r) for r in grp), [])
-                if any(r["Mo"] != Mo for r in grp) or len(shp) > 8:
+                if any(r["Mo"] != Mo for r in grp) or len(shp) > 16:
                     continue
                 tco = ops.wgrad_group_tile_co(Mo, shp)
                 ns = ops.wgrad_group_nsplit(Mo, sum(ops.wgrad_tiles(Mo, cd, kt, tco) for cd, kt in shp))
@@ -816,12 +817,15 @@ class TrunkPlan:
         # the block SIMT_DY_BUFFERS (default 4; memory is not the constraint) steps back before it overwrites them.
         e0 = b.record(0)
         b.wait(e0, 1)
-        npar = max(2, int(os.environ.get("SIMT_DY_BUFFERS", "4")))      # dY buffer sets: the dgrad chain may run this many blocks ahead of the weight gradients
+        npar = max(2, int(os.environ.get("SIMT_DY_BUFFERS", "6" if self._wgrad_grouped() else "4")))      # dY buffer sets: the dgrad chain may run this many blocks ahead of the weight gradients
         last_side = {i: None for i in range(npar)}
-        # Grouped weight gradients: the jobs of up to TWO consecutive Bottlenecks over the same pixels (and the same tile rule) go into one
-        # launch (SIMT_WGRAD_PAIR=0: one Bottleneck per launch): 34 tiles of 256 x 256 fill the chip with 7 pixel splits where one block's
-        # 17 need 15 -- half the slab bytes again.
+        # Grouped weight gradients: the jobs of up to SIMT_WGRAD_BLOCKS (default 3) consecutive Bottlenecks over the same pixels (and the
+        # same tile rule) go into one launch (SIMT_WGRAD_PAIR=0: one Bottleneck per launch): 34 tiles of 256 x 256 fill the chip with 7
+        # pixel splits where one block's 17 need 15 -- half the slab bytes again; 51 tiles with 5.  Measured per step: 26.03 ms one block per
+        # launch, 25.88 two, 25.80 three, 25.80 four (the weight gradients of a group start when its LAST block's dY is there: the dY
+        # buffer sets, SIMT_DY_BUFFERS, must outnumber the blocks of a group by three).
         pair_ok = os.environ.get("SIMT_WGRAD_PAIR", "1") != "0"
+        nblk_group = max(1, min(npar - 3, int(os.environ.get("SIMT_WGRAD_BLOCKS", "3")))) if pair_ok else 1
         pend = {"jobs": [], "pars": [], "M": None, "tco": None, "blocks": 0}
 
         def flush_wgrads():
@@ -908,12 +912,12 @@ class TrunkPlan:
                 # ONE launch for the block's weight gradients: 34 output tiles (layer 3) instead of 18 / 8 / 8, so 7 pixel splits fill the
                 # chip where the single launches need 14 / 31 / 31 (a third of the fp32 slabs, one launch-shaped overhead instead of three)
                 tco_b = ops.wgrad_group_tile_co(Mo, [(j["Cd"], len(j["taps"]) * j["Cin"]) for j in wjobs])
-                if pend["jobs"] and (pend["M"] != Mo or pend["tco"] != tco_b or len(pend["jobs"]) + len(wjobs) > 8):
+                if pend["jobs"] and (pend["M"] != Mo or pend["tco"] != tco_b or len(pend["jobs"]) + len(wjobs) > 16):
                     flush_wgrads()
                 pend["jobs"] += wjobs
                 pend["pars"].append(par)
                 pend.update(M=Mo, tco=tco_b, blocks=pend["blocks"] + 1)
-                if not pair_ok or pend["blocks"] == 2 or first_needed or bi == 0:
+                if pend["blocks"] >= nblk_group or first_needed or bi == 0:
                     flush_wgrads()
             else:
                 for j in wjobs[2:]:
