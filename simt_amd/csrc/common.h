@@ -51,6 +51,21 @@ __device__ __forceinline__ void load8(const bf16_t* p, float* v) {
   v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
   v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
 }
+// 8 elements as loaded (16 / 32 bytes), unpacked later: batches of loads can be in flight without holding 8 floats each
+template <typename T> struct Raw8;
+template <> struct Raw8<float> { float4 a, b; };
+template <> struct Raw8<bf16_t> { uint4 r; };
+__device__ __forceinline__ void raw8_load(const float* p, Raw8<float>& q) { q.a = *(const float4*)p; q.b = *(const float4*)(p + 4); }
+__device__ __forceinline__ void raw8_load(const bf16_t* p, Raw8<bf16_t>& q) { q.r = *(const uint4*)p; }
+__device__ __forceinline__ void raw8_unpack(const Raw8<float>& q, float* v) {
+  v[0] = q.a.x; v[1] = q.a.y; v[2] = q.a.z; v[3] = q.a.w; v[4] = q.b.x; v[5] = q.b.y; v[6] = q.b.z; v[7] = q.b.w;
+}
+__device__ __forceinline__ void raw8_unpack(const Raw8<bf16_t>& q, float* v) {
+  v[0] = __uint_as_float(q.r.x << 16); v[1] = __uint_as_float(q.r.x & 0xffff0000u);
+  v[2] = __uint_as_float(q.r.y << 16); v[3] = __uint_as_float(q.r.y & 0xffff0000u);
+  v[4] = __uint_as_float(q.r.z << 16); v[5] = __uint_as_float(q.r.z & 0xffff0000u);
+  v[6] = __uint_as_float(q.r.w << 16); v[7] = __uint_as_float(q.r.w & 0xffff0000u);
+}
 __device__ __forceinline__ void store8(float* p, const float* v) {
   *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
   *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
