@@ -114,7 +114,7 @@ int simt_conv_wgrad_multi(const void* table_dev, int n, int grid, int nsplit, in
 #define SIMT_WGRAD3_MIN_PIXELS 16384   /* the 256-row tile needs B * Ho * Wo >= this (fewer pixels: the extra splits cost more than they save) */
 int simt_conv_wgrad_tile_co(const simt_wgrad_desc* d);
 /* The reduces of a grouped launch as ONE launch: a device table of n <= 2 * SIMT_WGRAD_MULTI_MAX jobs (the arguments of simt_wgrad_reduce; needs Cin % 4 == 0,
- * Ktot % 4 == 0, 16-byte aligned slab and dst).  Job j owns blocks [block0, block0 + ceil(Cout * RS * Cin / 4 / 256)); `blocks` = their
+ * Ktot % 4 == 0, 16-byte aligned slab and dst).  Job j owns blocks [block0, block0 + simt_wgrad_reduce_blocks(Cout, RS, Cin)); `blocks` = their
  * total.  Per element the same sum in the same order as simt_wgrad_reduce: bitwise the same gradients. */
 typedef struct {
   const float* slab;
@@ -122,6 +122,7 @@ typedef struct {
   int32_t nsplit, Cd, Ktot, Cin, co_off, tap_off, Cout, RS, accumulate, block0;
 } simt_wgrad_reduce_job;
 int simt_wgrad_reduce_multi(const simt_wgrad_reduce_job* jobs_dev, int n, int blocks, simt_stream_t stream);
+int simt_wgrad_reduce_blocks(int Cout, int RS, int Cin);   /* 256-thread blocks of one job (3x3: a thread owns 4 channels x 9 taps) */
 
 /* ---- tap-expanded ASPP classifier (bf16 throughput path; model/deeplab_multi.py:104-119) -------------------------
  * The N = Q = 22 dilated conv is re-associated into a plain GEMM with one output column per (tap, class) plus a

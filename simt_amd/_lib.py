@@ -101,6 +101,7 @@ SIGNATURES = {
     "simt_conv_wgrad_multi": (_I, [c_p, _I, _I, _I, _I, c_p]),
     "simt_conv_wgrad_tile_co": (_I, [C.POINTER(WgradDesc)]),
     "simt_wgrad_reduce_multi": (_I, [c_p, _I, _I, c_p]),
+    "simt_wgrad_reduce_blocks": (_I, [_I, _I, _I]),
     "simt_pack_weight": (_I, [c_p, c_p, _I, _I, _I, _I, _I, _L, _I, _I, c_p, _I, c_p]),
     "simt_pack_weight_multi": (_I, [c_p, c_p, _I, _I, c_p]),
     "simt_bn_fold": (_I, [c_p, c_p, c_p, c_p, f32, c_p, c_p, _I, c_p]),

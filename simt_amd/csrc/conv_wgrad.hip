@@ -198,12 +198,50 @@ __global__ void wgrad_reduce_kernel(const float* slab, float* dst, int nsplit, i
   long d = ((long)co * Cin + ci) * RS + t;
   dst[d] = accumulate ? dst[d] + s : s;
 }
+// 3x3 (RS = 9): one thread owns FOUR input channels x all nine taps of one output channel -- nine coalesced 16-byte slab reads per split
+// and 36 CONSECUTIVE floats of the OIHW gradient (nine 16-byte stores) instead of four 4-byte stores 36 bytes apart per tap.  Per
+// element the same sum in the same order (split 0, 1, ...).
+__device__ __forceinline__ void wgrad_reduce9_body(const float* __restrict__ slab, float* __restrict__ dst, int nsplit, int Cd, int Ktot, int Cin,
+                                                    int co_off, int tap_off, int accumulate, long idx) {
+  const int c4 = Cin >> 2;
+  const int ci = (int)(idx % c4) << 2;
+  const int co = (int)(idx / c4);
+  const float* p = slab + (long)(co_off + co) * Ktot + (long)tap_off * Cin + ci;
+  const long sstride = (long)Cd * Ktot;
+  float4 s[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) s[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < nsplit; ++k) {
+    float4 v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = *(const float4*)(p + k * sstride + (long)t * Cin);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { s[t].x += v[t].x; s[t].y += v[t].y; s[t].z += v[t].z; s[t].w += v[t].w; }
+  }
+  // out[c * 9 + t] = s[t].{c}: 36 consecutive floats starting at ((co * Cin + ci) * 9)
+  float o[36];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { o[t] = s[t].x; o[9 + t] = s[t].y; o[18 + t] = s[t].z; o[27 + t] = s[t].w; }
+  float4* q = (float4*)(dst + ((long)co * Cin + ci) * 9);       // 16-byte aligned: (co * Cin + ci) % 4 == 0
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    float4 w = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+    if (accumulate) { const float4 old = q[j]; w.x += old.x; w.y += old.y; w.z += old.z; w.w += old.w; }
+    q[j] = w;
+  }
+}
+// threads a reduce needs (four elements each; 3x3: 36 each)
+__device__ __forceinline__ long wgrad_reduce_threads_d(int Cout, int RS, int Cin) { return RS == 9 ? (long)Cout * (Cin / 4) : (long)Cout * RS * (Cin / 4); }
+static inline long wgrad_reduce_threads(int Cout, int RS, int Cin) { return RS == 9 ? (long)Cout * (Cin / 4) : (long)Cout * RS * (Cin / 4); }
+extern "C" int simt_wgrad_reduce_blocks(int Cout, int RS, int Cin) { return (int)((wgrad_reduce_threads(Cout, RS, Cin) + 255) / 256); }
+
 // Same sums, same order (split 0, 1, ... per element), four consecutive ci per thread: 16-byte slab reads instead of 4-byte ones
 // (the scalar kernel reached ~2 TB/s on 32 MB of slabs).  Needs Cin % 4 == 0 and 16-byte aligned slab rows (Ktot % 4 == 0).
 __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* slab, float* dst, int nsplit, int Cd, int Ktot, int Cin,
                                                             int co_off, int tap_off, int Cout, int RS, int accumulate, long total4) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total4) return;
+  if (RS == 9) { wgrad_reduce9_body(slab, dst, nsplit, Cd, Ktot, Cin, co_off, tap_off, accumulate, idx); return; }
   const int c4 = Cin >> 2;
   int ci = (int)(idx % c4) << 2;
   long r = idx / c4;
@@ -238,7 +276,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_multi_kernel(const simt_wgr
   const int Cin = a.Cin, RS = a.RS, Ktot = a.Ktot, nsplit = a.nsplit;
   const long idx = (long)((int)blockIdx.x - a.block0) * 256 + threadIdx.x;
   const int c4 = Cin >> 2;
-  if (idx >= (long)a.Cout * RS * c4) return;
+  if (idx >= wgrad_reduce_threads_d(a.Cout, RS, Cin)) return;
+  if (RS == 9) { wgrad_reduce9_body(a.slab, a.dst, nsplit, a.Cd, Ktot, Cin, a.co_off, a.tap_off, a.accumulate, idx); return; }
   const int ci = (int)(idx % c4) << 2;
   const long r = idx / c4;
   const int t = (int)(r % RS);
@@ -322,7 +361,7 @@ extern "C" int simt_wgrad_reduce(const float* slab, float* dst, int nsplit, int 
   SIMT_CHECK(slab && dst && nsplit >= 1);
   long total = (long)Cout * RS * Cin;
   if (Cin % 4 == 0 && Ktot % 4 == 0 && ((uintptr_t)slab & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
-    const long total4 = total / 4;
+    const long total4 = wgrad_reduce_threads(Cout, RS, Cin);
     hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slab, dst, nsplit,
                        Cd, Ktot, Cin, co_off, tap_off, Cout, RS, accumulate, total4);
     SIMT_LAUNCH_CHECK();

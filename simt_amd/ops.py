@@ -214,7 +214,7 @@ def wgrad_reduce_multi_table(jobs, device):
         a.nsplit, a.Cd, a.Ktot, a.Cin = j["nsplit"], j["Cd"], j["Ktot"], j["Cin"]
         a.co_off, a.tap_off, a.Cout, a.RS = j["co_off"], j["tap_off"], j["Cout"], j["RS"]
         a.accumulate, a.block0 = int(j.get("accumulate", False)), blocks
-        blocks += -(-(j["Cout"] * j["RS"] * j["Cin"] // 4) // 256)
+        blocks += L.load().simt_wgrad_reduce_blocks(j["Cout"], j["RS"], j["Cin"])
     t = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
     return t, len(jobs), blocks
 
