@@ -154,3 +154,24 @@ def test_one_instruction_exp_error_bound():
     assert err.max() < 2.0 ** -24          # half an ulp of 1.0f
     rel = err[x > -20] / np.exp(x[x > -20].astype(np.float64))
     assert rel.max() < 2.5e-6              # and the gradient terms q_j keep six digits down to e^-20
+
+
+def test_wgrad_tile_rule_matches_header():
+    """The planner's copy of the weight-gradient tile rule (ops.wgrad_tile_co / WGRAD3_MIN_PIXELS) and the library's
+    (include/simt_hip.h SIMT_WGRAD3_MIN_PIXELS, simt_conv_wgrad_tile_co) must agree: the split count that fills the chip depends on it."""
+    import re
+    from simt_amd import _lib, ops
+    hdr = open(os.path.join(ROOT, "include", "simt_hip.h")).read()
+    m = re.search(r"#define\s+SIMT_WGRAD3_MIN_PIXELS\s+(\d+)", hdr)
+    assert m and int(m.group(1)) == ops.WGRAD3_MIN_PIXELS
+    m = re.search(r"#define\s+SIMT_WGRAD_MULTI_MAX\s+(\d+)", hdr)
+    assert m and int(m.group(1)) == 16
+    lib = _lib.load()
+    for (M, Cd, cin, ntaps) in ((37636, 256, 256, 9), (37636, 1024, 256, 1), (37636, 128, 512, 1), (8192, 256, 256, 9), (16384, 512, 64, 1),
+                                (40000, 432, 2048, 1)):
+        d = _lib.WgradDesc()
+        d.B, d.Ho, d.Wo, d.H, d.W = 1, 1, M, 1, M
+        d.Cd, d.Cin, d.ntaps, d.stride, d.dtype = Cd, cin, ntaps, 1, 1
+        assert lib.simt_conv_wgrad_tile_co(C.byref(d)) == ops.wgrad_tile_co(M, Cd, ntaps * cin), (M, Cd, cin, ntaps)
+    # a grouped launch's split count: whole 256-CU rounds
+    assert ops.wgrad_group_nsplit(37636, 51) == 5 and ops.wgrad_group_nsplit(37636, 34) == 7
