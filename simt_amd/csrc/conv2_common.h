@@ -21,7 +21,6 @@ struct Conv2KArgs {
   const char* zero;
   int H, W, Ho, Wo, Cout, Nstore, ldy, ldr, stride, ntaps, relu, M;
   int kc_per_tap, pix_bytes, wrow_bytes, ldm;
-  int chunk_major;                     // K-stage order: 0 = (tap, 64-channel chunk) as packed; 1 = (chunk, tap): the nine taps of a chunk back to back
   int ntiles_n, ntiles_m;
   int out_f32;     // 1: y is fp32 and is stored straight from the accumulators (no bias/residual/ReLU/stats)
   int rows;        // pixels per tile (<= BM)

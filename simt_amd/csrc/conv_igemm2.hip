@@ -220,21 +220,14 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
       const char* src = ok ? a.x + (unsigned)(a_off[i] + (unsigned)toff) : zsrc;
       __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sbase + (i * NT + wave * 64) * 16), 16, 0, 0);
     }
-    // weights are packed K-contiguous as (tap, channel): the stage's 64 columns start at (tap * chunks + chunk) * 128 bytes
-    const unsigned wk = a.chunk_major ? (unsigned)(ld_tap * a.kc_per_tap + ld_kc) * 128u : (unsigned)ld_kt * 128u;
+    const unsigned wk = (unsigned)ld_kt * 128u;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       if (MODE == 5) break;                             // timing ablation: no weight pieces
       __builtin_amdgcn_global_load_lds(GPTR(a.w + (b_off[i] + wk)), LPTR(sbase + A_BYTES + (i * NT + wave * 64) * 16), 16, 0, 0);
     }
     ++ld_kt;
-    if (a.chunk_major) {
-      // (chunk, tap): a pixel row's 128-byte line is read by all taps in consecutive stages -- an L2 reuse distance of one stage of the
-      // XCD's workgroups (~0.7 MB) instead of kc_per_tap stages (~2.8 MB of the 4 MB L2 for Cin = 256, with the weight stream on top)
-      if (++ld_tap == a.ntaps) { ld_tap = 0; ++ld_kc; }
-    } else {
-      if (++ld_kc == a.kc_per_tap) { ld_kc = 0; ++ld_tap; }
-    }
+    if (++ld_kc == a.kc_per_tap) { ld_kc = 0; ++ld_tap; }
   };
   // outstanding vector-memory ops of ONE stage for this wave (the counted wait leaves exactly one stage in flight)
   auto wait_stage = [&](bool more) {
@@ -605,10 +598,6 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
   k.rcp_hw = 1.0f / (float)(d->Ho * d->Wo); k.rcp_wo = 1.0f / (float)d->Wo;
   SIMT_CHECK((long)d->B * d->Ho * d->Wo < (1l << 24));     // fast_divmod range
   k.kc_per_tap = d->Cin * 2 / 128;
-  {
-    static const int km = getenv("SIMT_CONV_KORDER") ? atoi(getenv("SIMT_CONV_KORDER")) : 1;      // 0: (tap, chunk) order (A/B)
-    k.chunk_major = (km != 0 && d->ntaps > 1 && k.kc_per_tap > 1) ? 1 : 0;
-  }
   k.pix_bytes = d->Cin * 2;
   k.wrow_bytes = d->ntaps * d->Cin * 2;
   const Conv2Variant v = pick_variant(d);
