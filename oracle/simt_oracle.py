@@ -447,7 +447,7 @@ class OracleTrainer:
         self.bufs = {}
         self.first = True
 
-    def step(self, image, label, it):
+    def step(self, image, label, it, apply=True):
         """image / label: one micro-batch, or lists of hp.iter_size micro-batches (gradient accumulation,
         trainV2_simt.py:341-432: the W loop and zero_grad run once, every sub-iteration re-evaluates T, runs both nets,
         back-propagates loss / iter_size, and the optimisers step once)."""
@@ -476,6 +476,27 @@ class OracleTrainer:
             W2 = sig_w_forward(self.w[1])
             out = simt_losses(x1, x2, f2, label, T1, T2, W1, W2, hp, size)
             out["total"].backward()                   # simt_losses already divides by hp.iter_size (:427)
+        if apply:
+            self.apply_update(it)
+        return out
+
+    def applied_grads(self):
+        """The gradient tensors the optimisers consume (:434-436): name -> .grad of every parameter listed in the SGD groups that
+        received one, plus "NTM1" / "NTM2" (which carry the inner loop's leak, quirk 3).  Data parallelism averages
+        exactly these over the ranks; conv1 / layer1 / layer2 gradients are computed but never applied and stay rank-local."""
+        out = {}
+        for g in self.groups:
+            for n in g["names"]:
+                if self.st[n].grad is not None:
+                    out[n] = self.st[n].grad
+        out["NTM1"], out["NTM2"] = self.ntm[0].grad, self.ntm[1].grad
+        return out
+
+    def apply_update(self, it):
+        """optimizer.step() + optimizer_t1/t2.step() (:434-436) on whatever .grad currently holds."""
+        hp = self.hp
+        lr = lr_poly(hp.lr, it, hp.num_steps, hp.power)
+        lr_T = lr_poly(hp.lr_T, it, hp.num_steps, hp.power)
         with torch.no_grad():
             for g in self.groups:
                 ps, gs, bs, ms = [], [], [], []
@@ -492,7 +513,24 @@ class OracleTrainer:
                 s = self.tstate[k]
                 s["step"] += 1
                 adam_step_(self.ntm[k], self.ntm[k].grad, s["m"], s["v"], s["step"], lr_T)
-        return out
+
+
+def oracle_dp_step(replicas, images, labels, it):
+    """One data-parallel iteration of the SimT stage as SURVEY 8e defines it (the reference has no DP: `--gpu` is parsed and
+    ignored, trainV2_simt.py:151,246): every rank runs trainV2_simt.py:308-432 on ITS micro-batch (per-rank BN statistics, anchors,
+    CE means, W inner loop -- the latter replica-deterministic), the gradients the optimisers apply are replaced by their MEAN over
+    the ranks (NTM gradients including the rank-identical inner-loop leak: averaged, not summed), then every rank runs :434-436.
+    replicas: OracleTrainer per rank, holding identical state.  Returns the per-rank loss dicts."""
+    outs = [r.step(im, lb, it, apply=False) for r, im, lb in zip(replicas, images, labels)]
+    grads = [r.applied_grads() for r in replicas]
+    with torch.no_grad():
+        for n in grads[0]:
+            mean = sum(g[n] for g in grads) / len(grads)
+            for g in grads:
+                g[n].copy_(mean)
+    for r in replicas:
+        r.apply_update(it)
+    return outs
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -101,6 +101,42 @@ def restore(state, path, not_restore_last=False, strip_prefix=0, required=False)
     return n
 
 
+def save_atomic(obj, path):
+    """torch.save to a temporary name, then os.replace: a crash or a full disk during the save leaves the previous file intact."""
+    tmp = path + ".tmp"
+    torch.save(obj, tmp)
+    os.replace(tmp, path)
+
+
+class SnapshotKeeper:
+    """The snapshot rotation of trainV2_simt.py:452-464 / trainV1_warmup.py:243-256: after an evaluation keep ONE file
+    `<stem><iter>_mIoU<mIoU>.pth` for the best mIoU so far; without a validation set (the reference hard-codes one) keep ONE rolling
+    periodic file `<stem><iter>.pth`.  The new file is complete on disk (save_atomic) BEFORE the old one is removed."""
+
+    def __init__(self, snapshot_dir, stem):
+        self.dir, self.stem = snapshot_dir, stem
+        self.best_mIoU, self.best_iter, self.rolling_iter = 0, 0, None
+
+    def best(self, state_dict, i_iter, mIoU):
+        if not mIoU > self.best_mIoU:
+            return False
+        old_file = osp.join(self.dir, self.stem + str(self.best_iter) + "_mIoU" + str(self.best_mIoU) + ".pth")
+        print("Saving model with mIoU: ", mIoU)
+        save_atomic(state_dict, osp.join(self.dir, self.stem + str(i_iter) + "_mIoU" + str(mIoU) + ".pth"))
+        if os.path.exists(old_file):
+            os.remove(old_file)
+        self.best_mIoU, self.best_iter = mIoU, i_iter
+        return True
+
+    def rolling(self, state_dict, i_iter):
+        save_atomic(state_dict, osp.join(self.dir, self.stem + str(i_iter) + ".pth"))
+        if self.rolling_iter is not None and self.rolling_iter != i_iter:
+            old_file = osp.join(self.dir, self.stem + str(self.rolling_iter) + ".pth")
+            if os.path.exists(old_file):
+                os.remove(old_file)
+        self.rolling_iter = i_iter
+
+
 def batches(args, B, H, W, cd, rank, world, dev):
     """-> iterator of (image f32 [B,3,H,W], label i64 [B,H,W]) resident on the device."""
     if args.synthetic:
@@ -154,7 +190,7 @@ def main(argv=None):
               f"{h}x{w}, {args.compute_dtype}, K={K}")
         os.makedirs(args.snapshot_dir, exist_ok=True)
     data = batches(args, args.batch_size, h, w, cd, rank, world, dev)
-    evaluator, best_mIoU, best_iter = None, 0, 0
+    evaluator, keeper = None, SnapshotKeeper(args.snapshot_dir, "GTA5_iter")
     t0 = time.time()
     for i_iter in range(args.num_steps):
         mb = [next(data) for _ in range(args.iter_size)]           # gradient accumulation: iter_size micro-batches per step
@@ -170,7 +206,7 @@ def main(argv=None):
         if i_iter >= args.num_steps_stop - 1:
             if rank == 0:
                 print("save model ...")
-                torch.save(tr.state_dict(), osp.join(args.snapshot_dir, "GTA5_" + str(args.num_steps_stop) + ".pth"))   # :447-450
+                save_atomic(tr.state_dict(), osp.join(args.snapshot_dir, "GTA5_" + str(args.num_steps_stop) + ".pth"))   # :447-450
             break
         if i_iter % args.save_pred_every == 0 and i_iter != 0 and args.data_dir_val:
             # :452-464: evaluate, keep only the best-mIoU snapshot
@@ -183,21 +219,11 @@ def main(argv=None):
                                  open_classes=K, device=dev, dtype=dtype, evaluator=evaluator, rank=rank, world=world, process_group=pg)
             if rank == 0:
                 print("Finish Evaluation: " + time.asctime(time.localtime(time.time())))
-                if mIoU > best_mIoU:
-                    old_file = osp.join(args.snapshot_dir, "GTA5_iter" + str(best_iter) + "_mIoU" + str(best_mIoU) + ".pth")
-                    if os.path.exists(old_file):
-                        os.remove(old_file)
-                    print("Saving model with mIoU: ", mIoU)
-                    torch.save(tr.state_dict(), osp.join(args.snapshot_dir, "GTA5_iter" + str(i_iter) + "_mIoU" + str(mIoU) + ".pth"))
-                    best_mIoU, best_iter = mIoU, i_iter
+                keeper.best(tr.state_dict(), i_iter, mIoU)
         elif i_iter % args.save_pred_every == 0 and i_iter != 0 and rank == 0:
             # no validation set given (the reference hard-codes one, :452-464): without an evaluation there is no best-mIoU snapshot,
             # so keep a rolling periodic one -- a crash must not lose the run
-            old_file = osp.join(args.snapshot_dir, "GTA5_iter" + str(best_iter) + ".pth")
-            if best_iter and os.path.exists(old_file):
-                os.remove(old_file)
-            torch.save(tr.state_dict(), osp.join(args.snapshot_dir, "GTA5_iter" + str(i_iter) + ".pth"))
-            best_iter = i_iter
+            keeper.rolling(tr.state_dict(), i_iter)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

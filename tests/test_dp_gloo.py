@@ -73,3 +73,108 @@ def test_bucket_reducer_mean_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# DP SEMANTICS against the oracle (VERDICT r3 missing #2; north_star "DP scaling with loss parity to reference"): every rank runs
+# trainV2_simt.py:308-432 on its micro-batch, the applied gradients (incl. NTM1 / NTM2 with the inner-loop leak) are averaged,
+# every rank runs :434-436.  Here on CPU: two gloo ranks each hold an OracleTrainer, lay their applied gradients out in ONE flat
+# buffer (like TrunkPlan.flat_grad), exchange it through the product's BucketReducer, step -- and must land on the parameters of
+# `oracle_dp_step` (both ranks' oracle gradients averaged in one process).
+# ----------------------------------------------------------------------------------------------------------------------
+DP_LAYERS, DP_K = (1, 1, 2, 1), 3
+
+
+def _dp_case():
+    from oracle import simt_oracle as so
+    cd = so.load_class_dist()
+    st = so.recipe_state(so.state_shapes(19, DP_K, True, layers=DP_LAYERS), seed=11, head_scale=8.0)
+    fst = so.recipe_state(so.state_shapes(19, 0, False, layers=DP_LAYERS), seed=12, head_scale=8.0)
+    kw = dict(open_classes=DP_K, lambda_convex=0.1, lambda_volume=1.0, lambda_anchor=1.0, lr=6e-4, lr_T=6e-3)
+    mk = lambda: so.OracleTrainer(st, fst, so.ntm_init(19, DP_K, 1), so.ntm_init(19, DP_K, 2), so.Hyper(**kw), cd, layers=DP_LAYERS)
+    batches = [so.synthetic_batch(2, 65, 65, cd.numpy(), seed=100 + 10 * r, block=8) for r in range(2)]
+    return mk, batches
+
+
+def _dp_oracle_worker(rank, world, port, q):
+    from oracle import simt_oracle as so
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mk, batches = _dp_case()
+        orc = mk()
+        out = orc.step(*batches[rank], 0, apply=False)
+        grads = orc.applied_grads()
+        names = [n for n in grads if not n.startswith("NTM")]
+        sizes = {n: grads[n].numel() for n in names}
+        flat = torch.cat([grads[n].flatten() for n in names])
+        extra = torch.stack([grads["NTM1"], grads["NTM2"]]).clone()
+        red = BucketReducer(flat, make_buckets(names, sizes, {n: i for i, n in enumerate(names)}, bucket_elems=1 << 16),
+                            group=dist.group.WORLD, extra=[extra])
+        red.start()
+        red.ready_upto(len(names) // 2)
+        red.finish()
+        off = 0
+        with torch.no_grad():
+            for n in names:
+                grads[n].copy_(flat[off:off + sizes[n]].view_as(grads[n]))
+                off += sizes[n]
+            grads["NTM1"].copy_(extra[0])
+            grads["NTM2"].copy_(extra[1])
+        orc.apply_update(0)
+        res = {n: orc.st[n].detach().clone() for n in names}
+        res["NTM1"], res["NTM2"] = orc.ntm[0].detach().clone(), orc.ntm[1].detach().clone()
+        res["W1"] = orc.w[0].detach().clone()
+        q.put((rank, {k: v.numpy() for k, v in res.items()}, {k: float(out[k].detach()) for k in ("total", "loss_y2", "anchor")}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_step_equals_oracle_on_mean_gradients_world2():
+    from oracle import simt_oracle as so
+    import numpy as np
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_oracle_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    mk, batches = _dp_case()
+    reps = [mk(), mk()]
+    solo = mk()
+    outs = so.oracle_dp_step(reps, [b[0] for b in batches], [b[1] for b in batches], 0)
+    solo.step(*batches[0], 0)
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, params, losses in res:
+        for k, v in losses.items():                    # per-rank losses are the rank's own micro-batch's
+            assert abs(v - float(outs[rank][k].detach())) <= 1e-6 * (1 + abs(v)), (rank, k)
+        for n, v in params.items():
+            ref = {"NTM1": reps[rank].ntm[0], "NTM2": reps[rank].ntm[1], "W1": reps[rank].w[0]}.get(n)
+            ref = (ref if ref is not None else reps[rank].st[n]).detach().numpy()
+            assert np.allclose(v, ref, rtol=1e-6, atol=1e-7), (rank, n, np.abs(v - ref).max())
+    # the replicas agree with each other and DIFFER from a single-rank step on rank 0's micro-batch (the mean is not a no-op)
+    for n in res[0][1]:
+        assert np.array_equal(res[0][1][n], res[1][1][n]), n
+    n = "layer6.conv2d_list.0.weight"
+    assert not np.allclose(res[0][1][n], solo.st[n].detach().numpy(), rtol=1e-6, atol=1e-9)
+    # the NTM gradient's inner-loop leak (quirk 3, trainV2_simt.py:326-339) is rank-identical: the exchanged mean must carry it ONCE
+    # (a SUM over the ranks would carry it twice): mean - leak == mean over ranks of the loss-only part, and the leak is not small
+    leak = mk()
+    so.inner_w_loop(leak.ntm[0], leak.ntm[1], leak.w[0], leak.w[1], leak.wstate, leak.cd, leak.hp,
+                    so.lr_poly(6e-3, 0, leak.hp.num_steps, leak.hp.power))
+    singles = [mk(), mk()]
+    for r, b in zip(singles, batches):
+        r.step(*b, 0, apply=False)
+    for k in range(2):
+        lk = leak.ntm[k].grad
+        loss_only = sum(r.ntm[k].grad - lk for r in singles) / 2
+        assert lk.abs().max() > 1e-3
+        assert torch.allclose(reps[0].ntm[k].grad, lk + loss_only, rtol=1e-5, atol=1e-7)

@@ -60,6 +60,43 @@ def test_train_tool_real_files_eval_and_snapshots(dev, tmp_path, capsys):
     assert all(torch.isfinite(v).all() for k, v in sd.items() if v.dtype.is_floating_point)
 
 
+def test_warmup_tool_real_files_eval_and_snapshots(dev, tmp_path, capsys):
+    """The warm-up twin (trainV1_warmup.py:156-256): real files, `evaluate_warmup` every --save-pred-every iterations, the best-mIoU
+    rotation with the reference's file names (`GTA5_BAPA_warmup_iter<i>_mIoU<m>.pth`, :249-254), the final `GTA5_<stop>.pth` (:236-239),
+    and a reference-style command line that spells out flags the reference parses and never reads."""
+    Image = pytest.importorskip("PIL.Image")
+    from simt_amd.tools import trainV1_warmup as tool
+    _make_dataset(tmp_path, Image)
+    snap = str(tmp_path / "snap")
+    argv = ["--model", "DeepLab", "--target", "cityscapes", "--data-dir", "/nonexistent", "--data-list", "x.txt", "--ignore-label", "255",
+            "--input-size", "1024,512", "--set", "train", "--not-restore-last", "--open-classes", "15", "--learning-rate-T", "2.5e-4",
+            "--data-dir-target", str(tmp_path), "--data-list-target", str(tmp_path / "pseudo.lst"), "--input-size-target", "129,65",
+            "--batch-size", "2", "--num-steps", "50", "--num-steps-stop", "6", "--save-pred-every", "2", "--print-every", "1",
+            "--learning-rate", "2.5e-4", "--from-scratch", "--restore-from", "", "--snapshot-dir", snap,
+            "--data-dir-val", str(tmp_path), "--data-list-val", str(tmp_path / "kit" / "val.txt"),
+            "--gt-dir-val", str(tmp_path / "gt"), "--devkit-dir", str(tmp_path / "kit"), "--num-workers", "2", "--random-mirror"]
+    tool.main(argv)
+    out = capsys.readouterr().out
+    assert out.count("Begin evaluation") == 2 and out.count("===> mIoU:") == 2             # iterations 2 and 4 (5 is the stop: save + break)
+    assert "iter =        5/" in out and "loss_seg1" in out and "save model" in out
+    final = os.path.join(snap, "GTA5_6.pth")
+    assert os.path.exists(final)
+    sd = torch.load(final)
+    assert int(sd["bn1.num_batches_tracked"]) == 6 and sd["layer6.conv2d_list.0.weight"].shape[0] == 19
+    assert not any(k.startswith(("layer5_1", "layer6_1")) for k in sd)                    # DeeplabMulti(num_classes) without open-set heads
+    best = glob.glob(os.path.join(snap, "GTA5_BAPA_warmup_iter*_mIoU*.pth"))
+    assert len(best) == 1                                                                  # rotation: only the best one is kept
+    assert all(torch.isfinite(v).all() for k, v in sd.items() if v.dtype.is_floating_point)
+    # no validation set: a rolling periodic snapshot, one file
+    snap2 = str(tmp_path / "snap2")
+    i = argv.index("--snapshot-dir")
+    argv2 = argv[:i] + ["--snapshot-dir", snap2] + argv[i + 2:]
+    j = argv2.index("--data-dir-val")
+    argv2 = argv2[:j] + argv2[j + 2:]
+    tool.main(argv2)
+    assert sorted(os.listdir(snap2)) == ["GTA5_6.pth", "GTA5_BAPA_warmup_iter4.pth"]
+
+
 def test_train_tool_refuses_missing_data_and_checkpoint(dev, tmp_path):
     from simt_amd.tools import trainV2_simt as tool
     base = ["--input-size-target", "129,65", "--batch-size", "1", "--num-steps-stop", "1", "--snapshot-dir", str(tmp_path / "s")]

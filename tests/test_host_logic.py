@@ -175,3 +175,48 @@ def test_wgrad_tile_rule_matches_header():
         assert lib.simt_conv_wgrad_tile_co(C.byref(d)) == ops.wgrad_tile_co(M, Cd, ntaps * cin), (M, Cd, cin, ntaps)
     # a grouped launch's split count: whole 256-CU rounds
     assert ops.wgrad_group_nsplit(37636, 51) == 5 and ops.wgrad_group_nsplit(37636, 34) == 7
+
+
+@pytest.mark.parametrize("tool", ["trainV2_simt", "trainV1_warmup"])
+def test_cli_accepts_every_reference_flag(tool):
+    """Golden g15 (oracle/gen_golden_flags.py): every flag of the reference's argparse (trainV2_simt.py:72-157, trainV1_warmup.py:60-150)
+    parses with a value of the reference's type -- a reference command line that spells them all out must not die in argparse."""
+    import importlib
+    import json
+    flags = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g15_cli_flags.json")))[tool]
+    mod = importlib.import_module(f"simt_amd.tools.{tool}")
+    argv = []
+    for name, kind in flags:
+        argv.append(name)
+        if kind != "store_true":
+            argv.append({"int": "3", "float": "0.25", "str": "x,y"}[kind])
+    ns = vars(mod.get_arguments(argv))
+    for name, kind in flags:
+        v = ns[name[2:].replace("-", "_")]
+        assert v == {"int": 3, "float": 0.25, "str": "x,y", "store_true": True}[kind], (name, v)
+
+
+def test_snapshot_keeper_rotation_and_atomic_save(tmp_path):
+    """trainV2_simt.py:452-464 / trainV1_warmup.py:243-256: one best-mIoU file with the reference's names; the old file goes only after
+    the new one is complete (a failed save must not leave the run without a snapshot)."""
+    import torch
+    from simt_amd.tools import trainV2_simt as tool
+    k = tool.SnapshotKeeper(str(tmp_path), "GTA5_BAPA_warmup_iter")
+    sd = {"a": torch.zeros(3)}
+    assert k.best(sd, 1000, 31.25) and not k.best(sd, 2000, 30.0) and k.best(sd, 3000, 40.5)
+    assert sorted(os.listdir(tmp_path)) == ["GTA5_BAPA_warmup_iter3000_mIoU40.5.pth"]
+    k.rolling(sd, 4000)
+    k.rolling(sd, 5000)
+    assert sorted(os.listdir(tmp_path)) == ["GTA5_BAPA_warmup_iter3000_mIoU40.5.pth", "GTA5_BAPA_warmup_iter5000.pth"]
+    real_save = torch.save
+
+    def failing(obj, path, *a, **kw):
+        real_save(obj, path, *a, **kw)
+        raise OSError("disk full")
+    torch.save = failing
+    try:
+        with pytest.raises(OSError):
+            k.rolling(sd, 6000)
+    finally:
+        torch.save = real_save
+    assert "GTA5_BAPA_warmup_iter5000.pth" in os.listdir(tmp_path)            # the previous snapshot survived the failed save
