@@ -261,7 +261,8 @@ typedef struct {
   float* ntm_grad[2];
   const float* class_dist;
   const float* hout;    /* from simt_head_loss */
-  float* lout;          /* [16]: total*gscale, loss_p1, loss_p2, loss_y1, loss_y2, Place, Convex, Volume, Anchor, vol_ok */
+  float* lout;          /* [16]: total*gscale, loss_p1, loss_p2, loss_y1, loss_y2, Place, Convex, Volume, Anchor, vol_ok, log-vol x2,
+                           [12] += hout[15] (labels outside [0,C) and != 255, ACCUMULATED until the caller clears it) */
   int32_t Q, C;
   float lambda_seg, lambda_convex, lambda_volume, lambda_anchor, gscale;
   int32_t single;       /* 1: Convex / Volume / Anchor / total over NTM [1] only, no lambda_seg terms */

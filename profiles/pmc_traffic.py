@@ -32,7 +32,7 @@ def load(d, counter):
 
 
 def kernel_name(full):
-    """'void conv_igemm2_kernel<256, 5, 3, 0, 0, 0>(Conv2KArgs)' -> 'void conv_igemm2_kernel<256, 5, 3, 0, 0, 0>': cut at the first '('
+    """'void conv_igemm2_kernel<256, 5, 3>(Conv2KArgs)' -> 'void conv_igemm2_kernel<256, 5, 3>': cut at the first '('
     outside template brackets ('(anonymous namespace)' prefixes and function-pointer template arguments contain parentheses too)."""
     depth = 0
     for i, ch in enumerate(full):

@@ -6,13 +6,17 @@ OUT=../libsimt_hip.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 # -packed-fp32-ops: v_pk_*_f32 cannot issue in the shadow of an MFMA (profiles/microbench/mixbench2.hip: one per MFMA costs +77 %), plain VALU can
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -Xclang -target-feature -Xclang -packed-fp32-ops"
-# ABLATION=1: also compile the timing-ablation / loader-wave experiment instantiations (outputs meaningless; never shipped)
-if [ "${ABLATION:-0}" = "1" ]; then FLAGS="$FLAGS -DSIMT_ABLATION"; fi
-mkdir -p ../_build
+# ABLATION=1: also compile the timing-ablation instantiations and csrc/experiments/*.hip (round-3 experiments on the conv kernel: loader
+# waves, weights-direct, role-split conv_igemm3; outputs of the timing modes are meaningless; never shipped).  OUT=path BUILD=dir: where to.
+SRCS=(*.hip)
+BUILD=${BUILD:-../_build}
+if [ "${ABLATION:-0}" = "1" ]; then FLAGS="$FLAGS -DSIMT_ABLATION"; SRCS+=(experiments/*.hip); BUILD=${BUILD}_abl; OUT=${OUT_ABL:-../libsimt_hip_abl.so}; fi
+mkdir -p $BUILD
 objs=()
 pids=()
-for f in *.hip; do
-  o=../_build/${f%.hip}.o
+for f in "${SRCS[@]}"; do
+  b=$(basename "$f")
+  o=$BUILD/${b%.hip}.o
   objs+=("$o")
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv2_common.h -nt "$o" ] || [ conv2_epilogue.h -nt "$o" ] || [ ../../include/simt_hip.h -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &

@@ -21,8 +21,8 @@
 // L2, 104 KB in flight per CU, the LDS holds no more) is as long as the matrix work, and matrix work beside it slows it further (the
 // chip drops from 2.4 to 2.1 GHz at 1 200 W).  NOT the product path: compiled into -DSIMT_ABLATION builds only, SIMT_IGEMM3=1.
 #ifdef SIMT_ABLATION
-#include "conv2_common.h"
-#include "conv2_epilogue.h"
+#include "../conv2_common.h"
+#include "../conv2_epilogue.h"
 #include <stdlib.h>
 #include <type_traits>
 

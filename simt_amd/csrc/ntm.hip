@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256) void ntm_post_kernel(NtmPostArgs a) {
     float* l = a.lout;
     l[0] = total * a.gscale; l[1] = a.k0 ? 0.f : o[0]; l[2] = o[1]; l[3] = a.k0 ? 0.f : o[4]; l[4] = o[5]; l[5] = place; l[6] = convex; l[7] = vol;
     l[8] = anchor; l[9] = vol_ok ? 1.f : 0.f; l[10] = s_vol[0]; l[11] = s_vol[1];
+    l[12] += o[15];     // out-of-range labels since the host last cleared the slot (every micro-batch of every step counts)
   }
 }
 

@@ -123,7 +123,9 @@ class BucketReducer:
                 h[1].div_(self.world)
             else:
                 h.wait()
-        host = time.perf_counter() - t0 if not self.avg else 0.0      # RCCL: wait() only orders streams; gloo: blocks the host
+        # exposed wait: on CUDA tensors the e0 -> e1 event pair already contains whatever the host blocked for between the two records
+        # (gloo on device tensors), so the host timer counts only for CPU tensors -- never both (double counting)
+        host = time.perf_counter() - t0 if not self.cuda else 0.0
         if self.cuda:
             done = torch.cuda.Event()
             done.record(self.comm)

@@ -223,6 +223,22 @@ class LaunchList:
         return jobs, ch
 
 
+def layout_flat_grads(plan, order):
+    """ONE flat fp32 gradient buffer in backward-completion order (DP buckets are contiguous and become ready in order).  Every
+    entry starts on a 16-byte boundary (its span is padded to a multiple of 4 floats; the pad stays zero): the weight-gradient reduce
+    kernels store `float4` (csrc/conv_wgrad.hip wgrad_reduce4*), and e.g. DeepLabv3's 19 + 6 classifier biases at the head of the
+    buffer would otherwise leave every later gradient 4-byte aligned only.  grad_offsets[name] = (offset, padded span)."""
+    spans = [(plan.p[n].numel() + 3) // 4 * 4 for n in order]
+    plan.flat_grad = torch.zeros(sum(spans), device=plan.dev, dtype=torch.float32)
+    plan.grads, plan.grad_order, plan.grad_offsets = {}, list(order), {}
+    off = 0
+    for n, span in zip(order, spans):
+        plan.grads[n] = plan.flat_grad[off:off + plan.p[n].numel()].view(plan.p[n].shape)
+        plan.grad_offsets[n] = (off, span)
+        assert plan.grads[n].data_ptr() % 16 == 0
+        off += span
+
+
 class TrunkPlan:
     """Forward (train or eval) and backward of ResNetMulti for one fixed input shape.
 
@@ -376,10 +392,10 @@ class TrunkPlan:
         gen = L.load().simt_conv_variant(C.byref(d), C.byref(bn_), C.byref(tm_), C.byref(nst_))
         wd = 0
         if gen == 2 and ops.conv_wants_frag(d):
-            # the wide kernel takes its weight operand straight into registers from a fragment-ordered copy (csrc/conv_igemm2.hip, WD)
+            # -DSIMT_ABLATION builds with SIMT_WDIRECT=1 only: weight operand from a fragment-ordered copy (csrc/experiments/conv_igemm2_abl.hip)
             d.w_frag = self._frag_twin(wp, npad).data_ptr()
             wd = 1
-        tag = (f"conv_igemm2_kernel<{bn_.value}, {tm_.value}, {nst_.value}, 0, 0, {wd}>" if gen == 2 else
+        tag = (f"conv_igemm2_kernel<{bn_.value}, {tm_.value}, {nst_.value}>{' [weights-direct experiment]' if wd else ''}" if gen == 2 else
                "conv1x1_stream_kernel" if gen == 4 else "conv1x1_rows_kernel" if gen == 5 else
                f"conv_igemm_kernel<{tn[x.dtype]}, {tn[y.dtype]}, {tile}>")
         nbytes = (Bn * Hi * Wi * Cin + npad * len(taps) * Cin) * x.element_size() + M * Cout * y.element_size()
@@ -641,15 +657,7 @@ class TrunkPlan:
             blk = by_layer.get(li, [])
             # blocks in reverse order
             order += sorted(blk, key=lambda n: -int(n.split(".")[1]) if li else 0)
-        total = sum(self.p[n].numel() for n in order)
-        self.flat_grad = torch.zeros(total, device=self.dev, dtype=torch.float32)
-        self.grads, self.grad_order, self.grad_offsets = {}, order, {}
-        off = 0
-        for n in order:
-            k = self.p[n].numel()
-            self.grads[n] = self.flat_grad[off:off + k].view(self.p[n].shape)
-            self.grad_offsets[n] = (off, k)
-            off += k
+        layout_flat_grads(self, order)
 
     # ------------------------------------------------------------------ backward construction
     def _wgrad(self, lst, dy, x, gname, *, Bn, Hi, Wi, Cin, Ho, Wo, Cd, ldd, taps, stride, parts, stream=1):
@@ -917,7 +925,10 @@ class TrunkPlan:
                 pend["jobs"] += wjobs
                 pend["pars"].append(par)
                 pend.update(M=Mo, tco=tco_b, blocks=pend["blocks"] + 1)
-                if pend["blocks"] >= nblk_group or first_needed or bi == 0:
+                # ... and at every layer boundary (block 0 of a layer is the last one the backward reaches): a group must not straddle the
+                # applied / unapplied line (layer3.0 with layer2's blocks at small crops), or the last APPLIED gradient -- the early
+                # optimiser step and the final DP bucket wait for it -- would become final up to two blocks late
+                if pend["blocks"] >= nblk_group or first_needed or bi == sum(self.layers[:li - 1]):
                     flush_wgrads()
             else:
                 for j in wjobs[2:]:

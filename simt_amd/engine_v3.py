@@ -19,7 +19,7 @@ transposed operand.
 import torch
 
 from . import ops
-from .engine import TrunkPlan
+from .engine import TrunkPlan, layout_flat_grads
 
 R50 = "resnet.resnet_50."
 
@@ -256,15 +256,7 @@ class V3Plan(TrunkPlan):
 
     def _alloc_grads(self, grad_names=None):
         order = list(reversed(self.grad_param_names()))         # reverse-topological: DP buckets become ready in order
-        total = sum(self.p[n].numel() for n in order)
-        self.flat_grad = torch.zeros(total, device=self.dev, dtype=torch.float32)
-        self.grads, self.grad_order, self.grad_offsets = {}, order, {}
-        off = 0
-        for n in order:
-            k = self.p[n].numel()
-            self.grads[n] = self.flat_grad[off:off + k].view(self.p[n].shape)
-            self.grad_offsets[n] = (off, k)
-            off += k
+        layout_flat_grads(self, order)
 
     # ------------------------------------------------------------------ backward
     def _bnb(self, b, *, dz, y, bname, dy, M, Cn, mask_mode, **kw):

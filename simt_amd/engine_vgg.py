@@ -10,7 +10,7 @@ mask of the producing layer in the dgrad epilogue (simt_conv_desc.mask) or insid
 import torch
 
 from . import ops
-from .engine import HeadCfg, TrunkPlan
+from .engine import HeadCfg, TrunkPlan, layout_flat_grads
 
 # (features index, cin, cout, dilation, pool_after)
 VGG_LAYERS = [(0, 3, 64, 1, False), (2, 64, 64, 1, True), (5, 64, 128, 1, False), (7, 128, 128, 1, True),
@@ -98,15 +98,7 @@ class VggPlan(TrunkPlan):
         order = [f"classifier.conv2d_list.{i}.{k}" for i in range(len(self.heads[0].dilations)) for k in ("weight", "bias")]
         for (idx, *_r) in reversed(self.vgg_layers):
             order += [f"features.{idx}.weight", f"features.{idx}.bias"]
-        total = sum(self.p[n].numel() for n in order)
-        self.flat_grad = torch.zeros(total, device=self.dev, dtype=torch.float32)
-        self.grads, self.grad_order, self.grad_offsets = {}, order, {}
-        off = 0
-        for n in order:
-            k = self.p[n].numel()
-            self.grads[n] = self.flat_grad[off:off + k].view(self.p[n].shape)
-            self.grad_offsets[n] = (off, k)
-            off += k
+        layout_flat_grads(self, order)
 
     # ------------------------------------------------------------------ backward
     def _build_backward(self):

@@ -210,6 +210,9 @@ def wgrad_reduce_multi_table(jobs, device):
     blocks = 0
     for a, j in zip(arr, jobs):
         assert j["Cin"] % 4 == 0 and j["Ktot"] % 4 == 0
+        # the kernel loads / stores float4 (include/simt_hip.h: 16-byte aligned slab and dst); simt_wgrad_reduce has a scalar fallback,
+        # the table form does not -- engine.layout_flat_grads keeps every gradient on a 16-byte boundary
+        assert j["slab"].data_ptr() % 16 == 0 and j["dst"].data_ptr() % 16 == 0, "simt_wgrad_reduce_multi needs 16-byte aligned slab / dst"
         a.slab, a.dst = _p(j["slab"]), _p(j["dst"])
         a.nsplit, a.Cd, a.Ktot, a.Cin = j["nsplit"], j["Cd"], j["Ktot"], j["Cin"]
         a.co_off, a.tap_off, a.Cout, a.RS = j["co_off"], j["tap_off"], j["Cout"], j["RS"]

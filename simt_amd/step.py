@@ -471,8 +471,15 @@ class SimTTrainer:
 
     def losses(self):
         """Host copy of the scalars of the last step (synchronises)."""
-        v = self.lout.cpu().tolist()
-        bad = int(self.hout[15].item())
+        v = self.lout.cpu().tolist()                  # ONE device-to-host copy: the scalars and the bad-label count (lout[12])
+        bad = int(v[12])                               # accumulated by simt_ntm_post over every micro-batch since the last call
+        if bad:
+            self.lout[12] = 0.0
+        if self.pg is not None:                        # data parallel: every rank calls losses() and every rank raises (a rank that
+            import torch.distributed as dist           # raised alone would leave the others blocked in the next all-reduce)
+            flag = torch.tensor([float(bad)], device=self.dev if dist.get_backend(self.pg) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.pg)
+            bad = int(flag.item())
         if bad:          # utils/loss.py:36 / nn.CrossEntropyLoss raise on such a target; the kernels skip the pixel and count it
             raise ValueError(f"{bad} label value(s) outside [0, {self.hp.num_classes}) that are not the ignore value 255")
         keys = ["total", "loss_p1", "loss_p2", "loss_y1", "loss_y2", "place", "convex", "volume", "anchor", "vol_ok"]
@@ -578,7 +585,13 @@ class WarmupTrainer:
 
     def losses(self):
         v = self.hout[:16].cpu().tolist()
-        if int(v[15]):   # nn.CrossEntropyLoss(ignore_index=255) raises on such a target (trainV1_warmup.py:217-224)
-            raise ValueError(f"{int(v[15])} label value(s) outside [0, {self.hp.num_classes}) that are not the ignore value 255")
+        bad = int(v[15])
+        if self.pg is not None:                        # data parallel: every rank calls losses(), every rank raises
+            import torch.distributed as dist
+            flag = torch.tensor([float(bad)], device=self.dev if dist.get_backend(self.pg) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.pg)
+            bad = int(flag.item())
+        if bad:          # nn.CrossEntropyLoss(ignore_index=255) raises on such a target (trainV1_warmup.py:217-224)
+            raise ValueError(f"{bad} label value(s) outside [0, {self.hp.num_classes}) that are not the ignore value 255")
         # `loss = loss / args.iter_size` (trainV1_warmup.py:227): the reported total is the scaled one, like SimTTrainer's
         return {"total": v[14] / self.hp.iter_size, "loss_seg1": v[0], "loss_seg2": v[1]}

@@ -218,8 +218,15 @@ class SimTSingleTrainer:
         return [self._fix_fwd, self._fwd, self._bwd]
 
     def losses(self):
-        v = self.lout.cpu().tolist()
-        bad = int(self.hout[15].item())
+        v = self.lout.cpu().tolist()                  # ONE device-to-host copy: the scalars and the bad-label count (lout[12])
+        bad = int(v[12])                               # accumulated by simt_ntm_post over every micro-batch since the last call
+        if bad:
+            self.lout[12] = 0.0
+        if self.pg is not None:                        # data parallel: every rank calls losses() and every rank raises (a rank that
+            import torch.distributed as dist           # raised alone would leave the others blocked in the next all-reduce)
+            flag = torch.tensor([float(bad)], device=self.dev if dist.get_backend(self.pg) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.pg)
+            bad = int(flag.item())
         if bad:          # the reference's nll_loss raises on such a target; the kernels skip the pixel and count it
             raise ValueError(f"{bad} label value(s) outside [0, {self.hp.num_classes}) that are not the ignore value 255")
         return {"total": v[0], "loss_p": v[2], "loss_y": v[4], "place": v[5], "convex": v[6], "volume": v[7], "anchor": v[8],

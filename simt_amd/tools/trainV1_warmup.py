@@ -105,11 +105,12 @@ def main(argv=None):
         mb = [next(data) for _ in range(args.iter_size)]             # gradient accumulation: iter_size micro-batches per step
         img, lab = ([m[0] for m in mb], [m[1] for m in mb]) if args.iter_size > 1 else mb[0]
         tr.step(img, lab, i_iter)
-        if i_iter % args.print_every == 0 and rank == 0:              # :231-234 (every 100 iterations there)
-            l = tr.losses()
-            print("iter = {0:8d}/{1:8d}, loss_seg1 = {2:.3f} loss_seg2 = {3:.3f}  lr = {4:.2e}  ({5:.1f} img/s)".format(
-                i_iter, args.num_steps, l["loss_seg1"], l["loss_seg2"], lr_poly(args.learning_rate, i_iter, args.num_steps, args.power),
-                args.batch_size * world * (i_iter + 1) / max(time.time() - t0, 1e-9)))
+        if i_iter % args.print_every == 0:              # :231-234 (every 100 iterations there)
+            l = tr.losses()                        # every rank (DP: a bad-label error is raised on all of them together)
+            if rank == 0:
+                print("iter = {0:8d}/{1:8d}, loss_seg1 = {2:.3f} loss_seg2 = {3:.3f}  lr = {4:.2e}  ({5:.1f} img/s)".format(
+                    i_iter, args.num_steps, l["loss_seg1"], l["loss_seg2"], lr_poly(args.learning_rate, i_iter, args.num_steps, args.power),
+                    args.batch_size * world * (i_iter + 1) / max(time.time() - t0, 1e-9)))
         if i_iter >= args.num_steps_stop - 1:                         # :236-239
             if rank == 0:
                 print("save model ...")

@@ -196,13 +196,14 @@ def main(argv=None):
         mb = [next(data) for _ in range(args.iter_size)]           # gradient accumulation: iter_size micro-batches per step
         img, lab = ([m[0] for m in mb], [m[1] for m in mb]) if args.iter_size > 1 else mb[0]
         tr.step(img, lab, i_iter)
-        if i_iter % args.print_every == 0 and rank == 0:
-            l = tr.losses()
-            print("iter = {0:8d}/{1:8d}, loss_seg_p = {2:.3f} loss_seg_y = {3:.3f} Convex = {4:.3f} Volume = {5:.3f} "
-                  "Anchor = {6:.3f} Place_loss = {7:.3f}  lr = {8:.2e}  ({9:.1f} img/s)".format(
-                      i_iter, args.num_steps, l["loss_p1"] + l["loss_p2"], l["loss_y1"] + l["loss_y2"], l["convex"], l["volume"],
-                      l["anchor"], l["place"], lr_poly(args.learning_rate, i_iter, args.num_steps, args.power),
-                      args.batch_size * world * (i_iter + 1) / max(time.time() - t0, 1e-9)))               # :438-441 (p1+p2, y1+y2)
+        if i_iter % args.print_every == 0:
+            l = tr.losses()                        # every rank (DP: a bad-label error is raised on all of them together)
+            if rank == 0:
+                print("iter = {0:8d}/{1:8d}, loss_seg_p = {2:.3f} loss_seg_y = {3:.3f} Convex = {4:.3f} Volume = {5:.3f} "
+                      "Anchor = {6:.3f} Place_loss = {7:.3f}  lr = {8:.2e}  ({9:.1f} img/s)".format(
+                          i_iter, args.num_steps, l["loss_p1"] + l["loss_p2"], l["loss_y1"] + l["loss_y2"], l["convex"], l["volume"],
+                          l["anchor"], l["place"], lr_poly(args.learning_rate, i_iter, args.num_steps, args.power),
+                          args.batch_size * world * (i_iter + 1) / max(time.time() - t0, 1e-9)))               # :438-441 (p1+p2, y1+y2)
         if i_iter >= args.num_steps_stop - 1:
             if rank == 0:
                 print("save model ...")

@@ -336,7 +336,7 @@ WD_CASES = [
 
 @pytest.mark.parametrize("case", WD_CASES)
 def test_weights_direct_kernel_is_bitwise_the_lds_kernel(dev, case):
-    """conv_igemm2_kernel<256, *, 3, 0, 0, 1> (weights straight into registers from the fragment-ordered copy) against the same launch
+    """conv_igemm2x_kernel<256, *, 3, 0, 0, 1> (csrc/experiments/conv_igemm2_abl.hip, -DSIMT_ABLATION builds: weights straight into registers from the fragment-ordered copy) against the same launch
     without w_frag (weights staged through LDS): same MFMA chain per accumulator -> bit-identical outputs and statistics; and both against
     torch-CPU (1e-2 of max|ref|, the bf16 bar of this file)."""
     B, H, W, Cin, Cout, k, dil, epi = case
@@ -442,3 +442,29 @@ def test_grouped_wgrad_launch_is_bitwise_the_single_launches(dev, geom):
         y = torch.nn.functional.conv2d(xr, w, padding=dil * (k // 2), dilation=dil if k == 3 else 1)
         y.backward(dy.float().cpu().view(B, H, W, cd).permute(0, 3, 1, 2))
         assert _rel(got.cpu(), w.grad) <= 1e-2
+
+
+def test_wgrad_reduce_unaligned_destination(dev):
+    """the float4 reduce kernels need a 16-byte aligned destination.  simt_wgrad_reduce falls back to its scalar kernel for a
+    gradient that starts 4 bytes off (same sums, same order: bit-identical); the table form (no fallback) refuses it; and every plan
+    lays its flat gradient buffer out on 16-byte boundaries (engine.layout_flat_grads), DeepLabv3's 19 + 6 leading biases included."""
+    g = torch.Generator().manual_seed(5)
+    for (cd, cin, k, ns) in ((64, 64, 3, 3), (128, 32, 1, 4)):
+        slab = torch.randn(ns, cd, k * k * cin, generator=g).to(dev)
+        kw = dict(nsplit=ns, Cd=cd, Ktot=k * k * cin, Cin=cin, co_off=0, tap_off=0, Cout=cd, RS=k * k)
+        aligned = torch.empty(cd * cin * k * k, device=dev)
+        ops.wgrad_reduce(slab, aligned, **kw)
+        raw = torch.full((cd * cin * k * k + 8,), float("nan"), device=dev)
+        off = raw[1:1 + aligned.numel()]
+        assert off.data_ptr() % 16 == 4
+        ops.wgrad_reduce(slab, off, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(off, aligned) and torch.isnan(raw[0]) and torch.isnan(raw[1 + aligned.numel()])
+        with pytest.raises(AssertionError):
+            ops.wgrad_reduce_multi_table([dict(slab=slab, dst=off, **kw)], dev)
+    from simt_amd import model_spec as ms
+    from simt_amd.engine_v3 import V3Plan, v3_state_shapes
+    st = {k: v.to(dev) for k, v in ms.kaiming_init(v3_state_shapes(19, 6, True), seed=1).items()}
+    plan = V3Plan(st, 1, 64, 64, 19, 6, True, dtype=torch.bfloat16, train=True, device=dev)
+    assert all(t.data_ptr() % 16 == 0 for t in plan.grads.values())
+    assert plan.grad_offsets[plan.grad_order[1]][0] % 4 == 0 and plan.p[plan.grad_order[0]].numel() % 4 != 0

@@ -148,7 +148,7 @@ def test_dp_hooked_backward_world1_equals_plain(dev):
                              dtype=torch.float32, device=dev, layers=layers, process_group=pg)
             if pg is not None:
                 # only gradients the optimiser applies are exchanged: layer3 / layer4 / heads = a prefix of the flat buffer
-                applied = sum(tr.plan.grads[n].numel() for n in tr.sgd_names)
+                applied = sum(tr.plan.grad_offsets[n][1] for n in tr.sgd_names)      # spans (16-byte padded)
                 assert len(tr.reducer.buckets) >= 1 and tr.reducer.buckets[-1][1] == applied < tr.plan.flat_grad.numel()
             for it in range(2):
                 tr.step(img.to(dev), lab.to(dev), it)
@@ -336,3 +336,19 @@ def test_out_of_range_label_is_reported(dev):
     tr.step(img.to(dev), lab.to(dev), 1)
     with pytest.raises(ValueError, match="2 label value"):
         tr.losses()
+    # the count accumulates over steps that are not read and over EVERY micro-batch (the check used to see the last one only);
+    # raising clears it
+    lab_ok = lab.clone()
+    lab_ok[lab_ok == 19] = 0
+    lab_ok[lab_ok == 200] = 255
+    tr.step(img.to(dev), lab_ok.to(dev), 2)
+    assert np.isfinite(tr.losses()["total"])
+    tr.step(img.to(dev), lab.to(dev), 3)              # bad labels in a step whose losses nobody reads ...
+    tr.step(img.to(dev), lab_ok.to(dev), 4)           # ... followed by a clean one
+    with pytest.raises(ValueError, match="2 label value"):
+        tr.losses()
+    tr2 = SimTTrainer(st, fst, so.ntm_init(19, K, 1), so.ntm_init(19, K, 2), Hyper(open_classes=K, iter_size=2), CD.numpy(), 1, 65, 65,
+                      dtype=torch.float32, device=dev, layers=layers)
+    tr2.step([img.to(dev), img.to(dev)], [lab.to(dev), lab_ok.to(dev)], 0)      # bad labels in the FIRST micro-batch only
+    with pytest.raises(ValueError, match="2 label value"):
+        tr2.losses()
