@@ -126,6 +126,8 @@ def main():
     if world > 1 and backend == "nccl" and ndev < world:
         raise SystemExit(f"{world} ranks over RCCL need {world} GPUs, this node shows {ndev}")
     local = local % max(ndev, 1)       # (several ranks share a device only in the gloo functional test)
+    if world > ndev:                   # ... where the grid-barrier BatchNorm launches of two processes could starve each other (engine.py)
+        os.environ["SIMT_BN_GRID"] = "0"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None

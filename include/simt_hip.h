@@ -69,8 +69,36 @@ typedef struct {
                         * (row % 16) + 16 * ((kcol / 8) % 4)) * 8 + kcol % 8.  When present and simt_conv_wants_frag(d) != 0 the wide
                         * bf16 kernel loads its weight operand straight into registers (1 KB contiguous per wave-instruction)
                         * instead of staging it through LDS; results are bit-identical either way */
+  const struct simt_fbn_desc* fbn;   /* optional (may be NULL): the train-mode BatchNorm behind this conv fused into the launch, below */
 } simt_conv_desc;
+/* Train-mode BatchNorm2d (frozen affine; model/deeplab_multi.py:63-70,81-91) fused into the PRODUCING conv launch -- round 4.  For a
+ * launch whose workgroups are all co-resident (one round of the chip: simt_conv_fbn_ok), the pixel tile stays in LDS after the epilogue;
+ * every workgroup publishes its per-channel tile sums as 8-byte {value, tag} granules (write-through stores), the first C/8 workgroups
+ * poll the granules of 8 channels each, add them IN THE ORDER simt_bn_finalize / simt_bn_bwd's finalize use (bitwise the same constants)
+ * and publish the constants the same way; every workgroup polls its channels' constants and normalises its tile from LDS:
+ *   mode 1 (forward; needs d->stats):       y as usual, out = relu(y * scale + shift)   replaces simt_bn_finalize + simt_bn_apply
+ *   mode 2 (backward; needs d->bnr_mode 2): out = scale * (g - c1 - xhat * c2)          replaces simt_bn_bwd; d->y (the raw dz) is NOT written
+ * (d->stats / d->bnr_part themselves are not written in fused launches.)  Only a launch on the stream that owns the plan may wait like
+ * this: kernels of the other streams (frozen forward, weight gradients) never wait on anything, so the co-residency the polling needs
+ * always resolves (a workgroup traps after ~2 s of polling instead of hanging).  `work` belongs to ONE BatchNorm and direction: its
+ * ticket counters only ever grow and give every launch its generation = the granules' tag. */
+#define SIMT_FBN_BAR_WORDS 144            /* uint64 words at the head of `work`: 8 ticket counters, one 128-byte line each (+ spare) */
+typedef struct simt_fbn_desc {
+  int32_t mode;          /* 1 forward, 2 backward */
+  int32_t ldo;           /* row pitch of out in elements */
+  void* out;             /* [B*Ho*Wo][ldo] bf16 */
+  uint64_t* work;        /* [simt_conv_fbn_words(d)] uint64, zeroed ONCE by the caller: counters | [2][C] constants | [tiles][2|3][C] tile sums */
+  const float *gamma, *beta;              /* forward: [C] or NULL (1 / 0) */
+  float *running_mean, *running_var;      /* forward: updated with `momentum` like simt_bn_finalize, or NULL */
+  float momentum, eps;
+  float *mean, *rstd, *scale, *shift;     /* forward: OUT [C] each (the backward reads them) */
+  float* coef;                            /* backward: OUT [3][C] = (sum g, sum g*xhat, 0) / count */
+} simt_fbn_desc;
 int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);
+/* 1 if simt_conv_fprop can run d with a fused BatchNorm (d->fbn): bf16 v2 kernel with 256- or 128-column tiles and a grid that is
+ * co-resident on the current device (tiles <= compute units); d->fbn itself need not be set yet */
+int simt_conv_fbn_ok(const simt_conv_desc* d);
+long simt_conv_fbn_words(const simt_conv_desc* d);      /* uint64 words simt_fbn_desc.work needs for d (0 if !simt_conv_fbn_ok) */
 /* 1 if the launch for d would use d->w_frag when given (conv_igemm2_kernel<256, *, 3>: Npad tiles of 256, long reductions) */
 int simt_conv_wants_frag(const simt_conv_desc* d);
 /* `mode` of simt_pack_weight / PackJob: low byte = layout mode 0 / 1 / 2 below; SIMT_PACK_FRAG(nt16) additionally stores the

@@ -25,7 +25,17 @@ class ConvDesc(C.Structure):
                 ("relu", i32), ("dtype_in", i32), ("dtype_out", i32), ("tile_n", i32),
                 ("dy", C.c_int16 * MAX_TAPS), ("dx", C.c_int16 * MAX_TAPS), ("mask", c_p), ("ldm", i32),
                 ("res_bits", c_p), ("bnr_y", c_p), ("bnr_mean", c_p), ("bnr_rstd", c_p), ("bnr_scale", c_p), ("bnr_shift", c_p),
-                ("bnr_bits", c_p), ("bnr_part", c_p), ("bnr_mode", i32), ("bnr_ld", i32), ("w_frag", c_p)]
+                ("bnr_bits", c_p), ("bnr_part", c_p), ("bnr_mode", i32), ("bnr_ld", i32), ("w_frag", c_p), ("fbn", c_p)]
+
+
+FBN_BAR_WORDS = 144
+
+
+class FbnDesc(C.Structure):
+    """simt_fbn_desc (include/simt_hip.h): the train-mode BatchNorm behind a conv, fused into the producing launch."""
+    _fields_ = [("mode", i32), ("ldo", i32), ("out", c_p), ("work", c_p), ("gamma", c_p), ("beta", c_p),
+                ("running_mean", c_p), ("running_var", c_p), ("momentum", f32), ("eps", f32),
+                ("mean", c_p), ("rstd", c_p), ("scale", c_p), ("shift", c_p), ("coef", c_p)]
 
 
 class WgradDesc(C.Structure):
@@ -91,6 +101,8 @@ SIGNATURES = {
     "simt_abi_version": (_I, []),
     "simt_conv_fprop": (_I, [C.POINTER(ConvDesc), c_p]),
     "simt_conv_mtiles": (_I, [C.POINTER(ConvDesc)]),
+    "simt_conv_fbn_ok": (_I, [C.POINTER(ConvDesc)]),
+    "simt_conv_fbn_words": (_L, [C.POINTER(ConvDesc)]),
     "simt_conv_wants_frag": (_I, [C.POINTER(ConvDesc)]),
     "simt_conv_variant": (_I, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "simt_conv_wgrad": (_I, [C.POINTER(WgradDesc), c_p]),

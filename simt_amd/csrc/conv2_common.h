@@ -29,6 +29,15 @@ struct Conv2KArgs {
   int toff[SIMT_MAX_TAPS];   // (dy*W + dx) * pix_bytes: 32-bit so that the uniform per-stage lookup is an s_load_dword
                              // (a 16-bit table compiles to global_load_sshort, whose vmcnt(0) drains the glds ring)
   short dy[SIMT_MAX_TAPS], dx[SIMT_MAX_TAPS];
+  // fused train-mode BatchNorm (simt_fbn_desc; kernels instantiated with FBN = 1 only)
+  int fbn_mode, fbn_ldo;
+  bf16_t* fbn_out;
+  unsigned long long* fbn_bar;         // [SIMT_FBN_BAR_WORDS] ticket counters
+  unsigned long long *fbn_cgran, *fbn_slots;   // [2][Cout] constants granules; [ntiles_m][2 | 3][Cout] tile-sum granules
+  const float *fbn_gamma, *fbn_beta;
+  float *fbn_rmean, *fbn_rvar;
+  float fbn_momentum, fbn_eps;
+  float *fbn_mean, *fbn_rstd, *fbn_scale, *fbn_shift, *fbn_coef;
 };
 
 #ifdef SIMT_ABLATION

@@ -4,10 +4,28 @@
 // streaming).  acc[j][i][e]: cout = n0 + (wn*TN + j)*16 + (lane>>4)*4 + e ; pixel row = (wm*TM + i)*16 + (lane&15).
 #pragma once
 #include "conv2_common.h"
+#include <type_traits>
 
-template <int BN, int BM, int NT, int TN, int TM>
+// write-through / L1-bypassing accesses for bytes handed between workgroups of ONE launch (global_store / global_load ... sc1)
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_sc1(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 8-byte {value, tag} granules: ONE naturally aligned write-through store / L1-bypassing load each (never torn)
+__device__ __forceinline__ void st_gran(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_gran(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Polling loops below: the other workgroups of the launch must become resident for a poll to end.  If something keeps them off the chip
+// for ~2 s (two waiting launches of different processes starving each other: engine.py SIMT_BN_GRID), the kernel traps -- the process
+// dies loudly instead of hanging the GPU.  s_memrealtime = constant 100 MHz (s_memtime counts core clocks).
+// FBN = 1: the instantiation can also run the fused train-mode BatchNorm (simt_fbn_desc, a.fbn_mode 1 / 2): the tail of this function.
+template <int BN, int BM, int NT, int TN, int TM, int FBN = 0>
 __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a, char* smem, f32x4 (&acc)[TN][TM], bool compute_wave, int wm, int wn,
-                                               int tid, int lane, int m0, int n0, int m_end, int mt) {
+                                               int tid, int lane, int m0, int n0, int m_end, int mt, int tile = 0) {
   constexpr int CP = BN * 2 + 8;                   // epilogue tile pitch in bytes (bf16 row + 8 B pad)
   // ---------------- epilogue ----------------
   // acc[j][i][e]: cout = n0 + wn*TN*16 + j*16 + (lane>>4)*4 + e ; pixel row = wm*TM*16 + i*16 + (lane&15)
@@ -52,6 +70,13 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a, char* smem, 
       pk.y = pack_bf16x2(acc[j][i][2], acc[j][i][3]);
       *(uint2*)(sC + r * CP + c * 2) = pk;
     }
+  // fused BatchNorm: this launch's generation on its BatchNorm's counters = a ticket drawn NOW (one returning agent-scope add by one lane),
+  // needed only when the tile sums are published a few microseconds further down
+  unsigned long long fbn_ticket = 0;
+  if constexpr (FBN != 0) {
+    if (a.fbn_mode && tid == 0)
+      fbn_ticket = __hip_atomic_fetch_add(a.fbn_bar + (blockIdx.x & 7) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   struct Aux { uint4 res, by; unsigned rbits, ybits; };   // by: saved activation (bnr) or ReLU mask operand (VGG): exclusive
   const bool aux = (a.res || a.bnr_mode || a.mask) && n < a.Nstore;
   Aux q[NIT];
@@ -114,7 +139,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a, char* smem, 
         for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
       }
       if (plain) {
-        *(uint4*)(a.y + (long)m * a.ldy + n) = o;
+        if (!(FBN && a.fbn_mode)) *(uint4*)(a.y + (long)m * a.ldy + n) = o;      // fused BatchNorm: the rows go out AFTER the tile sums are published (forward) / never (backward: dy instead)
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bias8[e];
@@ -165,6 +190,13 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a, char* smem, 
       sR[(rg * 2 + 0) * BN + vcol + e] = s1[e];
       sR[(rg * 2 + 1) * BN + vcol + e] = s2[e];
     }
+    [[maybe_unused]] unsigned* sTag = (unsigned*)(smem + BM * CP + RPP * 2 * BN * 4 + 32 * 8 * 3 * 8);      // behind sRed (below)
+    if constexpr (FBN != 0) {
+      if (a.fbn_mode && tid == 0) {          // tag of this launch's granules: generation + 1 (never 0: the buffers start zeroed)
+        const unsigned cnt_s = (unsigned)(a.ntiles_m * a.ntiles_n - (int)(blockIdx.x & 7) + 7) >> 3;
+        sTag[0] = (unsigned)(fbn_ticket / cnt_s) + 1u;
+      }
+    }
     __syncthreads();
     STAMP(6);
     if (tid < BN) {
@@ -176,19 +208,218 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a, char* smem, 
           t1 += sR[(q * 2 + 0) * BN + tid];
           t2 += sR[(q * 2 + 1) * BN + tid];
         }
-        if (a.bnr_mode) {      // [m-tile][3][Cout]: S1, S2 and the (unused) second-BN row
+        if (FBN && a.fbn_mode) {
+          // fused BatchNorm: the tile sums go to the OWNER workgroups of this launch as 8-byte {value, tag} granules, one write-through
+          // store each (MI355X_MICROARCH.md hand-off form R2: the reader polls the data itself -- no flag, no drain, no second trip)
+          const int NJg = a.fbn_mode == 2 ? 3 : 2;
+          const unsigned long long tg = (unsigned long long)sTag[0] << 32;
+          unsigned long long* gs = a.fbn_slots + ((long)mt * NJg) * a.Cout + nn;
+          st_gran(gs, tg | __float_as_uint(t1));
+          st_gran(gs + a.Cout, tg | __float_as_uint(t2));
+        } else if (a.bnr_mode) {      // [m-tile][3][Cout]: S1, S2 and the (unused) second-BN row
           a.bnr_part[((long)mt * 3 + 0) * a.Cout + nn] = t1;
           a.bnr_part[((long)mt * 3 + 1) * a.Cout + nn] = t2;
           a.bnr_part[((long)mt * 3 + 2) * a.Cout + nn] = 0.f;
-          return;
+        } else {
+          a.stats[((long)mt * 2 + 0) * a.Cout + nn] = t1;
+          a.stats[((long)mt * 2 + 1) * a.Cout + nn] = t2;
+          if (mt == 0)   // the caller sums ceil(M/128) slots; tiles of more than 128 rows leave the tail unused: zero it
+            for (int sl = a.ntiles_m; sl < a.nblk128; ++sl) {
+              a.stats[((long)sl * 2 + 0) * a.Cout + nn] = 0.f;
+              a.stats[((long)sl * 2 + 1) * a.Cout + nn] = 0.f;
+            }
         }
-        a.stats[((long)mt * 2 + 0) * a.Cout + nn] = t1;
-        a.stats[((long)mt * 2 + 1) * a.Cout + nn] = t2;
-        if (mt == 0)   // the caller sums ceil(M/128) slots; tiles of more than 128 rows leave the tail unused: zero it
-          for (int sl = a.ntiles_m; sl < a.nblk128; ++sl) {
-            a.stats[((long)sl * 2 + 0) * a.Cout + nn] = 0.f;
-            a.stats[((long)sl * 2 + 1) * a.Cout + nn] = 0.f;
+      }
+    }
+    if constexpr (FBN != 0) {
+      if (a.fbn_mode) {
+        // ---------------- fused train-mode BatchNorm: tile sums -> owners -> constants -> every workgroup, all as polled granules
+        constexpr int RED_OFF = BM * CP + RPP * 2 * BN * 4;       // behind the tile and the row-group sums
+        double* sRed = (double*)(smem + RED_OFF);                 // [32][8][3]
+        float* sCst = (float*)(smem + RED_OFF + 32 * 8 * 3 * 8 + 16);     // [2][BN]: this tile's channels' constants
+        const int G = (a.Cout + 7) >> 3;                          // owner workgroups: 8 channels each, like bn_finalize_kernel's blocks
+        const bool owner = tile < G;
+        const int NJ = a.fbn_mode == 2 ? 3 : 2;
+        const unsigned tag = sTag[0];
+        STAMP(1);
+        if (a.fbn_mode == 1 && n < a.Nstore) {
+          // forward: NOW stream the rows of y out (the statistics loop above only summed them) -- the owners reduce meanwhile
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int r = rg + it * RPP;
+            const int m = m0 + r;
+            if (r >= BM || m >= m_end) break;
+            const uint2 lo = *(const uint2*)(sC + r * CP + vcol * 2);
+            const uint2 hi = *(const uint2*)(sC + r * CP + vcol * 2 + 8);
+            *(uint4*)(a.y + (long)m * a.ldy + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
           }
+        }
+        STAMP(2);
+        if (owner) {
+          // the same sums in the same order as part_colsum8 (bn_pool.hip): thread (r, cl) adds slots r, r + 32, ... of channel 8 * tile + cl
+          // in double, then r = 0 adds the 32 partials in order -> bitwise the constants of simt_bn_finalize / simt_bn_bwd.  (The forward's
+          // zero tail slots ntiles_m ... ceil(M / 128) add nothing.)  All granules of a thread are requested at once and re-requested until
+          // every tag is this launch's.
+          const int nblk = a.ntiles_m;
+          const int cl = tid & 7, r = tid >> 3;
+          const int c = tile * 8 + cl;
+          if (tid < 256) {
+            constexpr int MAXS = 12;                               // slots per thread: ntiles_m <= 384 (simt_conv_fbn_ok)
+            double sj[3] = {0.0, 0.0, 0.0};
+            if (c < a.Cout) {
+              auto run = [&](auto NJC) {
+                constexpr int NJc = decltype(NJC)::value == 3 ? 2 : 2;      // the third row of the backward is identically zero: not sent
+                float v[MAXS][NJc];
+                const unsigned off0 = (unsigned)(r * decltype(NJC)::value) * (unsigned)a.Cout + (unsigned)c;
+                const unsigned ostep = 32u * decltype(NJC)::value * (unsigned)a.Cout;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                bool ok;
+                do {
+                  ok = true;
+#pragma unroll
+                  for (int u = 0; u < MAXS; ++u)
+#pragma unroll
+                    for (int j = 0; j < NJc; ++j) {
+                      if (r + 32 * u < nblk) {
+                        const unsigned long long gq = ld_gran(a.fbn_slots + (off0 + u * ostep + j * (unsigned)a.Cout));
+                        ok = ok && (unsigned)(gq >> 32) == tag;
+                        v[u][j] = __uint_as_float((unsigned)gq);
+                      } else {
+                        v[u][j] = 0.f;
+                      }
+                    }
+                  if (!ok) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) __builtin_trap();      // ~2 s (see the top of this file)
+                  }
+                } while (!ok);
+#pragma unroll
+                for (int u = 0; u < MAXS; ++u)
+#pragma unroll
+                  for (int j = 0; j < NJc; ++j)
+                    if (r + 32 * u < nblk) sj[j] += (double)v[u][j];
+              };
+              if (NJ == 3) run(std::integral_constant<int, 3>{}); else run(std::integral_constant<int, 2>{});
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) sRed[(r * 8 + cl) * 3 + j] = sj[j];       // (constant trip counts: a run-time index puts the array in scratch)
+          }
+          __syncthreads();
+          if (tid < 8 && c < a.Cout) {
+            double t[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              for (int q = 0; q < 32; ++q) t[j] += sRed[(q * 8 + cl) * 3 + j];   // (row 2 is zero)
+            const long count = a.M;
+            const unsigned long long tg = (unsigned long long)tag << 32;
+            if (a.fbn_mode == 1) {                                 // bn_finalize_kernel
+              const double mean = t[0] / (double)count;
+              double var = t[1] / (double)count - mean * mean;
+              if (var < 0.0) var = 0.0;
+              const float rstd = (float)(1.0 / sqrt(var + (double)a.fbn_eps));
+              const float g = a.fbn_gamma ? a.fbn_gamma[c] : 1.f, bt = a.fbn_beta ? a.fbn_beta[c] : 0.f;
+              const float sc = g * rstd;
+              const float sh = bt - (float)mean * sc;
+              st_gran(a.fbn_cgran + c, tg | __float_as_uint(sc));
+              st_gran(a.fbn_cgran + a.Cout + c, tg | __float_as_uint(sh));
+              a.fbn_mean[c] = (float)mean;                         // (for the backward launches: ordinary stores)
+              a.fbn_rstd[c] = rstd;
+              a.fbn_scale[c] = sc;
+              a.fbn_shift[c] = sh;
+              if (a.fbn_rmean) {
+                const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+                a.fbn_rmean[c] = (1.f - a.fbn_momentum) * a.fbn_rmean[c] + a.fbn_momentum * (float)mean;
+                a.fbn_rvar[c] = (1.f - a.fbn_momentum) * a.fbn_rvar[c] + a.fbn_momentum * (float)unb;
+              }
+            } else {                                               // bn_bwd_finalize_kernel
+              const float c1 = (float)(t[0] / (double)count), c2 = (float)(t[1] / (double)count);
+              st_gran(a.fbn_cgran + c, tg | __float_as_uint(c1));
+              st_gran(a.fbn_cgran + a.Cout + c, tg | __float_as_uint(c2));
+              a.fbn_coef[c] = c1;
+              a.fbn_coef[a.Cout + c] = c2;
+              a.fbn_coef[2 * a.Cout + c] = 0.f;
+            }
+          }
+        }
+        // every workgroup: ONE wave polls the constants of this tile's BN channels (two granules per channel) into LDS
+        if (tid < 64) {
+          constexpr int PER = (2 * BN + 63) / 64;                  // granules per lane
+          const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+          float cv[PER];
+          bool ok;
+          do {
+            ok = true;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+              const int idx = lane + 64 * u;                       // [0, 2 * BN): row idx / BN (scale | shift  or  c1 | c2), channel n0 + idx % BN
+              const int ch = n0 + (idx % BN);
+              if (idx < 2 * BN && ch < a.Cout) {
+                const unsigned long long gq = ld_gran(a.fbn_cgran + (idx / BN) * a.Cout + ch);
+                ok = ok && (unsigned)(gq >> 32) == tag;
+                cv[u] = __uint_as_float((unsigned)gq);
+              } else {
+                cv[u] = 0.f;
+              }
+            }
+            ok = __all(ok);
+            if (!ok) {
+              __builtin_amdgcn_s_sleep(1);
+              if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) __builtin_trap();
+            }
+          } while (!ok);
+#pragma unroll
+          for (int u = 0; u < PER; ++u)
+            if (lane + 64 * u < 2 * BN) sCst[lane + 64 * u] = cv[u];
+        }
+        __syncthreads();
+        STAMP(7);                                                  // (constants published and seen)
+        // ---- apply: the tile is still in LDS (bf16, as stored)
+        if (n < a.Nstore) {
+          auto unpack8 = [](const uint4& qq, float* v) {
+            v[0] = __uint_as_float(qq.x << 16); v[1] = __uint_as_float(qq.x & 0xffff0000u);
+            v[2] = __uint_as_float(qq.y << 16); v[3] = __uint_as_float(qq.y & 0xffff0000u);
+            v[4] = __uint_as_float(qq.z << 16); v[5] = __uint_as_float(qq.z & 0xffff0000u);
+            v[6] = __uint_as_float(qq.w << 16); v[7] = __uint_as_float(qq.w & 0xffff0000u);
+          };
+          float sc[8], sh[8], mu[8], rs[8], c1[8], c2[8];
+          if (a.fbn_mode == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc[e] = sCst[vcol + e]; sh[e] = sCst[BN + vcol + e]; }
+          } else {
+            load8(a.bnr_scale + n, sc);
+            load8(a.bnr_shift + n, sh);
+            load8(a.bnr_mean + n, mu);
+            load8(a.bnr_rstd + n, rs);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { c1[e] = sCst[vcol + e]; c2[e] = sCst[BN + vcol + e]; }
+          }
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int r = rg + it * RPP;
+            const int m = m0 + r;
+            if (r >= BM || m >= m_end) break;
+            const uint2 lo = *(const uint2*)(sC + r * CP + vcol * 2);
+            const uint2 hi = *(const uint2*)(sC + r * CP + vcol * 2 + 8);
+            float v[8];
+            unpack8(make_uint4(lo.x, lo.y, hi.x, hi.y), v);
+            if (a.fbn_mode == 1) {                                 // bn_apply_kernel: relu(y * scale + shift)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+              store8(a.fbn_out + (long)m * a.fbn_ldo + n, v);
+            } else {                                               // bn_bwd_apply_kernel, mask_mode 2
+              float yv[8], o[8];
+              unpack8(q[it].by, yv);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (yv[e] * sc[e] + sh[e]) > 0.f ? v[e] : 0.f;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = sc[e] * (v[e] - c1[e] - ((yv[e] - mu[e]) * rs[e]) * c2[e]);
+              store8(a.fbn_out + (long)m * a.fbn_ldo + n, o);
+            }
+          }
+        }
+        STAMP(0);                                                  // (end of the fused tail; slot 0 = start is overwritten: read deltas)
       }
     }
   }

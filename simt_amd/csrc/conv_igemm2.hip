@@ -35,7 +35,9 @@ extern "C" int simt_debug_stamps(unsigned long long* out, int n) {
 // Round-3 experiments on this kernel (timing-ablation MODEs, loader waves LW = 4 / 8, weights straight into registers WD = 1, and the
 // role-split conv_igemm3) live in csrc/experiments/ and are compiled only into -DSIMT_ABLATION builds (csrc/build.sh ABLATION=1);
 // what they measured is in DESIGN.md section 9 and profiles/r03_conv_experiments.txt.  This file is the product kernel only.
-template <int BN, int TMP, int NSTP>
+// FBN = 1: the same kernel with the fused train-mode BatchNorm tail compiled in (conv2_epilogue.h; a.fbn_mode selects forward / backward).
+// A separate instantiation so that the plain kernels keep their code (the main loop is sensitive to what surrounds it).
+template <int BN, int TMP, int NSTP, int FBN = 0>
 __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(Conv2KArgs a) {
   constexpr int NT = 512, NST = NSTP;   // NST = 3: one workgroup per CU, two stages in flight; NST = 2 (short-K, output-
                                         // bound shapes): two workgroups per CU so one's epilogue overlaps the other's loads
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
   }
 
   STAMP(3);
-  conv2_epilogue<BN, BM, NT, TN, TM>(a, smem, acc, true, wm, wn, tid, lane, m0, n0, m_end, mt);
+  conv2_epilogue<BN, BM, NT, TN, TM, FBN>(a, smem, acc, true, wm, wn, tid, lane, m0, n0, m_end, mt, tile);
 }
 
 #ifdef SIMT_ABLATION
@@ -202,20 +204,20 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
 bool simt_conv2_abl_launch(const Conv2KArgs& k, int bn, int tm, int nst, hipStream_t st, int* rc);
 int simt_conv2_abl_wants_frag(const simt_conv_desc* d);
 #endif
-template <int BN, int TM, int NST = 3>
+template <int BN, int TM, int NST = 3, int FBN = 0>
 static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
   constexpr int WM = (BN == 64) ? 4 : 2;
   constexpr int BM = WM * TM * 16;
 #ifdef SIMT_ABLATION
-  { int rc; if (simt_conv2_abl_launch(k, BN, TM, NST, st, &rc)) return rc; }
+  if (!FBN) { int rc; if (simt_conv2_abl_launch(k, BN, TM, NST, st, &rc)) return rc; }
 #endif
   const size_t ring = NST * (size_t)(BM * 128 + BN * 128);
-  const size_t epi = (size_t)BM * (BN * 2 + 8) + (size_t)(512 / (BN / 8)) * 2 * BN * 4;
+  const size_t epi = (size_t)BM * (BN * 2 + 8) + (size_t)(512 / (BN / 8)) * 2 * BN * 4 + (FBN ? 32 * 8 * 3 * sizeof(double) + 16 + 2 * BN * sizeof(float) : 0);
   const size_t lds = ring > epi ? ring : epi;
   static SimtLdsAttrCache attr_cache;
   if (simt_lds_attr_needed(&attr_cache, lds))
-    (void)hipFuncSetAttribute((const void*)conv_igemm2_kernel<BN, TM, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((conv_igemm2_kernel<BN, TM, NST>), dim3(k.ntiles_m * k.ntiles_n), dim3(512), lds, st, k);
+    (void)hipFuncSetAttribute((const void*)conv_igemm2_kernel<BN, TM, NST, FBN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((conv_igemm2_kernel<BN, TM, NST, FBN>), dim3(k.ntiles_m * k.ntiles_n), dim3(512), lds, st, k);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
@@ -298,6 +300,35 @@ extern "C" int simt_conv_wants_frag(const simt_conv_desc* d) {
 #endif
 }
 
+// Fused BatchNorm (simt_fbn_desc): the wide / medium 3-slot kernels, every workgroup co-resident (one workgroup per CU: the ring takes the LDS)
+static int device_cus() {
+  static int cus[SIMT_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SIMT_MAX_DEVICES) return 0;
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+extern "C" int simt_conv_fbn_ok(const simt_conv_desc* d) {
+  int bn, tm, nst;
+  if (!d || d->dtype_in != SIMT_BF16 || d->dtype_out != SIMT_BF16 || simt_conv_variant(d, &bn, &tm, &nst) != 2) return 0;
+  if (!(bn == 256 && nst == 3)) return 0;
+  const Conv2Variant v = pick_variant(d);
+  const int M = d->B * d->Ho * d->Wo;
+  const long nwg = (long)((M + v.rows - 1) / v.rows) * v.ntiles_n;
+  return d->Cout % 8 == 0 && d->Nstore == d->Cout && nwg <= device_cus() && (M + 127) / 128 <= 384;     // (slots per owner thread: MAXS)
+}
+
+extern "C" long simt_conv_fbn_words(const simt_conv_desc* d) {
+  if (!simt_conv_fbn_ok(d)) return 0;
+  const Conv2Variant v = pick_variant(d);
+  const long tiles = (d->B * d->Ho * d->Wo + v.rows - 1) / v.rows;
+  return SIMT_FBN_BAR_WORDS + 2l * d->Cout + tiles * 3 * d->Cout;
+}
+
 extern "C" int simt_conv_mtiles(const simt_conv_desc* d) {
   int bn, tm, nst;
   const int gen = simt_conv_variant(d, &bn, &tm, &nst);
@@ -319,6 +350,19 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
   if (k.bnr_mode) {
     SIMT_CHECK(d->dtype_out == SIMT_BF16 && !d->stats && !d->relu && !d->mask && d->bnr_y && d->bnr_mean && d->bnr_rstd && d->bnr_part);
     SIMT_CHECK(d->bnr_ld % 8 == 0 && (d->bnr_mode == 2 ? (d->bnr_scale && d->bnr_shift) : (d->bnr_mode == 3 && d->bnr_bits)));
+  }
+  k.fbn_mode = 0;
+  if (d->fbn) {
+    const simt_fbn_desc* f = d->fbn;
+    SIMT_CHECK(simt_conv_fbn_ok(d) && f->out && f->work && f->ldo % 8 == 0 && !d->bias && !d->res && !d->relu && !d->mask);
+    SIMT_CHECK(((long)d->B * d->Ho * d->Wo + 127) / 128 <= 384);       // statistics slots per owner thread: conv2_epilogue.h MAXS
+    if (f->mode == 1) SIMT_CHECK(d->stats && !d->bnr_mode && f->mean && f->rstd && f->scale && f->shift && (!f->running_mean || f->running_var));
+    else SIMT_CHECK(f->mode == 2 && d->bnr_mode == 2 && f->coef);
+    k.fbn_mode = f->mode; k.fbn_ldo = f->ldo; k.fbn_out = (bf16_t*)f->out; k.fbn_bar = (unsigned long long*)f->work;
+    k.fbn_cgran = k.fbn_bar + SIMT_FBN_BAR_WORDS; k.fbn_slots = k.fbn_cgran + 2l * d->Cout;
+    k.fbn_gamma = f->gamma; k.fbn_beta = f->beta; k.fbn_rmean = f->running_mean; k.fbn_rvar = f->running_var;
+    k.fbn_momentum = f->momentum; k.fbn_eps = f->eps;
+    k.fbn_mean = f->mean; k.fbn_rstd = f->rstd; k.fbn_scale = f->scale; k.fbn_shift = f->shift; k.fbn_coef = f->coef;
   }
   k.out_f32 = d->dtype_out == SIMT_F32;
   if (k.out_f32) SIMT_CHECK(!d->bias && !d->res && !d->relu && !d->stats && d->Nstore % 4 == 0 && d->ldy % 4 == 0);
@@ -347,6 +391,7 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
   if (v.rowsk) return simt_conv_rows_launch(k, d->Npad, st);
   if (v.stream) return simt_conv_stream_launch(k, d->Npad, st);
   if (short_k) return tm == 5 ? launch_conv2<128, 5, 2>(k, st) : launch_conv2<128, 4, 2>(k, st);
+  if (tile_n == 256 && k.fbn_mode) return tm == 5 ? launch_conv2<256, 5, 3, 1>(k, st) : launch_conv2<256, 4, 3, 1>(k, st);
   if (tile_n == 256) return tm == 5 ? launch_conv2<256, 5>(k, st) : launch_conv2<256, 4>(k, st);
   if (tile_n == 128) return tm == 5 ? launch_conv2<128, 5>(k, st) : launch_conv2<128, 4>(k, st);
   return launch_conv2<64, 2>(k, st);

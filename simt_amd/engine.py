@@ -274,6 +274,15 @@ class TrunkPlan:
         self.packed_t = {}    # conv name -> dgrad operand
         self.fold = {}        # bn name -> (scale, shift) for eval plans
         self.bn = {}          # bn name -> dict(mean, rstd, scale, shift, part, nblk, count)
+        # Train-mode BatchNorm fused into the producing conv launch (simt_fbn_desc; round 4): the launch's workgroups exchange their tile
+        # sums through polled granules, so all of them must be resident at once.  Measured on the production step (profiles/
+        # r04_bn_fusion.txt): the BACKWARD form (dgrad + BatchNorm backward in one launch) is worth -0.2 ms; the FORWARD form is +0.75 ms
+        # slower in the step although it is 5 us faster per launch alone -- its waiting workgroups hold CUs the frozen forward on the side
+        # stream wants.  Default 3 = backward only.  ONE training plan per device may use it: two processes on one GPU (only the 1-GPU test
+        # rigs do that) must set SIMT_BN_GRID=0, or their waiting launches can starve each other (the kernel traps after ~2 s).
+        g = os.environ.get("SIMT_BN_GRID", "3")      # 0 off, 1 forward + backward, 2 forward only, 3 backward only
+        self._fbn_on = train and dtype == torch.bfloat16 and g != "0"
+        self._fbn_dirs = {"1": (1, 2), "2": (1,), "3": (2,)}.get(g, ())
         self.pack_list = LaunchList()
         self.fwd_list = LaunchList()
         self.bwd_list = LaunchList()
@@ -372,9 +381,12 @@ class TrunkPlan:
 
     # ------------------------------------------------------------------ forward construction
     def _conv(self, lst, x, wp_info, y, *, Bn, Hi, Wi, Cin, Ho, Wo, Cout, taps, stride=1, bias=None, res=None, stats=None,
-              relu=False, ldy=None, Nstore=None, alg_k=None, alg_flops=None, mask=None, res_bits=None, bnr=None, note=""):
+              relu=False, ldy=None, Nstore=None, alg_k=None, alg_flops=None, mask=None, res_bits=None, bnr=None, note="", fbn=None):
         """alg_k: algorithmic reduction length per output element (defaults to ntaps*Cin; the K-padded head dgrad and
-        the stem pass their true value) -> algorithmic FLOPs = 2 * M * Cout * alg_k."""
+        the stem pass their true value) -> algorithmic FLOPs = 2 * M * Cout * alg_k.
+        fbn: ask for the train-mode BatchNorm behind this conv to be fused into the launch (simt_fbn_desc; dict(mode, out, bname[,
+        coef])).  Granted only where the launch is one co-resident round of the chip (simt_conv_fbn_ok): the returned descriptor then has
+        `.fbn` set and the caller must NOT add the separate BatchNorm launches."""
         wp, tile, npad = wp_info
         # Few pixels (DeepLabv3's stride-16 maps: M = 8 192 at 512 x 1024): 128-row x 256-column tiles are 64 workgroups on 256 CUs, each
         # streaming the whole weight panel through its LDS.  Narrower column tiles fill the chip and cut the staged bytes per workgroup
@@ -390,12 +402,30 @@ class TrunkPlan:
         tn = {torch.bfloat16: "bf16", torch.float32: "f32"}
         bn_, tm_, nst_ = C.c_int(), C.c_int(), C.c_int()
         gen = L.load().simt_conv_variant(C.byref(d), C.byref(bn_), C.byref(tm_), C.byref(nst_))
+        fb = 0
+        if fbn is not None and self._fbn_on and fbn["mode"] in self._fbn_dirs and gen == 2 and L.load().simt_conv_fbn_ok(C.byref(d)):
+            sb = self.bn[fbn["bname"]]
+            fd = L.FbnDesc()
+            fd.mode, fd.ldo, fd.out = fbn["mode"], fbn["out"].shape[-1], fbn["out"].data_ptr()
+            # counters + granule buffers of THIS BatchNorm and direction (zeroed once; tags make every launch's granules its own)
+            fd.work = self.new(L.load().simt_conv_fbn_words(C.byref(d)), dtype=torch.int64, zero=True).data_ptr()
+            if fd.mode == 1:
+                bname = fbn["bname"]
+                fd.gamma, fd.beta = self.p[bname + ".weight"].data_ptr(), self.p[bname + ".bias"].data_ptr()
+                fd.running_mean, fd.running_var = self.p[bname + ".running_mean"].data_ptr(), self.p[bname + ".running_var"].data_ptr()
+                fd.momentum, fd.eps = BN_MOMENTUM, BN_EPS
+                fd.mean, fd.rstd, fd.scale, fd.shift = (sb[k_].data_ptr() for k_ in ("mean", "rstd", "scale", "shift"))
+            else:
+                fd.coef = fbn["coef"].data_ptr()
+            d.fbn = C.addressof(fd)
+            d._fbn_keep = fd                       # the descriptor is read at every launch
+            fb = 1
         wd = 0
         if gen == 2 and ops.conv_wants_frag(d):
             # -DSIMT_ABLATION builds with SIMT_WDIRECT=1 only: weight operand from a fragment-ordered copy (csrc/experiments/conv_igemm2_abl.hip)
             d.w_frag = self._frag_twin(wp, npad).data_ptr()
             wd = 1
-        tag = (f"conv_igemm2_kernel<{bn_.value}, {tm_.value}, {nst_.value}>{' [weights-direct experiment]' if wd else ''}" if gen == 2 else
+        tag = (f"conv_igemm2_kernel<{bn_.value}, {tm_.value}, {nst_.value}, {fb}>{' [weights-direct experiment]' if wd else ''}" if gen == 2 else
                "conv1x1_stream_kernel" if gen == 4 else "conv1x1_rows_kernel" if gen == 5 else
                f"conv_igemm_kernel<{tn[x.dtype]}, {tn[y.dtype]}, {tile}>")
         nbytes = (Bn * Hi * Wi * Cin + npad * len(taps) * Cin) * x.element_size() + M * Cout * y.element_size()
@@ -487,16 +517,20 @@ class TrunkPlan:
                 w1 = self._plan_pack(f"{name}.conv1", planes, inpl, 1)
                 w2 = self._plan_pack(f"{name}.conv2", planes, planes, 3)
                 w3 = self._plan_pack(f"{name}.conv3", c4, planes, 1)
-                self._conv(f, x, w1, y1, Bn=B, Hi=Hc, Wi=Wc, Cin=inpl, Ho=Ho, Wo=Wo, Cout=planes, taps=[(0, 0)],
-                           stride=stride, stats=s1["part"])
-                self._bn_train(f, f"{name}.bn1", y1, Mo, planes)
-                f.add("simt_bn_apply", y1.data_ptr(), s1["scale"].data_ptr(), s1["shift"].data_ptr(), None, None, None,
-                      None, a1.data_ptr(), Mo, planes, 1, ops.dt_code(dt))
-                self._conv(f, a1, w2, y2, Bn=B, Hi=Ho, Wi=Wo, Cin=planes, Ho=Ho, Wo=Wo, Cout=planes, taps=t3,
-                           stats=s2["part"])
-                self._bn_train(f, f"{name}.bn2", y2, Mo, planes)
-                f.add("simt_bn_apply", y2.data_ptr(), s2["scale"].data_ptr(), s2["shift"].data_ptr(), None, None, None,
-                      None, a2.data_ptr(), Mo, planes, 1, ops.dt_code(dt))
+                # bn1 / bn2: fused into the producing conv where its grid is one co-resident round (layer 3 at 4 x 768 x 768: 255 tiles):
+                # the launch writes y AND a = relu(bn(y)); otherwise statistics slots -> finalize -> apply as separate launches
+                dsc = self._conv(f, x, w1, y1, Bn=B, Hi=Hc, Wi=Wc, Cin=inpl, Ho=Ho, Wo=Wo, Cout=planes, taps=[(0, 0)],
+                                 stride=stride, stats=s1["part"], fbn=dict(mode=1, out=a1, bname=f"{name}.bn1"))
+                if not dsc.fbn:
+                    self._bn_train(f, f"{name}.bn1", y1, Mo, planes)
+                    f.add("simt_bn_apply", y1.data_ptr(), s1["scale"].data_ptr(), s1["shift"].data_ptr(), None, None, None,
+                          None, a1.data_ptr(), Mo, planes, 1, ops.dt_code(dt))
+                dsc = self._conv(f, a1, w2, y2, Bn=B, Hi=Ho, Wi=Wo, Cin=planes, Ho=Ho, Wo=Wo, Cout=planes, taps=t3,
+                                 stats=s2["part"], fbn=dict(mode=1, out=a2, bname=f"{name}.bn2"))
+                if not dsc.fbn:
+                    self._bn_train(f, f"{name}.bn2", y2, Mo, planes)
+                    f.add("simt_bn_apply", y2.data_ptr(), s2["scale"].data_ptr(), s2["shift"].data_ptr(), None, None, None,
+                          None, a2.data_ptr(), Mo, planes, 1, ops.dt_code(dt))
                 self._conv(f, a2, w3, y3, Bn=B, Hi=Ho, Wi=Wo, Cin=planes, Ho=Ho, Wo=Wo, Cout=c4, taps=[(0, 0)],
                            stats=s3["part"])
                 self._bn_train(f, f"{name}.bn3", y3, Mo, c4)
@@ -887,10 +921,15 @@ class TrunkPlan:
             wt3 = self._plan_pack_t(f"{name}.conv3", c4, p, 1)
             da2 = self.buf("g.da", Mo, p)
             bnr = self._bnr(f"{name}.bn2", rec["y2"], 2)
-            dsc = self._conv(b, dy3, wt3[:3], da2, Bn=B, Hi=Ho, Wi=Wo, Cin=wt3[3], Ho=Ho, Wo=Wo, Cout=p, taps=[(0, 0)], bnr=bnr)
             dy2 = self.buf("g.dy2.%d" % par, Mo, p)
-            self._bn_bwd(b, dz=da2, y=rec["y2"], bname=f"{name}.bn2", dy=dy2, M=Mo, Cn=p, mask_mode=2,
-                         reduce_done_nblk=self._fused_nblk(dsc, bnr))
+            coef = self.buf("bnb.coef", 3 * 2048, dtype=torch.float32)
+            # the BatchNorm backward fused into the dgrad launch (same condition as the forward): dy2 straight from the tile in LDS, the raw
+            # dz (da2) is never written
+            dsc = self._conv(b, dy3, wt3[:3], da2, Bn=B, Hi=Ho, Wi=Wo, Cin=wt3[3], Ho=Ho, Wo=Wo, Cout=p, taps=[(0, 0)], bnr=bnr,
+                             fbn=dict(mode=2, out=dy2, bname=f"{name}.bn2", coef=coef) if bnr else None)
+            if not dsc.fbn:
+                self._bn_bwd(b, dz=da2, y=rec["y2"], bname=f"{name}.bn2", dy=dy2, M=Mo, Cn=p, mask_mode=2,
+                             reduce_done_nblk=self._fused_nblk(dsc, bnr))
             # conv2 (3x3 dilated)
             t3 = ops.conv_taps(3, 3, dil, dil)
             wjobs.append(dict(dy=dy2, x=rec["a1"], Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cd=p, ldd=p, taps=t3, stride=1,
@@ -904,11 +943,13 @@ class TrunkPlan:
             # dy2 has p channels; the dgrad operand is K-padded to ck >= p: equal here because p % kq == 0
             assert wt2[3] == p and wt3[3] == c4
             bnr = self._bnr(f"{name}.bn1", rec["y1"], 2)
-            dsc = self._conv(b, dy2, wt2[:3], da1, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cout=p,
-                             taps=[(-a, -c) for (a, c) in t3], bnr=bnr)
             dy1 = self.buf("g.dy1.%d" % par, Mo, p)
-            self._bn_bwd(b, dz=da1, y=rec["y1"], bname=f"{name}.bn1", dy=dy1, M=Mo, Cn=p, mask_mode=2,
-                         reduce_done_nblk=self._fused_nblk(dsc, bnr))
+            dsc = self._conv(b, dy2, wt2[:3], da1, Bn=B, Hi=Ho, Wi=Wo, Cin=p, Ho=Ho, Wo=Wo, Cout=p,
+                             taps=[(-a, -c) for (a, c) in t3], bnr=bnr,
+                             fbn=dict(mode=2, out=dy1, bname=f"{name}.bn1", coef=coef) if bnr else None)
+            if not dsc.fbn:
+                self._bn_bwd(b, dz=da1, y=rec["y1"], bname=f"{name}.bn1", dy=dy1, M=Mo, Cn=p, mask_mode=2,
+                             reduce_done_nblk=self._fused_nblk(dsc, bnr))
             # conv1 (+ downsample) wgrads
             b.wait(b.record(0), 1)
             wjobs.append(dict(dy=dy1, x=rec["x"], Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Ho, Wo=Wo, Cd=p, ldd=p, taps=[(0, 0)], stride=stride,

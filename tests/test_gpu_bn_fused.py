@@ -1,0 +1,180 @@
+"""Train-mode BatchNorm fused into the producing conv launch behind a grid-wide barrier (round 4; include/simt_hip.h simt_fbn_desc,
+csrc/conv2_epilogue.h) -- replaces conv -> simt_bn_finalize -> simt_bn_apply (forward) and dgrad -> simt_bn_bwd (backward) for bn1 / bn2
+of the Bottlenecks whose conv grid is one co-resident round of the chip (model/deeplab_multi.py:62-70,81-91).
+
+The fused launch reduces the SAME per-tile slots in the SAME order with the same expressions as the separate kernels, so everything is
+compared BIT FOR BIT against the unfused path, at the production shapes (M = 4 x 97 x 97 = 37 636, BASELINE configs[1]):
+  * per launch, both directions, 3x3 256 -> 256 (dilation 2) and 1x1 1024 -> 256: y, a = relu(bn(y)), mean / rstd / scale / shift, the
+    running statistics; dy and the coefficients of the backward;
+  * the whole plan (B=4, 768x768, bf16, 33 Bottlenecks): forward logits, saved activations and the flat gradient buffer with
+    SIMT_BN_GRID=1 vs 0, the fused instantiation asserted by launch tag;
+  * a two-stream soak: full SimT iterations (frozen forward + weight gradients on the side stream beside the waiting launches), no hang,
+    trajectory identical to the unfused build's.
+"""
+import ctypes as C
+import os
+
+import pytest
+import torch
+
+from oracle import simt_oracle as so
+from simt_amd import _lib as L
+from simt_amd import ops
+from simt_amd.engine import BN_EPS, BN_MOMENTUM, TrunkPlan, multi_heads
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+B4, HW = 4, 97
+CD = so.load_class_dist()
+
+
+def _fbn(mode, out, bar, **kw):
+    fd = L.FbnDesc()
+    fd.mode, fd.ldo, fd.out, fd.work = mode, out.shape[-1], out.data_ptr(), bar.data_ptr()
+    for k, v in kw.items():
+        setattr(fd, k, v.data_ptr() if torch.is_tensor(v) else v)
+    return fd
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 3, 2), (1024, 256, 1, 1), (256, 256, 3, 1)], ids=["3x3_d2_256", "1x1_1024_256", "3x3_d1_256"])
+def test_fused_bn_forward_and_backward_launch_bitwise(dev, shape):
+    Cin, Cout, k, dil = shape
+    B, H, W = B4, HW, HW
+    M = B * H * W
+    g = torch.Generator().manual_seed(Cin + 7 * k + dil)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev, BF)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k)) ** 0.5).to(dev)
+    taps = ops.conv_taps(k, k, dil, dil * (k // 2))
+    wp = torch.zeros(Cout, len(taps) * Cin, device=dev, dtype=BF)
+    ops.pack_weight(w.contiguous(), wp, Cout=Cout, Cin=Cin, RS=k * k, ldk=len(taps) * Cin, mode=0)
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).to(dev), (torch.randn(Cout, generator=g) * 0.3).to(dev)
+    nblk = (M + 127) // 128
+
+    def run(fused, rounds=3):
+        y = torch.full((M, Cout), float("nan"), device=dev, dtype=BF)
+        a = torch.full((M, Cout), float("nan"), device=dev, dtype=BF)
+        part = torch.full((nblk, 2, Cout), float("nan"), device=dev)
+        cst = {n: torch.full((Cout,), float("nan"), device=dev) for n in ("mean", "rstd", "scale", "shift")}
+        rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+        d = ops.make_conv_desc(x, wp, y, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=Cout, taps=taps, Npad=Cout, tile_n=256, stats=part)
+        assert L.load().simt_conv_fbn_ok(C.byref(d)) == 1
+        bar = torch.zeros(L.load().simt_conv_fbn_words(C.byref(d)), device=dev, dtype=torch.int64)
+        if fused:
+            fd = _fbn(1, a, bar, gamma=gamma, beta=beta, running_mean=rm, running_var=rv, momentum=BN_MOMENTUM, eps=BN_EPS, **cst)
+            d.fbn = C.addressof(fd)
+        for _ in range(rounds):                      # the counters only grow: a launch must find its generation every time
+            ops.conv_fprop_desc(d)
+            if not fused:
+                ops.bn_finalize(part, nblk, Cout, M, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, cst["mean"], cst["rstd"], cst["scale"], cst["shift"])
+                ops.bn_apply(y, cst["scale"], cst["shift"], a, M=M, Cn=Cout, relu=True)
+        torch.cuda.synchronize()
+        return dict(y=y, a=a, rm=rm, rv=rv, **cst), int(bar[:128:16].sum().item())
+    ref, _ = run(False)
+    got, tickets = run(True)
+    assert tickets == 3 * L.load().simt_conv_mtiles(C.byref(ops.make_conv_desc(x, wp, ref["y"], B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=Cout,
+                                                                                taps=taps, Npad=Cout, tile_n=256)))   # one ticket per workgroup and launch
+    for n in ref:
+        assert torch.isfinite(got[n].float()).all(), n
+        assert torch.equal(got[n], ref[n]), f"forward {n}: fused launch differs from conv + finalize + apply"
+    assert (got["a"] > 0).float().mean().item() > 0.2
+    # ---- backward: this conv as the dgrad that produces dz of a BatchNorm-ed activation y (saved), mask = y * scale + shift > 0
+    ysave = torch.randn(M, Cout, generator=g).to(dev, BF)
+    cst = {n: ref[n] for n in ("mean", "rstd", "scale", "shift")}
+
+    def run_bwd(fused, rounds=2):
+        dz = torch.full((M, Cout), float("nan"), device=dev, dtype=BF)
+        dy = torch.full((M, Cout), float("nan"), device=dev, dtype=BF)
+        part = torch.full((nblk + 8, 3, Cout), float("nan"), device=dev)
+        coef = torch.full((3, Cout), float("nan"), device=dev)
+        bnr = {"y": ysave, "mode": 2, "part": part, **cst}
+        d = ops.make_conv_desc(x, wp, dz, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=Cout, taps=taps, Npad=Cout, tile_n=256, bnr=bnr)
+        bar = torch.zeros(L.load().simt_conv_fbn_words(C.byref(d)), device=dev, dtype=torch.int64)
+        if fused:
+            fd = _fbn(2, dy, bar, coef=coef)
+            d.fbn = C.addressof(fd)
+        for _ in range(rounds):
+            ops.conv_fprop_desc(d)
+            if not fused:
+                bd = ops.make_bn_bwd_desc(dz=dz, y=ysave, part=part, coef=coef, dy=dy, M=M, Cn=Cout, mask_mode=2,
+                                          reduce_done_nblk=L.load().simt_conv_mtiles(C.byref(d)), **cst)
+                L.call("simt_bn_bwd", C.byref(bd), ops.stream_ptr())
+        torch.cuda.synchronize()
+        return dy, coef, dz
+    dy_r, coef_r, _ = run_bwd(False)
+    dy_f, coef_f, dz_f = run_bwd(True)
+    assert torch.isfinite(dy_f.float()).all() and torch.equal(dy_f, dy_r), "backward dy: fused launch differs from dgrad + simt_bn_bwd"
+    assert torch.equal(coef_f, coef_r)
+    assert torch.isnan(dz_f.float()).all()                              # the raw dz is never written by the fused launch
+
+
+def _plan(dev, st, fused, **kw):
+    os.environ["SIMT_BN_GRID"] = "1" if fused else "0"
+    try:
+        p = {k: v.clone().to(dev) for k, v in st.items()}
+        return TrunkPlan(p, B4, 768, 768, multi_heads(19, 3, True), dtype=BF, train=True, **kw)
+    finally:
+        os.environ.pop("SIMT_BN_GRID")
+
+
+def test_fused_bn_whole_plan_bitwise_b4_768(dev):
+    """BASELINE configs[1]'s trainable net: forward + backward with the fused launches == without, bit for bit."""
+    st = so.recipe_state(so.state_shapes(19, 3, True), seed=1234, head_scale=8.0)
+    img, _ = so.synthetic_batch(B4, 768, 768, CD.numpy(), seed=1234)
+    res = []
+    for fused in (True, False):
+        tr = _plan(dev, st, fused)
+        ftags = [it.tag for it in tr.fwd_list.items if it.tag and it.tag.startswith("conv_igemm2_kernel<256, 5, 3, 1>")]
+        btags = [it.tag for it in tr.bwd_list.items if it.tag and it.tag.startswith("conv_igemm2_kernel<256, 5, 3, 1>")]
+        napply = sum(1 for it in tr.fwd_list.items if it.tag == "simt_bn_apply" or it.fn is L.load().simt_bn_apply)
+        if fused:
+            assert len(ftags) == 46 and len(btags) == 46, (len(ftags), len(btags))      # bn1 + bn2 of layer3's 23 Bottlenecks, both directions
+        else:
+            assert not ftags and not btags
+        out = tr.forward(img.to(dev))
+        g = torch.Generator().manual_seed(3)
+        for name in sorted(tr.dlogits):                 # a seeded upstream gradient of the heads' logits (live columns only)
+            t = tr.dlogits[name]
+            t.zero_()
+            t[:, :22].copy_((torch.randn(t.shape[0], 22, generator=g) * 1e-3).to(dev))
+        tr.backward()
+        torch.cuda.synchronize()
+        rec = tr.block_io[10]
+        res.append(dict(x1=out["x1"].clone(), x2=out["x2"].clone(), a1=rec["a1"].clone(), a2=rec["a2"].clone(), y2=rec["y2"].clone(),
+                        flat=tr.flat_grad.clone(), rm=tr.p["layer3.5.bn2.running_mean"].clone(), napply=napply))
+        del tr
+        torch.cuda.empty_cache()
+    a, b = res
+    assert a["napply"] == b["napply"] - 46
+    for k in ("x1", "x2", "a1", "a2", "y2", "flat", "rm"):
+        assert torch.isfinite(a[k].float()).all(), k
+        assert torch.equal(a[k], b[k]), f"{k}: plan with fused BatchNorm launches differs from the plan without"
+    assert a["flat"].abs().max().item() > 0
+
+
+def test_fused_bn_two_stream_soak(dev):
+    """60 full SimT iterations at the production size with the waiting launches on the main stream and the frozen forward / weight
+    gradients beside them on the side stream: completes (the kernel traps after ~2 s of waiting instead of hanging), and the
+    trajectory equals the unfused build's bit for bit (losses of the last step and a parameter checksum)."""
+    from simt_amd import model_spec as ms
+    from simt_amd.step import Hyper, SimTTrainer
+    K = 3
+    st = ms.trained_like_init(ms.state_shapes(19, K, True), seed=1234)
+    fst = ms.trained_like_init(ms.state_shapes(19, 0, False), seed=1234)
+    img, lab = ms.synthetic_batch(B4, 768, 768, CD.numpy(), seed=5, device=dev)
+    outs = []
+    for fused, steps in ((True, 60), (False, 60)):
+        os.environ["SIMT_BN_GRID"] = "1" if fused else "0"
+        try:
+            tr = SimTTrainer(st, fst, ms.ntm_init(19, K, 1), ms.ntm_init(19, K, 2), Hyper(open_classes=K, lr=2.5e-4, lr_T=6e-3), CD.numpy(),
+                             B4, 768, 768, dtype=BF, device=dev)
+        finally:
+            os.environ.pop("SIMT_BN_GRID")
+        assert tr.plan._fbn_on == fused
+        for it in range(steps):
+            tr.step(img, lab, it)
+        torch.cuda.synchronize()
+        outs.append((tr.lout.clone(), tr.params["layer3.7.conv2.weight"].clone(), tr.params["layer5.conv2d_list.0.weight"].clone()))
+        del tr
+        torch.cuda.empty_cache()
+    for x, y in zip(*outs):
+        assert torch.isfinite(x).all() and torch.equal(x, y)

@@ -379,7 +379,7 @@ def test_full_depth_r101_bf16_forward_b4_768(dev):
     p = {k: v.clone().to(dev) for k, v in st.items()}
     ev = TrunkPlan(p, B, H, W, multi_heads(19, K, True), dtype=BF, train=False)
     tags = {it.tag for it in ev.fwd_list.items}
-    assert any(t.startswith("conv_igemm2_kernel<256, 5, 3>") for t in tags) and "conv1x1_rows_kernel" in tags
+    assert any(t.startswith("conv_igemm2_kernel<256, 5, 3,") for t in tags) and "conv1x1_rows_kernel" in tags
     out = ev.forward(img.to(dev))
     torch.cuda.synchronize()
     e1, e2 = _nchw(out["x1"], 22), _nchw(out["x2"], 22)
@@ -401,7 +401,7 @@ def test_full_depth_r101_bf16_forward_b4_768(dev):
     assert flips.float().mean().item() < 2e-3
     tr = TrunkPlan(p, B, H, W, multi_heads(19, K, True), dtype=BF, train=True)
     tags = {it.tag for it in tr.fwd_list.items}
-    assert any(t.startswith("conv_igemm2_kernel<256, 5, 3>") for t in tags) and "conv1x1_stream_kernel" in tags
+    assert any(t.startswith("conv_igemm2_kernel<256, 5, 3,") for t in tags) and "conv1x1_stream_kernel" in tags
     out = tr.forward(img.to(dev))
     torch.cuda.synchronize()
     worst = 0.0

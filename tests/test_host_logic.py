@@ -42,7 +42,7 @@ def test_ctypes_struct_sizes_match_header():
     structs = {"simt_conv_desc": _lib.ConvDesc, "simt_wgrad_desc": _lib.WgradDesc, "simt_bn_bwd_desc": _lib.BnBwdDesc,
                "simt_head_desc": _lib.HeadDesc, "simt_ntm_inner_desc": _lib.NtmInnerDesc,
                "simt_ntm_post_desc": _lib.NtmPostDesc, "simt_sgd_desc": _lib.SgdDesc, "simt_tap_desc": _lib.TapDesc,
-               "simt_wgrad_reduce_job": _lib.WgradReduceJob}
+               "simt_wgrad_reduce_job": _lib.WgradReduceJob, "simt_fbn_desc": _lib.FbnDesc}
     prog = '#include <stdio.h>\n#include "simt_hip.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in structs) + "return 0;}"
     with tempfile.TemporaryDirectory() as td:
@@ -53,6 +53,7 @@ def test_ctypes_struct_sizes_match_header():
     sizes = dict(zip(out[::2], map(int, out[1::2])))
     for n, cls in structs.items():
         assert C.sizeof(cls) == sizes[n], f"{n}: ctypes {C.sizeof(cls)} vs C {sizes[n]}"
+    assert _lib.FBN_BAR_WORDS == int(re.search(r"#define SIMT_FBN_BAR_WORDS (\d+)", open(os.path.join(ROOT, "include", "simt_hip.h")).read()).group(1))
 
 
 def test_missing_library_fails_loudly(monkeypatch):
