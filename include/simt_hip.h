@@ -108,6 +108,9 @@ int simt_conv_wants_frag(const simt_conv_desc* d);
  * returns 0 (conv_igemm_kernel, fp32 parity + narrow outputs), 2 (conv_igemm2_kernel<bn, tm, nst>, the bf16 throughput kernel),
  * 4 (conv1x1_stream_kernel) or 5 (conv1x1_rows_kernel): the short-reduction / wide-output 1x1 shapes */
 int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int* nst);
+/* compile-time epilogue flavour of the bf16 v2 kernel the launch for d runs (the last template argument of conv_igemm2_kernel<bn, tm, nst,
+ * fbn, epi>): 0 generic (run-time flags), 1 BatchNorm statistics, 2 fused BatchNorm-backward reduce, 3 bias + ReLU; same results either way */
+int simt_conv_epilogue_flavour(const simt_conv_desc* d);
 /* number of pixel tiles (= statistics / bnr_part slots) the launch for d uses; 0 if d does not run on the bf16 v2 kernel */
 int simt_conv_mtiles(const simt_conv_desc* d);
 

@@ -102,6 +102,7 @@ SIGNATURES = {
     "simt_conv_fprop": (_I, [C.POINTER(ConvDesc), c_p]),
     "simt_conv_mtiles": (_I, [C.POINTER(ConvDesc)]),
     "simt_conv_fbn_ok": (_I, [C.POINTER(ConvDesc)]),
+    "simt_conv_epilogue_flavour": (_I, [C.POINTER(ConvDesc)]),
     "simt_conv_fbn_words": (_L, [C.POINTER(ConvDesc)]),
     "simt_conv_wants_frag": (_I, [C.POINTER(ConvDesc)]),
     "simt_conv_variant": (_I, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

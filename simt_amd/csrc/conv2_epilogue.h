@@ -23,13 +23,32 @@ __device__ __forceinline__ unsigned long long ld_gran(const unsigned long long* 
 // for ~2 s (two waiting launches of different processes starving each other: engine.py SIMT_BN_GRID), the kernel traps -- the process
 // dies loudly instead of hanging the GPU.  s_memrealtime = constant 100 MHz (s_memtime counts core clocks).
 // FBN = 1: the instantiation can also run the fused train-mode BatchNorm (simt_fbn_desc, a.fbn_mode 1 / 2): the tail of this function.
-template <int BN, int BM, int NT, int TN, int TM, int FBN = 0>
-__device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a, char* smem, f32x4 (&acc)[TN][TM], bool compute_wave, int wm, int wn,
+// EPI: compile-time epilogue flavour.  0 = generic (every option a run-time flag: ~4 000 instructions, of which a launch executes ~1 000 per
+// wave -- at two waves per SIMD that is 8 k clocks = 3.9 us of a 50 us conv, stamps in profiles/r04_bn_fusion.txt); 1 = BatchNorm
+// statistics only (train-mode forward convs); 2 = fused BatchNorm-backward reduce, mask from y * scale + shift (the dgrads of a
+// Bottleneck's conv3 / conv2); 3 = bias + ReLU (the frozen model's BN-folded convs).  The host picks the flavour from the descriptor
+// (launch_conv2_epi); every flavour computes exactly what the generic code computes for those flags.
+template <int BN, int BM, int NT, int TN, int TM, int FBN = 0, int EPI = 0>
+__device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem, f32x4 (&acc)[TN][TM], bool compute_wave, int wm, int wn,
                                                int tid, int lane, int m0, int n0, int m_end, int mt, int tile = 0) {
+  // the flags as this flavour sees them: constants for EPI != 0 (the compiler drops every other path)
+  struct Flags {
+    const Conv2KArgs& k;
+    __device__ __forceinline__ bool bias() const { return EPI == 0 ? k.bias != nullptr : EPI == 3; }
+    __device__ __forceinline__ bool res() const { return EPI == 0 ? k.res != nullptr : false; }
+    __device__ __forceinline__ bool res_bits() const { return EPI == 0 ? k.res_bits != nullptr : false; }
+    __device__ __forceinline__ bool relu() const { return EPI == 0 ? k.relu != 0 : EPI == 3; }
+    __device__ __forceinline__ bool mask() const { return EPI == 0 ? k.mask != nullptr : false; }
+    __device__ __forceinline__ bool stats() const { return EPI == 0 ? k.stats != nullptr : EPI == 1; }
+    __device__ __forceinline__ int bnr() const { return EPI == 0 ? k.bnr_mode : (EPI == 2 ? 2 : 0); }
+    __device__ __forceinline__ bool f32() const { return EPI == 0 ? k.out_f32 != 0 : false; }
+  };
+  const Conv2KArgs& a = a_;
+  const Flags fl{a_};
   constexpr int CP = BN * 2 + 8;                   // epilogue tile pitch in bytes (bf16 row + 8 B pad)
   // ---------------- epilogue ----------------
   // acc[j][i][e]: cout = n0 + wn*TN*16 + j*16 + (lane>>4)*4 + e ; pixel row = wm*TM*16 + i*16 + (lane&15)
-  if (a.out_f32) {
+  if (fl.f32()) {
     // fp32 result (tap-expanded ASPP GEMM): every accumulator quad is 16 contiguous bytes of one pixel's row; four lanes
     // cover a 64-B segment -> stored directly, no LDS round trip
     if (!compute_wave) return;
@@ -78,7 +97,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a, char* smem, 
       fbn_ticket = __hip_atomic_fetch_add(a.fbn_bar + (blockIdx.x & 7) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   struct Aux { uint4 res, by; unsigned rbits, ybits; };   // by: saved activation (bnr) or ReLU mask operand (VGG): exclusive
-  const bool aux = (a.res || a.bnr_mode || a.mask) && n < a.Nstore;
+  const bool aux = (fl.res() || fl.bnr() || fl.mask()) && n < a.Nstore;
   Aux q[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -86,15 +105,15 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a, char* smem, 
     q[it].rbits = q[it].ybits = 0xffu;
     const int m = m0 + rg + it * RPP;
     if (aux && rg + it * RPP < BM && m < m_end) {
-      if (a.res) {
+      if (fl.res()) {
         q[it].res = *(const uint4*)(a.res + (long)m * a.ldr + n);
-        if (a.res_bits) q[it].rbits = a.res_bits[((long)m * a.ldr + n) >> 3];
+        if (fl.res_bits()) q[it].rbits = a.res_bits[((long)m * a.ldr + n) >> 3];
       }
-      if (a.bnr_mode) {
+      if (fl.bnr()) {
         q[it].by = *(const uint4*)(a.bnr_y + (long)m * a.bnr_ld + n);
-        if (a.bnr_mode == 3) q[it].ybits = a.bnr_bits[((long)m * a.bnr_ld + n) >> 3];
+        if (fl.bnr() == 3) q[it].ybits = a.bnr_bits[((long)m * a.bnr_ld + n) >> 3];
       }
-      if (a.mask) q[it].by = *(const uint4*)(a.mask + (long)m * a.ldm + n);
+      if (fl.mask()) q[it].by = *(const uint4*)(a.mask + (long)m * a.ldm + n);
     }
   }
   __syncthreads();
@@ -105,13 +124,13 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a, char* smem, 
   if (n < a.Nstore) {
     float bias8[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = (a.bias && (n + e) < a.Cout) ? a.bias[n + e] : 0.f;
-    const bool plain = !a.bias && !a.res && !a.relu && !a.mask;
+    for (int e = 0; e < 8; ++e) bias8[e] = (fl.bias() && (n + e) < a.Cout) ? a.bias[n + e] : 0.f;
+    const bool plain = !fl.bias() && !fl.res() && !fl.relu() && !fl.mask();
     float bmu[8], brs[8], bsc[8], bsh[8];          // fused BN-backward reduce: per-channel constants of the BatchNorm whose dz this is
-    if (a.bnr_mode) {
+    if (fl.bnr()) {
       load8(a.bnr_mean + n, bmu);
       load8(a.bnr_rstd + n, brs);
-      if (a.bnr_mode == 2) { load8(a.bnr_scale + n, bsc); load8(a.bnr_shift + n, bsh); }
+      if (fl.bnr() == 2) { load8(a.bnr_scale + n, bsc); load8(a.bnr_shift + n, bsh); }
     }
     auto unpack = [](const uint4& qq, float* v) {
       v[0] = __uint_as_float(qq.x << 16); v[1] = __uint_as_float(qq.x & 0xffff0000u);
@@ -128,13 +147,13 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a, char* smem, 
       const uint2 lo = *(const uint2*)(sC + r * CP + vcol * 2);
       const uint2 hi = *(const uint2*)(sC + r * CP + vcol * 2 + 8);
       const uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      if (plain && !a.stats && !a.bnr_mode) {
+      if (plain && !fl.stats() && !fl.bnr()) {
         *(uint4*)(a.y + (long)m * a.ldy + n) = o;
         continue;
       }
       float v[8];
       unpack(o, v);
-      if (a.stats) {                               // forward: statistics of the stored value, before bias / residual / ReLU
+      if (fl.stats()) {                               // forward: statistics of the stored value, before bias / residual / ReLU
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
       }
@@ -143,17 +162,17 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a, char* smem, 
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bias8[e];
-        if (a.res) {
+        if (fl.res()) {
           float rv[8];
           unpack(cur.res, rv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += ((cur.rbits >> e) & 1u) ? rv[e] : 0.f;
         }
-        if (a.relu) {
+        if (fl.relu()) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
-        if (a.mask) {
+        if (fl.mask()) {
           float mv[8];
           unpack(cur.by, mv);
 #pragma unroll
@@ -161,7 +180,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a, char* smem, 
         }
         store8(a.y + (long)m * a.ldy + n, v);
       }
-      if (a.bnr_mode) {
+      if (fl.bnr()) {
         // backward: S1 = sum g, S2 = sum g * xhat on the value as stored (bf16), masked like the backward masks it
         if (!plain) {
 #pragma unroll
@@ -169,7 +188,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a, char* smem, 
         }
         float yv[8];
         unpack(cur.by, yv);
-        if (a.bnr_mode == 2) {
+        if (fl.bnr() == 2) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (yv[e] * bsc[e] + bsh[e]) > 0.f ? v[e] : 0.f;
         } else {
@@ -182,7 +201,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a, char* smem, 
     }
   }
   STAMP(5);
-  if (a.stats || a.bnr_mode) {
+  if (fl.stats() || fl.bnr()) {
     // combine the RPP row groups in fixed order: sR[rg][2][BN] floats behind the tile
     float* sR = (float*)(smem + BM * CP);
 #pragma unroll
@@ -216,7 +235,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a, char* smem, 
           unsigned long long* gs = a.fbn_slots + ((long)mt * NJg) * a.Cout + nn;
           st_gran(gs, tg | __float_as_uint(t1));
           st_gran(gs + a.Cout, tg | __float_as_uint(t2));
-        } else if (a.bnr_mode) {      // [m-tile][3][Cout]: S1, S2 and the (unused) second-BN row
+        } else if (fl.bnr()) {      // [m-tile][3][Cout]: S1, S2 and the (unused) second-BN row
           a.bnr_part[((long)mt * 3 + 0) * a.Cout + nn] = t1;
           a.bnr_part[((long)mt * 3 + 1) * a.Cout + nn] = t2;
           a.bnr_part[((long)mt * 3 + 2) * a.Cout + nn] = 0.f;

@@ -37,7 +37,8 @@ extern "C" int simt_debug_stamps(unsigned long long* out, int n) {
 // what they measured is in DESIGN.md section 9 and profiles/r03_conv_experiments.txt.  This file is the product kernel only.
 // FBN = 1: the same kernel with the fused train-mode BatchNorm tail compiled in (conv2_epilogue.h; a.fbn_mode selects forward / backward).
 // A separate instantiation so that the plain kernels keep their code (the main loop is sensitive to what surrounds it).
-template <int BN, int TMP, int NSTP, int FBN = 0>
+// EPI: compile-time epilogue flavour (conv2_epilogue.h): 0 generic, 1 statistics, 2 BatchNorm-backward reduce, 3 bias + ReLU.
+template <int BN, int TMP, int NSTP, int FBN = 0, int EPI = 0>
 __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(Conv2KArgs a) {
   constexpr int NT = 512, NST = NSTP;   // NST = 3: one workgroup per CU, two stages in flight; NST = 2 (short-K, output-
                                         // bound shapes): two workgroups per CU so one's epilogue overlaps the other's loads
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
   }
 
   STAMP(3);
-  conv2_epilogue<BN, BM, NT, TN, TM, FBN>(a, smem, acc, true, wm, wn, tid, lane, m0, n0, m_end, mt, tile);
+  conv2_epilogue<BN, BM, NT, TN, TM, FBN, EPI>(a, smem, acc, true, wm, wn, tid, lane, m0, n0, m_end, mt, tile);
 }
 
 #ifdef SIMT_ABLATION
@@ -204,22 +205,47 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
 bool simt_conv2_abl_launch(const Conv2KArgs& k, int bn, int tm, int nst, hipStream_t st, int* rc);
 int simt_conv2_abl_wants_frag(const simt_conv_desc* d);
 #endif
-template <int BN, int TM, int NST = 3, int FBN = 0>
-static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
+template <int BN, int TM, int NST = 3, int FBN = 0, int EPI = 0>
+static int launch_conv2e(const Conv2KArgs& k, hipStream_t st) {
   constexpr int WM = (BN == 64) ? 4 : 2;
   constexpr int BM = WM * TM * 16;
-#ifdef SIMT_ABLATION
-  if (!FBN) { int rc; if (simt_conv2_abl_launch(k, BN, TM, NST, st, &rc)) return rc; }
-#endif
   const size_t ring = NST * (size_t)(BM * 128 + BN * 128);
   const size_t epi = (size_t)BM * (BN * 2 + 8) + (size_t)(512 / (BN / 8)) * 2 * BN * 4 + (FBN ? 32 * 8 * 3 * sizeof(double) + 16 + 2 * BN * sizeof(float) : 0);
   const size_t lds = ring > epi ? ring : epi;
   static SimtLdsAttrCache attr_cache;
   if (simt_lds_attr_needed(&attr_cache, lds))
-    (void)hipFuncSetAttribute((const void*)conv_igemm2_kernel<BN, TM, NST, FBN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((conv_igemm2_kernel<BN, TM, NST, FBN>), dim3(k.ntiles_m * k.ntiles_n), dim3(512), lds, st, k);
+    (void)hipFuncSetAttribute((const void*)conv_igemm2_kernel<BN, TM, NST, FBN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((conv_igemm2_kernel<BN, TM, NST, FBN, EPI>), dim3(k.ntiles_m * k.ntiles_n), dim3(512), lds, st, k);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
+}
+
+// Which compile-time epilogue flavour computes exactly what the descriptor asks for (0: only the generic one does)
+static int conv2_flavour(const Conv2KArgs& k) {
+  static const int off = getenv("SIMT_CONV2_GENERIC_EPI") ? atoi(getenv("SIMT_CONV2_GENERIC_EPI")) : 0;     // A/B switch
+  if (off || k.out_f32 || k.res || k.mask || k.Nstore != k.Cout || k.Cout % 8) return 0;
+  if (k.stats && !k.bias && !k.relu && !k.bnr_mode) return 1;
+  if (k.bnr_mode == 2 && !k.stats && !k.bias && !k.relu) return 2;
+  if (k.bias && k.relu && !k.stats && !k.bnr_mode) return 3;
+  return 0;
+}
+
+template <int BN, int TM, int NST = 3>
+static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
+#ifdef SIMT_ABLATION
+  { int rc; if (!k.fbn_mode && simt_conv2_abl_launch(k, BN, TM, NST, st, &rc)) return rc; }
+#endif
+  if constexpr (NST == 3) {
+    const int e = conv2_flavour(k);
+    if constexpr (BN == 256) {
+      if (k.fbn_mode == 1) return launch_conv2e<BN, TM, NST, 1, 1>(k, st);
+      if (k.fbn_mode == 2) return launch_conv2e<BN, TM, NST, 1, 2>(k, st);
+    }
+    if (e == 1) return launch_conv2e<BN, TM, NST, 0, 1>(k, st);
+    if (e == 2) return launch_conv2e<BN, TM, NST, 0, 2>(k, st);
+    if (e == 3) return launch_conv2e<BN, TM, NST, 0, 3>(k, st);
+  }
+  return launch_conv2e<BN, TM, NST, 0, 0>(k, st);
 }
 
 // Pixel rows per tile: 128 (TM = 4) or, for the 2x4 wave layouts, up to 160 (TM = 5) when that saves a whole round of
@@ -298,6 +324,18 @@ extern "C" int simt_conv_wants_frag(const simt_conv_desc* d) {
   (void)d;
   return 0;
 #endif
+}
+
+// Which compile-time epilogue flavour (conv2_epilogue.h EPI) the launch for d runs: 0 generic, 1 statistics, 2 BatchNorm-backward reduce,
+// 3 bias + ReLU (reporting: the kernel name is conv_igemm2_kernel<bn, tm, nst, fbn, epi>)
+extern "C" int simt_conv_epilogue_flavour(const simt_conv_desc* d) {
+  int bn, tm, nst;
+  if (!d || simt_conv_variant(d, &bn, &tm, &nst) != 2 || nst != 3) return 0;
+  if (d->fbn) return d->fbn->mode == 1 ? 1 : 2;
+  Conv2KArgs k;
+  k.out_f32 = d->dtype_out == SIMT_F32; k.res = (const bf16_t*)d->res; k.mask = (const bf16_t*)d->mask; k.Nstore = d->Nstore; k.Cout = d->Cout;
+  k.stats = d->stats; k.bias = d->bias; k.relu = d->relu; k.bnr_mode = d->bnr_mode;
+  return conv2_flavour(k);
 }
 
 // Fused BatchNorm (simt_fbn_desc): the wide / medium 3-slot kernels, every workgroup co-resident (one workgroup per CU: the ring takes the LDS)
@@ -391,7 +429,6 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
   if (v.rowsk) return simt_conv_rows_launch(k, d->Npad, st);
   if (v.stream) return simt_conv_stream_launch(k, d->Npad, st);
   if (short_k) return tm == 5 ? launch_conv2<128, 5, 2>(k, st) : launch_conv2<128, 4, 2>(k, st);
-  if (tile_n == 256 && k.fbn_mode) return tm == 5 ? launch_conv2<256, 5, 3, 1>(k, st) : launch_conv2<256, 4, 3, 1>(k, st);
   if (tile_n == 256) return tm == 5 ? launch_conv2<256, 5>(k, st) : launch_conv2<256, 4>(k, st);
   if (tile_n == 128) return tm == 5 ? launch_conv2<128, 5>(k, st) : launch_conv2<128, 4>(k, st);
   return launch_conv2<64, 2>(k, st);

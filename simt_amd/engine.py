@@ -425,7 +425,8 @@ class TrunkPlan:
             # -DSIMT_ABLATION builds with SIMT_WDIRECT=1 only: weight operand from a fragment-ordered copy (csrc/experiments/conv_igemm2_abl.hip)
             d.w_frag = self._frag_twin(wp, npad).data_ptr()
             wd = 1
-        tag = (f"conv_igemm2_kernel<{bn_.value}, {tm_.value}, {nst_.value}, {fb}>{' [weights-direct experiment]' if wd else ''}" if gen == 2 else
+        epi = L.load().simt_conv_epilogue_flavour(C.byref(d)) if gen == 2 else 0
+        tag = (f"conv_igemm2_kernel<{bn_.value}, {tm_.value}, {nst_.value}, {fb}, {epi}>{' [weights-direct experiment]' if wd else ''}" if gen == 2 else
                "conv1x1_stream_kernel" if gen == 4 else "conv1x1_rows_kernel" if gen == 5 else
                f"conv_igemm_kernel<{tn[x.dtype]}, {tn[y.dtype]}, {tile}>")
         nbytes = (Bn * Hi * Wi * Cin + npad * len(taps) * Cin) * x.element_size() + M * Cout * y.element_size()

@@ -123,8 +123,8 @@ def test_fused_bn_whole_plan_bitwise_b4_768(dev):
     res = []
     for fused in (True, False):
         tr = _plan(dev, st, fused)
-        ftags = [it.tag for it in tr.fwd_list.items if it.tag and it.tag.startswith("conv_igemm2_kernel<256, 5, 3, 1>")]
-        btags = [it.tag for it in tr.bwd_list.items if it.tag and it.tag.startswith("conv_igemm2_kernel<256, 5, 3, 1>")]
+        ftags = [it.tag for it in tr.fwd_list.items if it.tag and it.tag.startswith("conv_igemm2_kernel<256, 5, 3, 1,")]
+        btags = [it.tag for it in tr.bwd_list.items if it.tag and it.tag.startswith("conv_igemm2_kernel<256, 5, 3, 1,")]
         napply = sum(1 for it in tr.fwd_list.items if it.tag == "simt_bn_apply" or it.fn is L.load().simt_bn_apply)
         if fused:
             assert len(ftags) == 46 and len(btags) == 46, (len(ftags), len(btags))      # bn1 + bn2 of layer3's 23 Bottlenecks, both directions
