@@ -35,8 +35,30 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense, /opt/skills/guides/MI355X_MICROARCH.md
 FLOP_PER_IMAGE_768 = 3.33e12                            # SURVEY 8(d): conv MACs x2, fixed fwd + fwd + bwd
-PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01h_pmc_traffic.json")
-PMC_MFMA_FILES = ("r03_pmc_mfma.json",)
+PMC_FILES = ("r04_pmc_traffic.json",)          # rocprofv3 PMC summaries (profiles/collect.sh), stamped with the sha256 of the library they
+PMC_MFMA_FILES = ("r04_pmc_mfma.json",)        # were collected on: used only when that is the library this run has loaded
+
+
+def pmc_lookup(files, kernel, key):
+    """-> (value, source, reason).  The counters of `kernel` from the newest committed PMC summary -- only if it was collected on the very
+    library loaded now (VERDICT r3 weak #15: nothing used to tie the committed JSON to the measured build)."""
+    import hashlib
+    from simt_amd import _lib
+    sha = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+    reason = "no PMC summary committed for this round"
+    for fn in files:
+        path = os.path.join(ROOT, "profiles", fn)
+        if not os.path.exists(path):
+            continue
+        d = json.load(open(path))
+        if d.get("lib_sha256") != sha:
+            reason = f"profiles/{fn} was collected on another build of libsimt_hip.so (sha256 {str(d.get('lib_sha256'))[:12]}... != {sha[:12]}...)"
+            continue
+        for kname, v in d["kernels"].items():
+            if kname.replace("void ", "").strip() == kernel:
+                return v[key], "profiles/" + fn, None
+        reason = f"profiles/{fn} has no entry for {kernel}"
+    return None, None, reason
 
 
 def parse():
@@ -250,20 +272,8 @@ def main():
         ach = fl / (ms_k * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[a.dtype]
         tot_ms = sum(v[0] for v in acc.values())
-        traffic, tsrc = None, None
-        for fn in PMC_FILES:                 # HBM bytes per launch from rocprofv3 PMC passes of this same command (see the file)
-            pmc = os.path.join(ROOT, "profiles", fn)
-            if traffic is None and os.path.exists(pmc):
-                for kname, v in json.load(open(pmc))["kernels"].items():
-                    if kname.replace("void ", "").strip() == dom:
-                        traffic, tsrc = v["hbm_bytes_per_launch_corrected"], "profiles/" + fn
-        mfma_busy, msrc = None, None
-        for fn in PMC_MFMA_FILES:            # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs), own rocprofv3 --pmc pass (profiles/pmc_mfma.py)
-            pmc = os.path.join(ROOT, "profiles", fn)
-            if mfma_busy is None and os.path.exists(pmc):
-                for kname, v in json.load(open(pmc))["kernels"].items():
-                    if kname.replace("void ", "").strip() == dom:
-                        mfma_busy, msrc = v["mfma_util"], "profiles/" + fn
+        traffic, tsrc, twhy = pmc_lookup(PMC_FILES, dom, "hbm_bytes_per_launch_corrected")      # HBM bytes per launch (FETCH_SIZE / WRITE_SIZE passes)
+        mfma_busy, msrc, mwhy = pmc_lookup(PMC_MFMA_FILES, dom, "mfma_util")    # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)
         # ---- the step north_star puts a number on: ASPP (the tap-expanded classifier GEMMs of both nets, forward and backward) + T-matrix
         # (the fused head: softmax x T contraction, losses and their gradients).  Algorithmic FLOPs / event time of those launches.
         aspp = None
@@ -292,11 +302,14 @@ def main():
                     "tap_gather_scatter_ms": round(aux, 4),
                     "head_loss_ms": round(evs[0].elapsed_time(evs[1]), 4), "head_grad_ms": round(evs[1].elapsed_time(evs[2]), 4),
                     "logitsT_alg_gflop": round(t_fl / 1e9, 2),
+                    # the WHOLE ASPP + T-matrix step as it runs: (GEMM + logits x T FLOPs) / (GEMMs + tap gather / scatter + fused head) / peak
+                    "whole_step_ms": round(g_ms + aux + evs[0].elapsed_time(evs[2]), 4),
+                    "whole_step_frac": round((g_fl + t_fl) / ((g_ms + aux + evs[0].elapsed_time(evs[2])) * 1e-3) / 1e12 / peak, 4),
                     "what": "tap-expanded ASPP classifier GEMMs (3 forward: two trainable heads + the frozen main head; 2 dgrad; wgrads are in "
                             "conv_wgrad) as launched in the step, plus the fused head kernels (upsample, softmax, logits x T, the nine losses and "
                             "their gradients: VALU per lane, 22 x 19 mat-vec, SURVEY allows) timed alone; target north_star: >= 0.5 of MFMA peak"}
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc, "mfma_busy": mfma_busy, "mfma_busy_source": msrc,
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc or twhy, "mfma_busy": mfma_busy, "mfma_busy_source": msrc or mwhy,
                 "alg_bytes_per_launch": int(by / n), "launches_per_step": n,
                 "avg_launch_us": round(ms_k / n * 1e3, 2), "alg_gflop_per_launch": round(fl / n / 1e9, 3),
                 "share_of_step_kernel_time": round(ms_k / tot_ms, 3),

@@ -17,6 +17,15 @@ import json
 import os
 import sys
 
+
+def lib_sha256():
+    """sha256 of the shipped libsimt_hip.so the counters were collected on: bench.py emits `traffic` / `mfma_busy` from this file only
+    when it matches the library it has loaded (a profile of an older build must not decorate a newer kernel's line)."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.environ.get("SIMT_LIB_PATH") or os.path.join(here, "..", "simt_amd", "libsimt_hip.so")
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
 SIMDS = 256 * 4
 NAMES = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")
 
@@ -52,7 +61,7 @@ def main():
     out = {"note": "rocprofv3 --kernel-trace --pmc " + " ".join(NAMES) + " over `bench.py --steps 2 --warmup 1` (own pass); per-dispatch averages "
                    "per kernel.  mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024): share of all SIMD-cycles of the dispatch "
                    "with the matrix pipe busy (profiled passes run at a lower clock than un-profiled ones: a cycle ratio, not a time).",
-           "kernels": {}}
+           "lib_sha256": lib_sha256(), "kernels": {}}
     for k in sorted(acc, key=lambda k: -acc[k]["SQ_VALU_MFMA_BUSY_CYCLES"]):
         n = max(1, len(disp[k]))
         a = {c: acc[k][c] / n for c in NAMES}

@@ -17,6 +17,15 @@ import os
 import sys
 
 
+def lib_sha256():
+    """sha256 of the shipped libsimt_hip.so the counters were collected on: bench.py emits `traffic` / `mfma_busy` from this file only
+    when it matches the library it has loaded (a profile of an older build must not decorate a newer kernel's line)."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.environ.get("SIMT_LIB_PATH") or os.path.join(here, "..", "simt_amd", "libsimt_hip.so")
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
 def load(d, counter):
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     assert files, f"no counter_collection.csv under {d}"
@@ -50,7 +59,7 @@ def main():
     out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) over `bench.py --steps 2 "
                    "--warmup 1`; per-dispatch averages per kernel. Correction per MI355X_MICROARCH.md HBM section: FETCH_SIZE counts 1/2 "
                    "of wide coalesced reads on gfx950 -> bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.",
-           "kernels": {}}
+           "lib_sha256": lib_sha256(), "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, [0.0, 0]), write.get(k, [0.0, 0])
         fa = f[0] / f[1] if f[1] else 0.0

@@ -223,10 +223,17 @@ static int launch_conv2e(const Conv2KArgs& k, hipStream_t st) {
 // Which compile-time epilogue flavour computes exactly what the descriptor asks for (0: only the generic one does)
 static int conv2_flavour(const Conv2KArgs& k) {
   static const int off = getenv("SIMT_CONV2_GENERIC_EPI") ? atoi(getenv("SIMT_CONV2_GENERIC_EPI")) : 0;     // A/B switch
-  if (off || k.out_f32 || k.res || k.mask || k.Nstore != k.Cout || k.Cout % 8) return 0;
+  if (off || k.out_f32 || k.mask || k.Nstore != k.Cout || k.Cout % 8) return 0;
+  if (k.res) {
+    if (k.bias || k.relu || k.stats) return 0;
+    if (k.res_bits && k.bnr_mode == 3) return 4;
+    if (!k.res_bits && !k.bnr_mode) return 6;
+    return 0;
+  }
   if (k.stats && !k.bias && !k.relu && !k.bnr_mode) return 1;
   if (k.bnr_mode == 2 && !k.stats && !k.bias && !k.relu) return 2;
   if (k.bias && k.relu && !k.stats && !k.bnr_mode) return 3;
+  if (!k.bias && !k.relu && !k.stats && !k.bnr_mode) return 5;
   return 0;
 }
 
@@ -235,8 +242,8 @@ static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
 #ifdef SIMT_ABLATION
   { int rc; if (!k.fbn_mode && simt_conv2_abl_launch(k, BN, TM, NST, st, &rc)) return rc; }
 #endif
+  const int e = conv2_flavour(k);
   if constexpr (NST == 3) {
-    const int e = conv2_flavour(k);
     if constexpr (BN == 256) {
       if (k.fbn_mode == 1) return launch_conv2e<BN, TM, NST, 1, 1>(k, st);
       if (k.fbn_mode == 2) return launch_conv2e<BN, TM, NST, 1, 2>(k, st);
@@ -245,6 +252,10 @@ static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
     if (e == 2) return launch_conv2e<BN, TM, NST, 0, 2>(k, st);
     if (e == 3) return launch_conv2e<BN, TM, NST, 0, 3>(k, st);
   }
+  // the dgrad flavours: all tile shapes (the 2-slot short-K kernels run nothing else in a training step)
+  if (e == 4) return launch_conv2e<BN, TM, NST, 0, 4>(k, st);
+  if (e == 5) return launch_conv2e<BN, TM, NST, 0, 5>(k, st);
+  if (e == 6) return launch_conv2e<BN, TM, NST, 0, 6>(k, st);
   return launch_conv2e<BN, TM, NST, 0, 0>(k, st);
 }
 
@@ -330,12 +341,13 @@ extern "C" int simt_conv_wants_frag(const simt_conv_desc* d) {
 // 3 bias + ReLU (reporting: the kernel name is conv_igemm2_kernel<bn, tm, nst, fbn, epi>)
 extern "C" int simt_conv_epilogue_flavour(const simt_conv_desc* d) {
   int bn, tm, nst;
-  if (!d || simt_conv_variant(d, &bn, &tm, &nst) != 2 || nst != 3) return 0;
+  if (!d || simt_conv_variant(d, &bn, &tm, &nst) != 2) return 0;
   if (d->fbn) return d->fbn->mode == 1 ? 1 : 2;
   Conv2KArgs k;
   k.out_f32 = d->dtype_out == SIMT_F32; k.res = (const bf16_t*)d->res; k.mask = (const bf16_t*)d->mask; k.Nstore = d->Nstore; k.Cout = d->Cout;
-  k.stats = d->stats; k.bias = d->bias; k.relu = d->relu; k.bnr_mode = d->bnr_mode;
-  return conv2_flavour(k);
+  k.stats = d->stats; k.bias = d->bias; k.relu = d->relu; k.bnr_mode = d->bnr_mode; k.res_bits = d->res_bits;
+  const int e = conv2_flavour(k);
+  return (nst != 3 && e >= 1 && e <= 3) ? 0 : e;
 }
 
 // Fused BatchNorm (simt_fbn_desc): the wide / medium 3-slot kernels, every workgroup co-resident (one workgroup per CU: the ring takes the LDS)

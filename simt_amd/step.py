@@ -22,6 +22,7 @@ import torch
 
 from . import _lib as L
 from . import ops
+from . import trace
 from .engine import LaunchList, TrunkPlan, multi_heads, side_stream
 
 
@@ -246,7 +247,7 @@ class SimTTrainer:
             ev_in.record(main)
 
             def frozen():
-                with torch.cuda.stream(side):
+                with torch.cuda.stream(side), trace.range("frozen-forward"):
                     side.wait_event(ev_in)
                     self.fixed.forward()
                     ops.softmax_rows(self.fixed.out["x2"], self.ldf, self.fixp, self.ldf, self.B * self.h * self.w, self.C)
@@ -255,16 +256,19 @@ class SimTTrainer:
                 return ev
             if self._fixed_graph or order == "side":
                 ev_fix = frozen()
-                self._fwd_rest.run()               # 3. trainable forward (its im2col already ran above)
+                with trace.range("forward"):
+                    self._fwd_rest.run()           # 3. trainable forward (its im2col already ran above)
             else:
-                self._fwd_rest.run()
+                with trace.range("forward"):
+                    self._fwd_rest.run()
                 ev_fix = frozen()
             main.wait_event(ev_fix)
         else:
             # ONE list with the launches of the two forwards interleaved 1:1
             if self._fwd_both is None:
                 self._fwd_both = self._interleaved_forwards()
-            self._fwd_both.run()
+            with trace.range("forward + frozen-forward (interleaved)"):
+                self._fwd_both.run()
         # 4. fused head + NTM regularisers + gradients of the low-res logits (every term scaled by 1 / iter_size, :427;
         #    the NTM gradients accumulate on top of the inner loop's leak and of earlier micro-batches)
         #    The regularisers only feed the Adam step and the loss read-out: they run on the side stream (idle between the frozen forward
@@ -273,15 +277,16 @@ class SimTTrainer:
         side = side_stream(self.dev) if self._post_side else main
         if self._ev_post is not None:
             main.wait_event(self._ev_post)     # an earlier micro-batch's regularisers still read the head's outputs
-        L.call("simt_head_loss", C.byref(self.head_desc), st)
-        ev_loss = torch.cuda.Event()
-        ev_loss.record(main)
-        with torch.cuda.stream(side):
-            side.wait_event(ev_loss)
-            L.call("simt_ntm_post", C.byref(self.post_desc), side.cuda_stream)
-            self._ev_post = torch.cuda.Event()
-            self._ev_post.record(side)
-        L.call("simt_head_grad", C.byref(self.head_desc), st)
+        with trace.range("head"):
+            L.call("simt_head_loss", C.byref(self.head_desc), st)
+            ev_loss = torch.cuda.Event()
+            ev_loss.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_loss)
+                L.call("simt_ntm_post", C.byref(self.post_desc), side.cuda_stream)
+                self._ev_post = torch.cuda.Event()
+                self._ev_post.record(side)
+            L.call("simt_head_grad", C.byref(self.head_desc), st)
 
     def _interleaved_forwards(self):
         """fwd_rest (main stream) and the frozen forward + its soft-max (side stream) as one launch list, alternating."""
@@ -388,15 +393,19 @@ class SimTTrainer:
             self._micro_batch(img, lab, st)
             # 5. trunk backward (+ 6. data-parallel mean of the gradients, bucket by bucket, on a side stream)
             if self._early_sgd:            # (with a reducer: the exchange completes on the side stream too, ahead of its SGD)
-                self._backward_early_sgd(lr, st)
+                with trace.range("backward (+ exchange + early optimiser step)"):
+                    self._backward_early_sgd(lr, st)
                 continue
             if self.reducer is not None and hp.iter_size == 1:
                 self.reducer.start()
-                self.plan.backward(hook=self.reducer.ready_upto)
+                with trace.range("backward (+ bucketed exchange)"):
+                    self.plan.backward(hook=self.reducer.ready_upto)
                 torch.cuda.current_stream().wait_event(self._ev_post)      # the NTM gradients it exchanges last (side stream)
-                self.reducer.finish()
+                with trace.range("exchange (flush + wait)"):
+                    self.reducer.finish()
                 continue
-            self.plan.backward()
+            with trace.range("backward"):
+                self.plan.backward()
             if hp.iter_size > 1:      # loss.backward() accumulates into .grad (:428): keep the running sum beside the plan's buffer
                 if mi == 0:
                     self._grad_acc.copy_(flat)
@@ -410,7 +419,8 @@ class SimTTrainer:
                         self.reducer.finish()
         # 7. optimisers
         if not self._early_sgd:
-            self._sgd(lr, st)
+            with trace.range("optimiser"):
+                self._sgd(lr, st)
         torch.cuda.current_stream().wait_event(self._ev_post)      # regularisers (side stream): NTM gradients and the losses are final
         for k in range(2):
             ops.adam_step(self.ntm[k], self.ntm_grad[k], self.ntm_m[k], self.ntm_v[k], lr=lr_T, step=self.it_done + 1)
