@@ -281,8 +281,11 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
 
 // QT / CT: the channel counts as compile-time constants (0 = taken from the geometry at run time): every `j < Q` predicate of the unrolled
 // per-channel loops folds away -- with run-time counts they were a third of the instructions and spilled SGPR masks into VGPR lanes.
+#ifndef SIMT_HEAD_P1_WAVES
+#define SIMT_HEAD_P1_WAVES 2      // 3 waves per SIMD need 21 spilled VGPRs (335-348 us); 2 waves, no scratch: 352-375 us (profiles/tools/ab_head.py)
+#endif
 template <int QM, int QT, int CT>
-__global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(HeadArgs a) {
+__global__ __launch_bounds__(256, (QM <= 24 ? SIMT_HEAD_P1_WAVES : 2)) void head_pass1_kernel(HeadArgs a) {
   const HeadGeom g = a.g;
   const int Q = QT ? QT : g.Q, C = CT ? CT : g.C, QC = Q * C;
   constexpr int CM = CT ? (CT + 3) / 4 * 4 : QM;
@@ -307,7 +310,11 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
 
   const long P = (long)g.B * g.H * g.W;
   const long ngroups = (P + 255) / 256;
-  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  // Logical block id: blocks that share an XCD (b, b + 8, ...) take CONSECUTIVE logical ids, so the pixel groups of one XCD lie in a few bands
+  // of the image and the low-res maps they gather from (14.5 MB in all) stay in that XCD's 4 MB L2 (round 3: 202 MB of fabric reads per launch
+  // for ~30 MB of operands).  Group -> partial-sum slot assignment is unchanged: bitwise the same results.
+  const int lbid = xcd_remap(blockIdx.x, gridDim.x);
+  for (long grp = lbid; grp < ngroups; grp += gridDim.x) {
     const long p = grp * 256 + tid;
     const bool live = p < P;
     int b = 0, y = 0, x = 0;
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(256, (QM <= 24 ? 3 : 2)) void head_pass1_kernel(Hea
     if (lane == 0) sRed[wave * NSCAL + i] = s;
   }
   __syncthreads();
-  float* part = a.part + (long)blockIdx.x * (NSCAL + 2 * QC);
+  float* part = a.part + (long)lbid * (NSCAL + 2 * QC);
   if (tid < NSCAL) part[tid] = sRed[tid] + sRed[NSCAL + tid] + sRed[2 * NSCAL + tid] + sRed[3 * NSCAL + tid];
   for (int i = tid; i < 2 * QC; i += 256)
     part[NSCAL + i] = sdT[i] + sdT[2 * QC + i] + sdT[4 * QC + i] + sdT[6 * QC + i];
@@ -631,7 +638,8 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
   float* sL1 = (float*)(sI0 + 256);          // [256] its right-tap weight
   int* sStart = (int*)(sL1 + 256);           // [XR_MAX + 1] first pixel of the chunk whose low-res column is >= xl_lo + k
   const int tid = threadIdx.x;
-  const int b = blockIdx.x / g.H, y = blockIdx.x % g.H;
+  const int lbid = xcd_remap(blockIdx.x, gridDim.x);      // an XCD's blocks take consecutive image rows (L2 locality of the gathers; pass 1)
+  const int b = lbid / g.H, y = lbid % g.H;
   for (int i = tid; i < QC; i += 256) { sT[i] = a.mode == 0 ? a.T1[i] : 0.f; sT[QC + i] = a.mode == 0 ? a.T2[i] : 0.f; }
   for (int i = tid; i < 2 * g.w * Q; i += 256) sAcc[i] = 0.f;
   const float* o = a.hout;

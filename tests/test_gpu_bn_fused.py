@@ -126,6 +126,10 @@ def test_fused_bn_whole_plan_bitwise_b4_768(dev):
         ftags = [it.tag for it in tr.fwd_list.items if it.tag and it.tag.startswith("conv_igemm2_kernel<256, 5, 3, 1,")]
         btags = [it.tag for it in tr.bwd_list.items if it.tag and it.tag.startswith("conv_igemm2_kernel<256, 5, 3, 1,")]
         napply = sum(1 for it in tr.fwd_list.items if it.tag == "simt_bn_apply" or it.fn is L.load().simt_bn_apply)
+        # no launch of the production plan runs the generic (run-time-flag, spilling) epilogue of the 2-slot short-K conv: tests/test_host_logic.py
+        # test_no_scratch_in_production_kernels exempts exactly those two instantiations
+        import re
+        assert not [it.tag for lst in (tr.fwd_list, tr.bwd_list) for it in lst.items if it.tag and re.match(r"conv_igemm2_kernel<128, \d, 2, 0, 0>", it.tag)]
         if fused:
             assert len(ftags) == 46 and len(btags) == 46, (len(ftags), len(btags))      # bn1 + bn2 of layer3's 23 Bottlenecks, both directions
         else:

@@ -221,3 +221,22 @@ def test_snapshot_keeper_rotation_and_atomic_save(tmp_path):
     finally:
         torch.save = real_save
     assert "GTA5_BAPA_warmup_iter5000.pth" in os.listdir(tmp_path)            # the previous snapshot survived the failed save
+
+
+def test_no_scratch_in_production_kernels():
+    """no kernel a production plan launches may use scratch memory (spilled VGPRs or stack arrays).  The shipped
+    library's gfx950 code objects are disassembled (tests/_codeobj.py) and every kernel is checked for scratch_* instructions; the only
+    ones allowed to have any are the generic FALLBACK instantiations no BASELINE configuration runs: the head kernels for class counts
+    other than (Q, C) = (22, 19) / (25, 19), and the run-time-flag epilogue of the 2-slot short-K conv (training plans launch its
+    compile-time flavours 4-7: asserted by launch tag in tests/test_gpu_prod_shapes.py)."""
+    import __graft_entry__ as ge
+    import _codeobj
+    from simt_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        ge.build()
+    res = _codeobj.kernels_with_scratch(_lib.LIB_PATH)
+    assert len(res) > 100 and any("conv_igemm2_kernel<256, 5, 3, 0, 1>" in k for k in res) and any("head_pass1_kernel<24, 22, 19>" in k for k in res)
+    allowed = ("conv_igemm2_kernel<128, 5, 2, 0, 0>", "conv_igemm2_kernel<128, 4, 2, 0, 0>",
+               "head_pass1_kernel<24, 0, 0>", "head_pass1_kernel<40, 0, 0>", "head_pass2_kernel<40, 0, 0>")
+    bad = {k: v for k, v in res.items() if v and not any(a in k for a in allowed)}
+    assert not bad, f"kernels with scratch_* instructions: {bad}"
