@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: 4; vgg: 8)")
     ap.add_argument("--size", type=int, nargs=2, default=None, metavar=("H", "W"), help="default 768 768; v3: 512 1024; vgg: 512 512")
     ap.add_argument("--open-classes", type=int, default=None, help="default 3; v3: 6")
+    ap.add_argument("--v3-layers", type=int, nargs=3, default=[3, 4, 6], metavar=("L1", "L2", "L3"),
+                    help="--model v3: Bottlenecks of layer1..3.  3 4 6 = model/deeplabv3.py as written (a torchvision ResNet-50 cut after layer3); "
+                         "3 4 23 = the ResNet-101 depth BASELINE.json's configs[3] NAMES ('DeepLabv3-ResNet101')")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -175,8 +178,11 @@ def main():
             from simt_amd.step_single import SimTSingleTrainer
             if a.model == "v3":
                 from simt_amd.engine_v3 import v3_state_shapes
-                st = ms.kaiming_init(v3_state_shapes(19, K, True), seed=1234)
-                fst = ms.kaiming_init(v3_state_shapes(19, 0, False), seed=1234)
+                lay = tuple(a.v3_layers)
+                st = ms.kaiming_init(v3_state_shapes(19, K, True, layers=lay), seed=1234)
+                fst = ms.kaiming_init(v3_state_shapes(19, 0, False, layers=lay), seed=1234)
+                return SimTSingleTrainer(a.model, st, fst, ms.ntm_init(19, K, 2), hp, cd, a.batch, H, W, dtype=dtype, device=dev, process_group=pg,
+                                         arch={"layers": lay})
             else:
                 from simt_amd.engine_vgg import vgg_state_shapes
                 st = ms.kaiming_init(vgg_state_shapes(19 + K), seed=1234)
@@ -355,7 +361,8 @@ def main():
             flop_img = FLOP_PER_IMAGE_768 * (H * W) / (768.0 * 768.0)
         else:                           # algorithmic conv FLOPs of the three launch lists (frozen forward, forward, backward) per image
             flop_img = sum(it.flops for lst in tr.timed_lists() for it in lst.items if it.fn is not None) / a.batch
-        names = {"v2": ("DeepLabv2-R101+SimT", "DeepLabv2-ResNet101"), "v3": ("DeepLabv3-R50+SimT", "DeepLabv3 (torchvision-style ResNet-50 to layer3 + ASSP)"),
+        names = {"v2": ("DeepLabv2-R101+SimT", "DeepLabv2-ResNet101"), "v3": (("DeepLabv3-R50+SimT", "DeepLabv3 (torchvision-style ResNet-50 to layer3 + ASSP; model/deeplabv3.py as written)") if tuple(a.v3_layers) == (3, 4, 6)
+                        else (f"DeepLabv3-R{'101' if tuple(a.v3_layers) == (3, 4, 23) else '?'}+SimT", f"DeepLabv3 (ResNet layers {tuple(a.v3_layers)} to layer3 + ASSP)")),
                  "vgg": ("DeepLab-VGG16+SimT", "DeepLab-VGG16")}[a.model]
         cfg = {"v2": "configs[1]" if world == 1 else "configs[2]", "v3": "configs[3]", "vgg": "configs[4]"}[a.model]
         mode = ("bf16 storage / fp32 accumulate = throughput mode (parity claims 'loss within 1e-4' are made by the fp32 mode of the same "

@@ -11,13 +11,13 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra-passes"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prod -- $CMD > $OUT/prod.log 2>&1
-SIMT_SINGLE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -- $CMD > $OUT/serial.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prod -- $CMD > $OUT/prod.log 2>&1
+SIMT_SINGLE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -- $CMD > $OUT/serial.log 2>&1
 CMD2="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extra-passes"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD2 > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD2 > $OUT/write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD2 > $OUT/fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD2 > $OUT/write.log 2>&1
 # MFMA utilisation (north_star: "rocprof HBM GB/s and MFMA utilisation"): its own counter pass, program directly after `--`
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- $CMD2 > $OUT/mfma.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- $CMD2 > $OUT/mfma.log 2>&1
 cd $ROOT
 python3 profiles/pmc_traffic.py $OUT/fetch $OUT/write > $OUT/pmc_traffic.json 2> $OUT/pmc.err
 python3 profiles/pmc_mfma.py $OUT/mfma > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err

@@ -176,15 +176,29 @@ def _tags(tr):
     return out
 
 
-@pytest.mark.parametrize("model", ["v3", "vgg"])
+@pytest.mark.parametrize("model", ["v3", "v3_r101", "vgg"])
 def test_config3_config4_full_size_bf16_step(dev, model):
     """configs[3] (DeepLabv3 + SimT K=6, B=4, 512x1024) / configs[4] (DeepLab-VGG16 + SimT K=3, B=8 per GPU, 512x512), bf16."""
     from simt_amd.step_single import SimTSingleTrainer
-    if model == "v3":
+    arch = None
+    if model.startswith("v3"):
+        # "v3": model/deeplabv3.py:9-21 as written (a torchvision ResNet-50 cut after layer3).  "v3_r101": the depth BASELINE.json's
+        # configs[3] NAMES ("DeepLabv3-ResNet101"): layers (3, 4, 23), same file otherwise (VERDICT r3 missing #4)
         from simt_amd.engine_v3 import v3_state_shapes
         K, B, H, W = 6, 4, 512, 1024
-        st = ms.kaiming_init(v3_state_shapes(19, K, True), seed=1234)
-        fst = ms.kaiming_init(v3_state_shapes(19, 0, False), seed=1234)
+        lay = (3, 4, 23) if model == "v3_r101" else (3, 4, 6)
+        arch = {"layers": lay}
+        model = "v3"
+        st = ms.kaiming_init(v3_state_shapes(19, K, True, layers=lay), seed=1234)
+        fst = ms.kaiming_init(v3_state_shapes(19, 0, False, layers=lay), seed=1234)
+        if lay != (3, 4, 6):
+            # 30 residual blocks of Kaiming-initialised convs under EVAL-mode BatchNorm with identity running statistics (the frozen model)
+            # double the activation variance per block: logits ~1e7, an Anchor term ~1e14 in fp32 and bf16 alike.  A checkpoint does not do
+            # that; damp the residual branches (conv3 x 0.2, the zero-init-residual idea) so that the comparison below is about the kernels
+            for d_ in (st, fst):
+                for k_ in d_:
+                    if k_.endswith("conv3.weight"):
+                        d_[k_] = d_[k_] * 0.2
     else:
         from simt_amd.engine_vgg import vgg_state_shapes
         K, B, H, W = 3, 8, 512, 512
@@ -195,9 +209,11 @@ def test_config3_config4_full_size_bf16_step(dev, model):
     keys = ["total", "loss_p", "loss_y", "place", "convex", "volume", "anchor"]
     res = {}
     for dtype in (torch.bfloat16, torch.float32):
-        tr = SimTSingleTrainer(model, st, fst, ms.ntm_init(19, K, 2), hp, CD.numpy(), B, H, W, dtype=dtype, device=dev)
+        tr = SimTSingleTrainer(model, st, fst, ms.ntm_init(19, K, 2), hp, CD.numpy(), B, H, W, dtype=dtype, device=dev, arch=arch)
         if dtype == torch.bfloat16:
             tags = _tags(tr)
+            if arch and arch["layers"] == (3, 4, 23):
+                assert sum(1 for n in tr.params if ".layer3." in n and n.endswith("conv2.weight")) == 23
             if model == "v3":
                 # the stride-16 maps (M = 4*32*64 = 8192 pixels): wide layers must run the narrow column tiles (engine._conv)
                 narrow = [(t, s) for (t, s) in tags if s.startswith("M8192 ") and re.match(r"conv_igemm2_kernel<(64|128), ", t)
@@ -216,7 +232,7 @@ def test_config3_config4_full_size_bf16_step(dev, model):
             assert torch.isfinite(tr.params[n]).all(), n
         if dtype == torch.bfloat16:
             # bitwise repeatable: a second trainer from the same state, same batch -> identical losses, labels and parameters
-            tr2 = SimTSingleTrainer(model, st, fst, ms.ntm_init(19, K, 2), hp, CD.numpy(), B, H, W, dtype=dtype, device=dev)
+            tr2 = SimTSingleTrainer(model, st, fst, ms.ntm_init(19, K, 2), hp, CD.numpy(), B, H, W, dtype=dtype, device=dev, arch=arch)
             tr2.step(img, lab, 0)
             l1 = tr2.losses()
             assert all(l0[k] == l1[k] for k in keys), (l0, l1)
