@@ -54,9 +54,13 @@ def pmc_lookup(files, kernel, key):
         if d.get("lib_sha256") != sha:
             reason = f"profiles/{fn} was collected on another build of libsimt_hip.so (sha256 {str(d.get('lib_sha256'))[:12]}... != {sha[:12]}...)"
             continue
-        for kname, v in d["kernels"].items():
-            if kname.replace("void ", "").strip() == kernel:
-                return v[key], "profiles/" + fn, None
+        # `kernel` may name a family ("conv_igemm2_kernel<256, 5, 3, *>": every epilogue flavour of one tile shape): dispatch-weighted average
+        pref = kernel[:-2] if kernel.endswith("*>") else None
+        hits = [v for kname, v in d["kernels"].items()
+                if (kname.replace("void ", "").strip().startswith(pref) if pref else kname.replace("void ", "").strip() == kernel)]
+        if hits:
+            n = sum(v["dispatches"] for v in hits)
+            return sum(v[key] * v["dispatches"] for v in hits) / max(n, 1), "profiles/" + fn, None
         reason = f"profiles/{fn} has no entry for {kernel}"
     return None, None, reason
 
@@ -272,9 +276,19 @@ def main():
             for (tag, shape), v in sorted(shp.items(), key=lambda kv: -kv[1][0]):
                 print(f"{tag:28s} {shape:44s} n={v[3]:3d} total {v[0]:7.3f} ms  avg {v[0] / v[3] * 1e3:8.1f} us  "
                       f"{v[1] / (v[0] * 1e-3) / 1e12:7.1f} TF/s  {v[2] / (v[0] * 1e-3) / 1e9:7.0f} GB/s(alg)", file=sys.stderr)
-        conv = {k: v for k, v in acc.items() if k.startswith("conv_igemm")}
-        dom = max(conv, key=lambda k: conv[k][0])
-        ms_k, fl, by, n = conv[dom]
+        # dominant kernel = the conv tile shape with the largest total time, over ALL its compile-time epilogue flavours (round 4 split every
+        # shape into flavours <bn, tm, nst, fused-BN, epilogue>; the family is what round 3 reported as one instantiation)
+        fam = {}
+        for k, v in acc.items():
+            if k.startswith("conv_igemm"):
+                f = (", ".join(k.split(", ")[:3]) + ", *>") if k.startswith("conv_igemm2_kernel<") else k
+                a_ = fam.setdefault(f, [0.0, 0.0, 0.0, 0])
+                for i in range(4):
+                    a_[i] += v[i]
+        dom = max(fam, key=lambda k: fam[k][0])
+        ms_k, fl, by, n = fam[dom]
+        flav = {k: {"ms": round(v[0], 3), "us": round(v[0] / v[3] * 1e3, 1), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1), "n": v[3]}
+                for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0]) if dom.endswith("*>") and k.startswith(dom[:-2])}
         ach = fl / (ms_k * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[a.dtype]
         tot_ms = sum(v[0] for v in acc.values())
@@ -319,6 +333,7 @@ def main():
                 "alg_bytes_per_launch": int(by / n), "launches_per_step": n,
                 "avg_launch_us": round(ms_k / n * 1e3, 2), "alg_gflop_per_launch": round(fl / n / 1e9, 3),
                 "share_of_step_kernel_time": round(ms_k / tot_ms, 3),
+                "flavours": flav,      # <..., fused BatchNorm (0 | 1), epilogue (0 generic, 1 statistics, 2 BN-backward reduce, 3 bias + ReLU, 4-7 dgrads)>
                 "classes": {k: {"ms": round(v[0], 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[1] else None,
                                 "n": v[3]} for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])[:16]}}
 
