@@ -63,6 +63,10 @@ for (Cin, Cout, k, dil) in ((256, 256, 3, 2), (1024, 256, 1, 1)):
         def show(nm, v):
             v = np.sort(v)
             print(f"   {nm:44s} min {v[0]:7d}  p10 {v[len(v) // 10]:7d}  median {v[len(v) // 2]:7d}  p90 {v[len(v) * 9 // 10]:7d}  max {v[-1]:7d}  clocks")
+        if not fused:
+            show("start -> addressing done", b[:, 1] - b[:, 0])
+            show("addressing done -> first stage landed", b[:, 2] - b[:, 1])
+            show("first stage landed -> main loop done", b[:, 3] - b[:, 2])
         show("main loop done -> tile in LDS", b[:, 4] - b[:, 3])
         show("tile in LDS -> rows stored", b[:, 5] - b[:, 4])
         show("rows stored -> tile sums combined", b[:, 6] - b[:, 5])

@@ -69,6 +69,13 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
   const int a_cg = c_pos ^ (((tid >> 3) >> 1) & 7);          // (row>>1)&7 only depends on tid>>3 because NT/8 = 64 is even
   unsigned a_off[A_IT];
   unsigned long long a_ok[A_IT];
+  // The tap offsets as scalars, fetched ONCE with wide scalar loads (round 4: stamps showed 14.7 k clocks = 6.7 us between kernel start and
+  // "addressing done" for a 3x3 conv -- the validity loop below re-read a.dy[t] / a.dx[t] from the kernel arguments with a dependent
+  // s_load + wait per tap and row, 27 round trips).  Nine pairs cover every 1x1 / 3x3 conv; longer tap lists keep the loop.
+  int tdy[9], tdx[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { tdy[t] = a.dy[t]; tdx[t] = a.dx[t]; }
+  const int ntaps = a.ntaps;
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int row = i * (NT / 8) + (tid >> 3);
@@ -82,9 +89,17 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
       const int iy = oy * a.stride, ix = ox * a.stride;
       a_off[i] = (unsigned)(((b * a.H + iy) * a.W + ix)) * (unsigned)a.pix_bytes + (unsigned)(a_cg * 16);
       unsigned long long msk = 0ull;
-      for (int t = 0; t < a.ntaps; ++t) {
-        const int yy = iy + a.dy[t], xx = ix + a.dx[t];
-        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) msk |= (1ull << t);
+      if (ntaps <= 9) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int yy = iy + tdy[t], xx = ix + tdx[t];
+          if (t < ntaps && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) msk |= (1ull << t);
+        }
+      } else {
+        for (int t = 0; t < ntaps; ++t) {
+          const int yy = iy + a.dy[t], xx = ix + a.dx[t];
+          if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) msk |= (1ull << t);
+        }
       }
       a_ok[i] = msk;
     }
