@@ -67,6 +67,18 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
   // ---- hoisted A-gather metadata: chunk q = i*NT + tid -> row = q>>3, position q&7
   const int c_pos = tid & 7;
   const int a_cg = c_pos ^ (((tid >> 3) >> 1) & 7);          // (row>>1)&7 only depends on tid>>3 because NT/8 = 64 is even
+  unsigned b_off[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int row = i * (NT / 8) + (tid >> 3);
+    b_off[i] = (unsigned)(n0 + row) * (unsigned)a.wrow_bytes + (unsigned)(a_cg * 16);
+  }
+  // Stage 0's weight pieces need no pixel addressing: they leave NOW, so that their L2 latency runs under the address arithmetic below
+  // (stamps, round 4: 2.1-3.4 us between "addressing done" and "first stage landed").  Issue order B(0), A(0), A(1), B(1): the counted wait of
+  // the first K step (<= one stage outstanding) still retires exactly stage 0.
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i)
+    __builtin_amdgcn_global_load_lds(GPTR(a.w + b_off[i]), LPTR(smem + A_BYTES + (i * NT + wave * 64) * 16), 16, 0, 0);
   unsigned a_off[A_IT];
   unsigned long long a_ok[A_IT];
   // The tap offsets as scalars, fetched ONCE with wide scalar loads (round 4: stamps showed 14.7 k clocks = 6.7 us between kernel start and
@@ -104,17 +116,11 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
       a_ok[i] = msk;
     }
   }
-  unsigned b_off[B_IT];
-#pragma unroll
-  for (int i = 0; i < B_IT; ++i) {
-    const int row = i * (NT / 8) + (tid >> 3);
-    b_off[i] = (unsigned)(n0 + row) * (unsigned)a.wrow_bytes + (unsigned)(a_cg * 16);
-  }
   const char* zsrc = a.zero + a_cg * 16;
   const bool a_tail_wave = !A_TAIL || wave < (BM * 8 - (A_IT - 1) * NT) / 64;
 
   int ld_tap = 0, ld_kc = 0;                     // position of the NEXT stage to be issued: (64-channel chunk, tap), taps innermost
-  auto issue = [&](int buf) {
+  auto issue = [&](int buf, bool weights = true) {
     const int toff = a.toff[ld_tap] + ld_kc * 128;
     char* sbase = smem + buf * STAGE;
 #pragma unroll
@@ -129,9 +135,10 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
     // top): 3x3 convs 1-2.5 % faster, the step 26.39 -> 26.10 ms.  Weights are packed K-contiguous as (tap, channel): this stage's 64 columns
     // start at (tap * chunks + chunk) * 128 bytes.  (Compile-time only: the same order behind a run-time flag cost every launch 17-28 %.)
     const unsigned wk = (unsigned)(ld_tap * a.kc_per_tap + ld_kc) * 128u;
+    if (weights) {
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      __builtin_amdgcn_global_load_lds(GPTR(a.w + (b_off[i] + wk)), LPTR(sbase + A_BYTES + (i * NT + wave * 64) * 16), 16, 0, 0);
+      for (int i = 0; i < B_IT; ++i)
+        __builtin_amdgcn_global_load_lds(GPTR(a.w + (b_off[i] + wk)), LPTR(sbase + A_BYTES + (i * NT + wave * 64) * 16), 16, 0, 0);
     }
     if (++ld_tap == a.ntaps) { ld_tap = 0; ++ld_kc; }
   };
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][j], xf[s][i], acc[j][i], 0, 0, 0);
   };
   STAMP(1);
-  issue(0);
+  issue(0, false);                               // (its weight pieces are already in flight)
   if (NST == 3 && nk > 1) issue(1);
   int buf = 0;
   if (wave < 4) {
