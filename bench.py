@@ -368,6 +368,21 @@ def main():
                                       "pixels_with_confidence_label": int(hout[6].item()), "pixels": P,
                                       "what": "same workload with ms.trained_like_init weights (non-trivial BN statistics, scaled "
                                               "classifiers): both --Threshold-high and --Threshold-low branches are populated"}
+        # ---- NOT the headline: the same iteration with the backward stopped at the input of layer3.  The SimT stage's optimiser never lists
+        # conv1 / layer1 / layer2 (model/deeplab_multi.py:194-237), so their weight gradients -- which the reference's autograd computes and the
+        # headline above computes too -- are dead values: the trajectory is bit-identical without them (tests/test_gpu_iteration.py).  Reported
+        # so that the price of matching the reference's work item for item is on the line.
+        if not a.skip_unapplied_grads:
+            del tr
+            torch.cuda.empty_cache()
+            hp_skip = Hyper(open_classes=K, lr=6e-4, lr_T=6e-3, skip_unapplied_grads=True)
+            init = ms.reference_init
+            tr = SimTTrainer(init(ms.state_shapes(19, K, True), seed=1234), init(ms.state_shapes(19, 0, False), seed=1234), ms.ntm_init(19, K, 1),
+                             ms.ntm_init(19, K, 2), hp_skip, cd, a.batch, H, W, dtype=dtype, device=dev, process_group=pg)
+            dt4, _ = timed(tr, resident(1234 + rank), n2, 3)
+            extra["skip_unapplied_grads_pass"] = {"value": round(a.batch * world * n2 / dt4, 3), "ms_per_step": round(dt4 / n2 * 1e3, 3), "steps": n2,
+                                                  "what": "NOT the headline: backward stopped at layer3's input (the gradients of conv1 / layer1 / layer2 "
+                                                          "are never applied by the SimT stage; identical parameter trajectory); Hyper(skip_unapplied_grads=True)"}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(K, a.cpu_iters)
