@@ -25,6 +25,10 @@
 #define SIMT_ROWS_ABL 0
 #endif
 
+#ifndef SIMT_ROWS_PF1
+#define SIMT_ROWS_PF1 6
+#endif
+
 namespace {
 
 
@@ -81,7 +85,7 @@ struct Aux { uint4 res, by; unsigned rbits, ybits; };
 enum { FL_GEN = 0, FL_GEN_AUX = 1, FL_STATS = 2, FL_BRR = 3, FL_BNR = 4 };
 
 template <int KS, int TM, int D, int FL, int NSW, int NCW, int TN>
-__global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
+__global__ __launch_bounds__((NCW + NSW) * 64, (KS == 32 ? 2 : 3)) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
   using g = Geo<KS, TM, D, NSW, NCW, TN>;
   constexpr int WCOLS = TN * 16;                               // output channels per compute wave
   constexpr int RGS = g::RGS, NS = g::NS, NC = g::NC, BN = g::BN, CP = g::CP, VPR = g::VPR;
@@ -242,7 +246,7 @@ __global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2
       constexpr int KSN = (SIMT_ROWS_ABL & 1) ? 0 : KS;
       // pixel fragments: requested PF k-steps ahead into PF + 1 rotating register sets (an LDS round trip under load is longer than the
       // 4 MFMAs of one k-step)
-      constexpr int PF = TM == 2 ? 2 : 1;
+      constexpr int PF = TM == 2 ? 2 : TM == 1 ? SIMT_ROWS_PF1 : 1;     // (TM = 1, Cin = 1024: one MFMA per k-step -- a deeper fragment queue)
       bf16x8 xf[PF + 1][TM];
       const unsigned st_addr = (unsigned)(size_t)LPTR(st);
       const unsigned ad01[2] = {st_addr + (unsigned)(((0 + kq) ^ sw) << 4), st_addr + (unsigned)(((4 + kq) ^ sw) << 4)};   // even / odd k-steps
@@ -254,10 +258,11 @@ __global__ __launch_bounds__((NCW + NSW) * 64, 3) void conv1x1_rows_kernel(Conv2
         }
       };
       auto landed = [&](bf16x8* f, int younger) {              // f is complete: everything but the `younger` most recent LDS operations has returned
-        static_assert(TM == 2 || TM == 4, "fragment blocks");
-#define SIMT_LANDED(N) if (younger == N) { if (TM == 2) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0]), "+v"(f[1])); \
+        static_assert(TM == 1 || TM == 2 || TM == 4, "fragment blocks");
+#define SIMT_LANDED(N) if (younger == N) { if (TM == 1) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0])); \
+                                             else if (TM == 2) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0]), "+v"(f[1])); \
                                              else asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2 % TM]), "+v"(f[3 % TM])); }
-        SIMT_LANDED(0) SIMT_LANDED(2) SIMT_LANDED(4)
+        SIMT_LANDED(0) SIMT_LANDED(1) SIMT_LANDED(2) SIMT_LANDED(3) SIMT_LANDED(4) SIMT_LANDED(5) SIMT_LANDED(6)
 #undef SIMT_LANDED
       };
       if (MMA) {
@@ -645,7 +650,7 @@ int launch_rows(Conv2KArgs k, int npad, hipStream_t st) {
   k.ntiles_n = npad / g::BN;
   k.ntiles_m = (k.M + 127) / 128;
   const int nwg = k.ntiles_m * k.ntiles_n;
-  const int cap = NCW == 8 ? 256 : 512;                        // persistent: one or two (NCW = 4: 384 threads) workgroups per CU
+  const int cap = (NCW == 8 || g::LDS > 80 * 1024) ? 256 : 512;    // persistent: one or two (NCW = 4: 384 threads) workgroups per CU
   const int G = nwg < cap ? nwg : cap;
   static SimtLdsAttrCache attr_cache;
   if (simt_lds_attr_needed(&attr_cache, g::LDS))
@@ -668,7 +673,8 @@ bool simt_conv_rows_eligible(const simt_conv_desc* d) {
   if (d->dtype_in != SIMT_BF16 || d->dtype_out != SIMT_BF16 || d->ntaps != 1 || d->dy[0] != 0 || d->dx[0] != 0) return false;
   if (d->stride != 1 || d->H != d->Ho || d->W != d->Wo) return false;          // dense pixel rows
   if (d->mask || (d->bnr_mode != 0 && d->bnr_mode != 3)) return false;         // fused BN-backward reduce: bit-mask flavour only
-  if (d->Cin != 64 && d->Cin != 128 && d->Cin != 256 && d->Cin != 512) return false;
+  if (d->Cin != 64 && d->Cin != 128 && d->Cin != 256 && d->Cin != 512 && d->Cin != 1024) return false;
+  if (d->Cin == 1024 && (d->bnr_mode || d->res)) return false;                 // long reduction: the forward flavours only (statistics / bias + ReLU)
   if (d->Cin == 512 && d->bnr_mode) return false;                              // measured: 214 us here vs 203 us on conv_igemm2_kernel<128, 4, 2>
   if (d->Npad % 256 != 0) return false;
   const long M = (long)d->B * d->Ho * d->Wo, lim = 1l << 32;                   // 32-bit byte offsets in the store waves
@@ -693,6 +699,10 @@ int simt_conv_rows_launch(Conv2KArgs k, int npad, hipStream_t st) {
     if (f_brr) return launch_rows<8, 2, D256, FL_BRR, SW, CW>(k, npad, st);
     if (f_bnr) return launch_rows<8, 2, D256, FL_BNR, SW, CW>(k, npad, st);
     return aux ? launch_rows<8, 2, 6, FL_GEN_AUX, 4, 8>(k, npad, st) : launch_rows<8, 2, 6, FL_GEN, 4, 8>(k, npad, st);
+  }
+  if (cin == 1024) {                                           // 16 channels per wave (128 weight registers), 16-row stages of whole 2-KB rows
+    if (f_stats) return launch_rows<32, 1, 4, FL_STATS, 1, 4, 1>(k, npad, st);
+    return launch_rows<32, 1, 4, FL_GEN, 1, 4, 1>(k, npad, st);
   }
   if (cin == 512) {                                            // 16 channels per wave: 128-column workgroups, 8 + 2 waves
     if (f_stats) return launch_rows<16, 2, 3, FL_STATS, 2, 8, 1>(k, npad, st);

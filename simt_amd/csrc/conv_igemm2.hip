@@ -325,7 +325,13 @@ static Conv2Variant pick_variant(const simt_conv_desc* d) {
 #ifdef SIMT_ABLATION
   { static const int no_short = getenv("SIMT_NO_SHORTK") ? atoi(getenv("SIMT_NO_SHORTK")) : 0; if (no_short) { Conv2Variant w; w.stream = false; w.rowsk = false; w.tile_n = d->tile_n; w.nst = 3; w.ntiles_n = d->Npad / w.tile_n; w.tm = 4; pick_rows(M, w.ntiles_n, w.tile_n != 64, &w.rows, &w.tm); if (w.tile_n == 64) w.tm = 2; return w; } }
 #endif
-  v.rowsk = short_k && rows_enabled() && simt_conv_rows_eligible(d);
+  // Round 4 experiment (SIMT_ROWS_1024=1; default OFF): the long-reduction 1x1 convs on dense rows (conv1 of layer 3 / 4: 1024 -> 256 / 512)
+  // as whole 2-KB pixel rows streamed past register-resident weights (conv1x1_rows_kernel<32, 1, 4, ..., 1, 4, 1>: 128 weight registers per
+  // wave leave room for 4 compute waves and 64-column workgroups only).  Parity green, and SLOWER: 45.6 us against 29.6-31.9 on
+  // conv_igemm2_kernel<256, 5, 3> (one MFMA per k-step and wave, four workgroups re-reading every pixel row), the step +0.45 ms.
+  static const int rows1024 = getenv("SIMT_ROWS_1024") ? atoi(getenv("SIMT_ROWS_1024")) : 0;
+  const bool long_rows = rows1024 && d->ntaps == 1 && d->Cin == 1024 && d->Cout <= 512 && d->dtype_out == SIMT_BF16;
+  v.rowsk = (short_k || long_rows) && rows_enabled() && simt_conv_rows_eligible(d);
   if (v.rowsk) { v.stream = false; v.tile_n = 256; v.nst = 6; v.ntiles_n = d->Npad / 256; v.tm = 2; v.rows = 128; return v; }
   v.stream = short_k && stream_enabled() && simt_conv_stream_eligible(d);
   if (v.stream) { v.tile_n = 128; v.nst = 3; v.ntiles_n = d->Npad / 128; v.tm = 4; v.rows = 128; return v; }

@@ -61,6 +61,7 @@ CONV_CASES = [
     ("fixed l3.conv3 256->1024 bias+res+relu", B4, HW, HW, 256, 1024, 1, 1, 1, "bias_res_relu", ROWS),
     ("l3.conv1 dgrad 256->1024 + res_bits + bnr3", B4, HW, HW, 256, 1024, 1, 1, 1, "res_bits_bnr3", ROWS),
     ("l3.conv1 1024->256 + stats", B4, HW, HW, 1024, 256, 1, 1, 1, "stats", (256, 5, 3)),
+    ("fixed l3.conv1 1024->256 bias+relu", B4, HW, HW, 1024, 256, 1, 1, 1, "bias_relu", (256, 5, 3)),
     ("l3.conv3 dgrad 1024->256 + bnr2", B4, HW, HW, 1024, 256, 1, 1, 1, "bnr2", (256, 5, 3)),
     ("l4.conv1 2048->512", B4, HW, HW, 2048, 512, 1, 1, 1, "stats", (256, 5, 3)),
     ("l4.conv3 512->2048", B4, HW, HW, 512, 2048, 1, 1, 1, "stats", ROWS),
