@@ -114,8 +114,12 @@ def test_config0_fp32_iteration_vs_oracle_512(dev):
         p0, pg, pr = st[n].double(), tr.params[n].detach().cpu().double(), orc.st[n].detach().double()
         du_ref = (pr - p0).norm().item()
         rel = (pg - pr).norm().item() / max(du_ref, 1e-30)
-        print(f"{n}: |update| {du_ref:.3e}, gpu-vs-oracle / |update| {rel:.3e}")
+        ratio = (pg - p0).norm().item() / max(du_ref, 1e-30)
+        print(f"{n}: |update| {du_ref:.3e}, gpu-vs-oracle / |update| {rel:.3e}, |update_gpu| / |update_ref| {ratio:.4f}")
         assert rel <= _update_bound(n), f"{n}: parameter update differs from the oracle's by {rel:.3e} of its norm"
+        # the SCALE of the update is well conditioned even where single entries are not (the 0.15 bound alone would let a
+        # 10 % gradient-scale bug -- a wrong listing multiplicity, lr group or 1 / iter_size -- through): norms within 3 %
+        assert abs(ratio - 1.0) <= 0.03, f"{n}: |update_gpu| / |update_ref| = {ratio:.4f}"
 
 
 def test_g8b_wellconditioned_reference_iterations(dev):
@@ -160,9 +164,11 @@ def test_g8b_wellconditioned_reference_iterations(dev):
             r = d["param_samples"][it][i][: len(g)].astype(np.float64)
             upd = np.linalg.norm(r - before[k][: len(g)])
             rel = np.linalg.norm(g - r) / max(upd, 1e-30)
-            print(f"   {k}: |cumulative update| {upd:.3e}, gpu-vs-reference / |update| {rel:.3e}")
+            ratio = np.linalg.norm(g - before[k][: len(g)]) / max(upd, 1e-30)
+            print(f"   {k}: |cumulative update| {upd:.3e}, gpu-vs-reference / |update| {rel:.3e}, norm ratio {ratio:.4f}")
             if it == 0:          # (iteration 1 is printed only: two chaotic trajectories, measured up to 0.56 of the cumulative update)
                 assert rel <= _update_bound(k), f"it {it} {k}: {rel:.3e}"
+                assert abs(ratio - 1.0) <= 0.03, f"it {it} {k}: |update_gpu| / |update_ref| = {ratio:.4f} (scale of the update)"
     np.testing.assert_allclose(tr.ntm[0].cpu().numpy(), d["ntm1"], atol=1e-4)
     np.testing.assert_allclose(tr.wraw[0].cpu().numpy(), d["w1"], atol=1e-4 * (1 + np.abs(d["w1"]).max()))
 
