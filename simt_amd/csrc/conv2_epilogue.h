@@ -28,7 +28,7 @@ __device__ __forceinline__ unsigned long long ld_gran(const unsigned long long* 
 // statistics only (train-mode forward convs); 2 = fused BatchNorm-backward reduce, mask from y * scale + shift (the dgrads of a
 // Bottleneck's conv3 / conv2); 3 = bias + ReLU (the frozen model's BN-folded convs); 4 = bit-masked residual + BatchNorm-backward reduce with
 // the bit mask (the dx GEMM of a Bottleneck); 5 = nothing (plain dgrads); 6 = residual only; 7 = BatchNorm-backward reduce with the bit mask + an optional
-// plain residual (the tap-expanded heads' dgrads into layer 3 / 4's output gradient).  The host picks the flavour from the descriptor
+// plain residual (the tap-expanded heads' dgrads into layer 3 / 4's output gradient); 8 = ReLU mask operand only (the dgrads of the BatchNorm-free VGG trunk).  The host picks the flavour from the descriptor
 // (launch_conv2_epi); every flavour computes exactly what the generic code computes for those flags.
 template <int BN, int BM, int NT, int TN, int TM, int FBN = 0, int EPI = 0>
 __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem, f32x4 (&acc)[TN][TM], bool compute_wave, int wm, int wn,
@@ -40,7 +40,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
     __device__ __forceinline__ bool res() const { return (EPI == 0 || EPI == 7) ? k.res != nullptr : (EPI == 4 || EPI == 6); }
     __device__ __forceinline__ bool res_bits() const { return EPI == 0 ? k.res_bits != nullptr : EPI == 4; }
     __device__ __forceinline__ bool relu() const { return EPI == 0 ? k.relu != 0 : EPI == 3; }
-    __device__ __forceinline__ bool mask() const { return EPI == 0 ? k.mask != nullptr : false; }
+    __device__ __forceinline__ bool mask() const { return EPI == 0 ? k.mask != nullptr : EPI == 8; }
     __device__ __forceinline__ bool stats() const { return EPI == 0 ? k.stats != nullptr : EPI == 1; }
     __device__ __forceinline__ int bnr() const { return EPI == 0 ? k.bnr_mode : (EPI == 2 ? 2 : (EPI == 4 || EPI == 7) ? 3 : 0); }
     __device__ __forceinline__ bool f32() const { return EPI == 0 ? k.out_f32 != 0 : false; }

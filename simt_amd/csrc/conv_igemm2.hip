@@ -245,7 +245,8 @@ static int launch_conv2e(const Conv2KArgs& k, hipStream_t st) {
 // Which compile-time epilogue flavour computes exactly what the descriptor asks for (0: only the generic one does)
 static int conv2_flavour(const Conv2KArgs& k) {
   static const int off = getenv("SIMT_CONV2_GENERIC_EPI") ? atoi(getenv("SIMT_CONV2_GENERIC_EPI")) : 0;     // A/B switch
-  if (off || k.out_f32 || k.mask || k.Nstore != k.Cout || k.Cout % 8) return 0;
+  if (off || k.out_f32 || k.Nstore != k.Cout || k.Cout % 8) return 0;
+  if (k.mask) return (!k.res && !k.bias && !k.relu && !k.stats && !k.bnr_mode) ? 8 : 0;
   if (k.bnr_mode == 3 && !k.res_bits && !k.bias && !k.relu && !k.stats) return 7;       // (res or not: a run-time pointer test)
   if (k.res) {
     if (k.bias || k.relu || k.stats) return 0;
@@ -280,6 +281,7 @@ static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
   if (e == 5) return launch_conv2e<BN, TM, NST, 0, 5>(k, st);
   if (e == 6) return launch_conv2e<BN, TM, NST, 0, 6>(k, st);
   if (e == 7) return launch_conv2e<BN, TM, NST, 0, 7>(k, st);
+  if (e == 8) return launch_conv2e<BN, TM, NST, 0, 8>(k, st);
   return launch_conv2e<BN, TM, NST, 0, 0>(k, st);
 }
 
