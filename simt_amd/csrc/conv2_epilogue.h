@@ -6,12 +6,6 @@
 #include "conv2_common.h"
 #include <type_traits>
 
-// write-through / L1-bypassing accesses for bytes handed between workgroups of ONE launch (global_store / global_load ... sc1)
-__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long ld_sc1(const unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 // 8-byte {value, tag} granules: ONE naturally aligned write-through store / L1-bypassing load each (never torn)
 __device__ __forceinline__ void st_gran(unsigned long long* p, unsigned long long v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -29,7 +23,7 @@ __device__ __forceinline__ unsigned long long ld_gran(const unsigned long long* 
 // Bottleneck's conv3 / conv2); 3 = bias + ReLU (the frozen model's BN-folded convs); 4 = bit-masked residual + BatchNorm-backward reduce with
 // the bit mask (the dx GEMM of a Bottleneck); 5 = nothing (plain dgrads); 6 = residual only; 7 = BatchNorm-backward reduce with the bit mask + an optional
 // plain residual (the tap-expanded heads' dgrads into layer 3 / 4's output gradient); 8 = ReLU mask operand only (the dgrads of the BatchNorm-free VGG trunk).  The host picks the flavour from the descriptor
-// (launch_conv2_epi); every flavour computes exactly what the generic code computes for those flags.
+// (conv2_flavour in conv_igemm2.hip); every flavour computes exactly what the generic code computes for those flags.
 template <int BN, int BM, int NT, int TN, int TM, int FBN = 0, int EPI = 0>
 __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem, f32x4 (&acc)[TN][TM], bool compute_wave, int wm, int wn,
                                                int tid, int lane, int m0, int n0, int m_end, int mt, int tile = 0) {
