@@ -182,3 +182,32 @@ def test_fused_bn_two_stream_soak(dev):
         torch.cuda.empty_cache()
     for x, y in zip(*outs):
         assert torch.isfinite(x).all() and torch.equal(x, y)
+
+
+def test_fused_bn_under_hipgraph_replay(dev):
+    """The fused launches draw their generation from device-side ticket counters, so a captured launch list replays correctly: the production
+    step with the backward (and forward) captured as hipGraphs (SIMT_GRAPHS=2 / 1) gives the eager default's trajectory bit for bit."""
+    from simt_amd import model_spec as ms
+    from simt_amd.step import Hyper, SimTTrainer
+    K = 3
+    st = ms.trained_like_init(ms.state_shapes(19, K, True), seed=1234)
+    fst = ms.trained_like_init(ms.state_shapes(19, 0, False), seed=1234)
+    img, lab = ms.synthetic_batch(B4, 768, 768, CD.numpy(), seed=5, device=dev)
+    outs = []
+    for env in ({}, {"SIMT_GRAPHS": "2"}, {"SIMT_GRAPHS": "1", "SIMT_BN_GRID": "1"}):
+        os.environ.update(env)
+        try:
+            tr = SimTTrainer(st, fst, ms.ntm_init(19, K, 1), ms.ntm_init(19, K, 2), Hyper(open_classes=K, lr=2.5e-4, lr_T=6e-3), CD.numpy(),
+                             B4, 768, 768, dtype=BF, device=dev)
+        finally:
+            for k in env:
+                os.environ.pop(k)
+        assert tr.plan._fbn_dirs == ((1, 2) if env.get("SIMT_BN_GRID") == "1" else (2,))
+        for it in range(5):
+            tr.step(img, lab, it)
+        torch.cuda.synchronize()
+        outs.append((tr.lout.clone(), tr.params["layer3.7.conv2.weight"].clone()))
+        del tr
+        torch.cuda.empty_cache()
+    for o in outs[1:]:
+        assert torch.isfinite(o[0]).all() and torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
