@@ -93,10 +93,12 @@ typedef struct simt_fbn_desc {
   float momentum, eps;
   float *mean, *rstd, *scale, *shift;     /* forward: OUT [C] each (the backward reads them) */
   float* coef;                            /* backward: OUT [3][C] = (sum g, sum g*xhat, 0) / count */
+  float *dgamma, *dbeta;                  /* backward, trainable affine (model/deeplabv3.py's BatchNorm): OUT [C] = sum g*xhat, sum g; or NULL */
 } simt_fbn_desc;
 int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);
-/* 1 if simt_conv_fprop can run d with a fused BatchNorm (d->fbn): bf16 v2 kernel with 256- or 128-column tiles and a grid that is
- * co-resident on the current device (tiles <= compute units); d->fbn itself need not be set yet */
+/* 1 if simt_conv_fprop can run d with a fused BatchNorm (d->fbn): bf16 v2 kernel with the 3-slot ring -- 256-column tiles in both directions,
+ * 128- / 64-column tiles (the small maps of model/deeplabv3.py) in the backward direction (d->bnr_mode 2) -- and a grid that is co-resident on
+ * the current device (tiles <= compute units); d->fbn itself need not be set yet */
 int simt_conv_fbn_ok(const simt_conv_desc* d);
 long simt_conv_fbn_words(const simt_conv_desc* d);      /* uint64 words simt_fbn_desc.work needs for d (0 if !simt_conv_fbn_ok) */
 /* 1 if the launch for d would use d->w_frag when given (conv_igemm2_kernel<256, *, 3>: Npad tiles of 256, long reductions) */

@@ -35,7 +35,7 @@ class FbnDesc(C.Structure):
     """simt_fbn_desc (include/simt_hip.h): the train-mode BatchNorm behind a conv, fused into the producing launch."""
     _fields_ = [("mode", i32), ("ldo", i32), ("out", c_p), ("work", c_p), ("gamma", c_p), ("beta", c_p),
                 ("running_mean", c_p), ("running_var", c_p), ("momentum", f32), ("eps", f32),
-                ("mean", c_p), ("rstd", c_p), ("scale", c_p), ("shift", c_p), ("coef", c_p)]
+                ("mean", c_p), ("rstd", c_p), ("scale", c_p), ("shift", c_p), ("coef", c_p), ("dgamma", c_p), ("dbeta", c_p)]
 
 
 class WgradDesc(C.Structure):

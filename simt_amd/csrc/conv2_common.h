@@ -37,7 +37,7 @@ struct Conv2KArgs {
   const float *fbn_gamma, *fbn_beta;
   float *fbn_rmean, *fbn_rvar;
   float fbn_momentum, fbn_eps;
-  float *fbn_mean, *fbn_rstd, *fbn_scale, *fbn_shift, *fbn_coef;
+  float *fbn_mean, *fbn_rstd, *fbn_scale, *fbn_shift, *fbn_coef, *fbn_dgamma, *fbn_dbeta;
 };
 
 #ifdef SIMT_ABLATION

@@ -353,6 +353,8 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
               a.fbn_coef[c] = c1;
               a.fbn_coef[a.Cout + c] = c2;
               a.fbn_coef[2 * a.Cout + c] = 0.f;
+              if (a.fbn_dbeta) a.fbn_dbeta[c] = (float)t[0];        // (bn_bwd_finalize_kernel's d beta / d gamma: trainable affine)
+              if (a.fbn_dgamma) a.fbn_dgamma[c] = (float)t[1];
             }
           }
         }

@@ -270,8 +270,8 @@ static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
   if constexpr (NST == 3) {
     if constexpr (BN == 256) {
       if (k.fbn_mode == 1) return launch_conv2e<BN, TM, NST, 1, 1>(k, st);
-      if (k.fbn_mode == 2) return launch_conv2e<BN, TM, NST, 1, 2>(k, st);
     }
+    if (k.fbn_mode == 2) return launch_conv2e<BN, TM, NST, 1, 2>(k, st);
     if (e == 1) return launch_conv2e<BN, TM, NST, 0, 1>(k, st);
     if (e == 2) return launch_conv2e<BN, TM, NST, 0, 2>(k, st);
     if (e == 3) return launch_conv2e<BN, TM, NST, 0, 3>(k, st);
@@ -397,11 +397,12 @@ static int device_cus() {
 extern "C" int simt_conv_fbn_ok(const simt_conv_desc* d) {
   int bn, tm, nst;
   if (!d || d->dtype_in != SIMT_BF16 || d->dtype_out != SIMT_BF16 || simt_conv_variant(d, &bn, &tm, &nst) != 2) return 0;
-  if (!(bn == 256 && nst == 3)) return 0;
+  if (nst != 3 || !(bn == 256 || d->bnr_mode == 2)) return 0;      // (the 128- / 64-column tiles are instantiated for the backward only)
   const Conv2Variant v = pick_variant(d);
   const int M = d->B * d->Ho * d->Wo;
   const long nwg = (long)((M + v.rows - 1) / v.rows) * v.ntiles_n;
-  return d->Cout % 8 == 0 && d->Nstore == d->Cout && nwg <= device_cus() && (M + 127) / 128 <= 384;     // (slots per owner thread: MAXS)
+  // (every 8 channels need an owner workgroup: tiny maps have fewer tiles than that; slots per owner thread: MAXS)
+  return d->Cout % 8 == 0 && d->Nstore == d->Cout && nwg <= device_cus() && nwg >= (d->Cout + 7) / 8 && (M + 127) / 128 <= 384;
 }
 
 extern "C" long simt_conv_fbn_words(const simt_conv_desc* d) {
@@ -445,6 +446,7 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
     k.fbn_gamma = f->gamma; k.fbn_beta = f->beta; k.fbn_rmean = f->running_mean; k.fbn_rvar = f->running_var;
     k.fbn_momentum = f->momentum; k.fbn_eps = f->eps;
     k.fbn_mean = f->mean; k.fbn_rstd = f->rstd; k.fbn_scale = f->scale; k.fbn_shift = f->shift; k.fbn_coef = f->coef;
+    k.fbn_dgamma = f->dgamma; k.fbn_dbeta = f->dbeta;
   }
   k.out_f32 = d->dtype_out == SIMT_F32;
   if (k.out_f32) SIMT_CHECK(!d->bias && !d->res && !d->relu && !d->stats && d->Nstore % 4 == 0 && d->ldy % 4 == 0);

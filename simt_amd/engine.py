@@ -385,7 +385,7 @@ class TrunkPlan:
         """alg_k: algorithmic reduction length per output element (defaults to ntaps*Cin; the K-padded head dgrad and
         the stem pass their true value) -> algorithmic FLOPs = 2 * M * Cout * alg_k.
         fbn: ask for the train-mode BatchNorm behind this conv to be fused into the launch (simt_fbn_desc; dict(mode, out, bname[,
-        coef])).  Granted only where the launch is one co-resident round of the chip (simt_conv_fbn_ok): the returned descriptor then has
+        coef, affine])).  Granted only where the launch is one co-resident round of the chip (simt_conv_fbn_ok): the returned descriptor then has
         `.fbn` set and the caller must NOT add the separate BatchNorm launches."""
         wp, tile, npad = wp_info
         # Few pixels (DeepLabv3's stride-16 maps: M = 8 192 at 512 x 1024): 128-row x 256-column tiles are 64 workgroups on 256 CUs, each
@@ -417,6 +417,9 @@ class TrunkPlan:
                 fd.mean, fd.rstd, fd.scale, fd.shift = (sb[k_].data_ptr() for k_ in ("mean", "rstd", "scale", "shift"))
             else:
                 fd.coef = fbn["coef"].data_ptr()
+                if fbn.get("affine"):              # trainable affine (engine_v3): d gamma / d beta leave the owners of the fused launch
+                    bname = fbn["bname"]
+                    fd.dgamma, fd.dbeta = self.grads[bname + ".weight"].data_ptr(), self.grads[bname + ".bias"].data_ptr()
             d.fbn = C.addressof(fd)
             d._fbn_keep = fd                       # the descriptor is read at every launch
             fb = 1

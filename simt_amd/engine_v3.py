@@ -318,9 +318,20 @@ class V3Plan(TrunkPlan):
                                None, ops.dt_code(dt))
             row += cout
         daf = self.new(M, ac)
-        self._conv(b, dl, (wt, tile, npad), daf, Bn=B, Hi=h, Wi=w, Cin=ck, Ho=h, Wo=w, Cout=ac, taps=[(0, 0)], alg_k=Q)
         dyf = self.new(M, ac)
-        self._bnb(b, dz=daf, y=self.yf, bname="assp.bnf", dy=dyf, M=M, Cn=ac, mask_mode=2)
+        coef = self.buf("bnb.coef", 3 * 2048, dtype=torch.float32)
+
+        def conv_bnb(x, wi, dz, y, bname, dy, **kw):
+            """dgrad GEMM + the backward of the (ReLU-masked, trainable-affine) BatchNorm its result belongs to: the reduce pass in the GEMM
+            epilogue, and on a co-resident grid the whole BatchNorm backward in the launch (simt_fbn_desc mode 2)."""
+            bnr = self._bnr(bname, y, 2)
+            dsc = self._conv(b, x, wi, dz, Bn=B, Hi=h, Wi=w, Ho=h, Wo=w, Cout=ac, taps=[(0, 0)], bnr=bnr,
+                             fbn=dict(mode=2, out=dy, bname=bname, coef=coef, affine=True) if bnr else None, **kw)
+            if dsc.fbn:
+                self.grad_ready[bname + ".weight"] = self.grad_ready[bname + ".bias"] = len(b)
+            else:
+                self._bnb(b, dz=dz, y=y, bname=bname, dy=dy, M=M, Cn=ac, mask_mode=2, reduce_done_nblk=self._fused_nblk(dsc, bnr))
+        conv_bnb(dl, (wt, tile, npad), daf, self.yf, "assp.bnf", dyf, Cin=ck, alg_k=Q)
         # ---- convf: 5-tap wgrad over the planes; input gradient plane by plane
         b.wait(b.record(0), 1)
         self._wgrad(b, dyf, self.acat, None, Bn=1, Hi=5 * B * h, Wi=w, Cin=ac, Ho=B * h, Wo=w, Cd=ac, ldd=ac, taps=self.ptaps,
@@ -328,14 +339,13 @@ class V3Plan(TrunkPlan):
         wtf = self._plan_pack_t("assp.convf", ac, 5 * ac, 1)       # [5*ac (rows = concat channel)][ck = ac]
         assert wtf[3] == ac and wtf[2] >= 5 * ac
         dacat = self.new(5, M, ac)
-        for t in range(5):
-            self._conv(b, dyf, (wtf[0][t * ac:(t + 1) * ac], min(wtf[1], ac), ac), dacat[t], Bn=B, Hi=h, Wi=w, Cin=ac, Ho=h, Wo=w,
-                       Cout=ac, taps=[(0, 0)])
+        dybs = [self.new(M, ac) for _ in ASSP_BRANCHES]
+        for t, (i, k, dil) in enumerate(ASSP_BRANCHES):
+            conv_bnb(dyf, (wtf[0][t * ac:(t + 1) * ac], min(wtf[1], ac), ac), dacat[t], self.ycat[t], f"assp.bn{i}", dybs[t], Cin=ac)
         # ---- branches
         dfeat = None
         for t, (i, k, dil) in enumerate(ASSP_BRANCHES):
-            dyb = self.new(M, ac)
-            self._bnb(b, dz=dacat[t], y=self.ycat[t], bname=f"assp.bn{i}", dy=dyb, M=M, Cn=ac, mask_mode=2)
+            dyb = dybs[t]
             b.wait(b.record(0), 1)
             taps = ops.conv_taps(3, 3, dil, dil) if k == 3 else [(0, 0)]
             self._wgrad(b, dyb, self.feat, None, Bn=B, Hi=h, Wi=w, Cin=cin, Ho=h, Wo=w, Cd=ac, ldd=ac, taps=taps, stride=1,
@@ -378,10 +388,17 @@ class V3Plan(TrunkPlan):
             wt3 = self._plan_pack_t(name + ".conv3", c4, p, 1)
             da2 = self.new(Mo, p)
             bnr = self._bnr(name + ".bn2", rec["y2"], 2)       # first pass of bn2's backward inside the GEMM that produces da2
-            dsc = self._conv(b, dy3, wt3[:3], da2, Bn=B, Hi=Ho, Wi=Wo, Cin=wt3[3], Ho=Ho, Wo=Wo, Cout=p, taps=[(0, 0)], bnr=bnr)
             dy2 = self.new(Mo, p)
-            self._bnb(b, dz=da2, y=rec["y2"], bname=name + ".bn2", dy=dy2, M=Mo, Cn=p, mask_mode=2,
-                      reduce_done_nblk=self._fused_nblk(dsc, bnr))
+            coef = self.buf("bnb.coef", 3 * 2048, dtype=torch.float32)
+            # on the small maps (the launch is one co-resident round of the chip) the whole BatchNorm backward rides in the dgrad launch:
+            # simt_fbn_desc mode 2, d gamma / d beta written by its owner workgroups (engine.TrunkPlan._conv)
+            dsc = self._conv(b, dy3, wt3[:3], da2, Bn=B, Hi=Ho, Wi=Wo, Cin=wt3[3], Ho=Ho, Wo=Wo, Cout=p, taps=[(0, 0)], bnr=bnr,
+                             fbn=dict(mode=2, out=dy2, bname=name + ".bn2", coef=coef, affine=True) if bnr else None)
+            if dsc.fbn:
+                self.grad_ready[name + ".bn2.weight"] = self.grad_ready[name + ".bn2.bias"] = len(b)
+            else:
+                self._bnb(b, dz=da2, y=rec["y2"], bname=name + ".bn2", dy=dy2, M=Mo, Cn=p, mask_mode=2,
+                          reduce_done_nblk=self._fused_nblk(dsc, bnr))
             # conv2: 3x3, stride s.  dgrad of a strided conv = stride-1 correlation of the zero-inserted dY with mirrored taps
             t3 = ops.conv_taps(3, 3, 1, 1)
             wgrad(True, dy=dy2, x=rec["a1"], Bn=B, Hi=Hi, Wi=Wi, Cin=p, Ho=Ho, Wo=Wo, Cd=p, ldd=p, taps=t3, stride=stride,
@@ -394,11 +411,15 @@ class V3Plan(TrunkPlan):
                 b.add("simt_scatter_stride", dy2.data_ptr(), src.data_ptr(), B, Hi, Wi, p, Ho, Wo, stride, ops.dt_code(dt))
             da1 = self.new(Mi, p)
             bnr = self._bnr(name + ".bn1", rec["y1"], 2)
-            dsc = self._conv(b, src, wt2[:3], da1, Bn=B, Hi=Hi, Wi=Wi, Cin=p, Ho=Hi, Wo=Wi, Cout=p, taps=[(-a, -c) for (a, c) in t3],
-                             alg_flops=2.0 * Mo * p * 9 * p, bnr=bnr)
             dy1 = self.new(Mi, p)
-            self._bnb(b, dz=da1, y=rec["y1"], bname=name + ".bn1", dy=dy1, M=Mi, Cn=p, mask_mode=2,
-                      reduce_done_nblk=self._fused_nblk(dsc, bnr))
+            dsc = self._conv(b, src, wt2[:3], da1, Bn=B, Hi=Hi, Wi=Wi, Cin=p, Ho=Hi, Wo=Wi, Cout=p, taps=[(-a, -c) for (a, c) in t3],
+                             alg_flops=2.0 * Mo * p * 9 * p, bnr=bnr,
+                             fbn=dict(mode=2, out=dy1, bname=name + ".bn1", coef=coef, affine=True) if bnr else None)
+            if dsc.fbn:
+                self.grad_ready[name + ".bn1.weight"] = self.grad_ready[name + ".bn1.bias"] = len(b)
+            else:
+                self._bnb(b, dz=da1, y=rec["y1"], bname=name + ".bn1", dy=dy1, M=Mi, Cn=p, mask_mode=2,
+                          reduce_done_nblk=self._fused_nblk(dsc, bnr))
             wgrad(True, dy=dy1, x=rec["x"], Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Hi, Wo=Wi, Cd=p, ldd=p, taps=[(0, 0)], stride=1,
                   parts=[(name + ".conv1.weight", 0, 0, p, 1, inpl)])
             if grouped:

@@ -211,3 +211,44 @@ def test_fused_bn_under_hipgraph_replay(dev):
         torch.cuda.empty_cache()
     for o in outs[1:]:
         assert torch.isfinite(o[0]).all() and torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+
+
+def test_fused_bn_backward_v3_plan_bitwise_b4_512x1024(dev):
+    """BASELINE configs[3] (model/deeplabv3.py, B = 4, 512 x 1024): on the stride-8 / stride-16 maps a dgrad launch is one co-resident round of
+    the chip with the 128- / 64-column tiles too, so bn2's and bn1's backward (trainable affine: d gamma / d beta come from the owner
+    workgroups) ride in the conv3 / conv2 dgrad launches.  Same logits, same flat gradient (every conv weight, every BatchNorm weight and
+    bias) as the plan without fused launches, bit for bit."""
+    import re
+    from simt_amd.engine_v3 import V3Plan, v3_state_shapes
+    from test_gpu_v3 import make_state              # (tests/ is on sys.path under pytest: rootdir conftest)
+    st = make_state(v3_state_shapes(19, 6, True), 11)
+    g = torch.Generator().manual_seed(12)
+    img = torch.randn(B4, 3, 512, 1024, generator=g)
+    res = []
+    for grid in ("3", "0"):
+        os.environ["SIMT_BN_GRID"] = grid
+        try:
+            plan = V3Plan({k: v.clone().to(dev) for k, v in st.items()}, B4, 512, 1024, 19, 6, True, dtype=BF, train=True)
+        finally:
+            os.environ.pop("SIMT_BN_GRID")
+        ftags = [it.tag for it in plan.bwd_list.items if it.tag and re.match(r"conv_igemm2_kernel<\d+, \d, 3, 1, 2>", it.tag)]
+        nbwd = sum(1 for it in plan.bwd_list.items if it.fn is L.load().simt_bn_bwd)
+        if grid == "3":
+            # layer2 (4 Bottlenecks, 128 x 256 maps, 128-column tiles) and layer3 (6, 64 x 128 maps after the stride, 64-column tiles): bn2 and bn1 each,
+            # except where the launch is more than one round of the chip (layer1; the stride-2 block's conv2 dgrad runs on its input map)
+            assert len(ftags) >= 16, ftags
+            assert {t.split("<")[1].split(",")[0] for t in ftags} >= {"64"}, ftags
+        else:
+            assert not ftags
+        out = plan.forward(img.to(dev))
+        up = (torch.randn(B4, 25, 32, 64, generator=torch.Generator().manual_seed(13)) * 1e-3).to(dev)
+        plan.backward(torch.nn.functional.interpolate(up, size=(512, 1024), mode="bilinear"))
+        torch.cuda.synchronize()
+        res.append(dict(out=out.clone(), flat=plan.flat_grad.clone(), nf=len(ftags), nbwd=nbwd))
+        del plan
+        torch.cuda.empty_cache()
+    a, b = res
+    assert a["nbwd"] == b["nbwd"] - a["nf"]
+    assert torch.isfinite(a["flat"]).all() and a["flat"].abs().max().item() > 0
+    assert torch.equal(a["out"], b["out"])
+    assert torch.equal(a["flat"], b["flat"]), "v3 plan with the BatchNorm backward fused into the dgrad launches differs from the plan without"
