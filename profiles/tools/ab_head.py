@@ -16,7 +16,7 @@ fx=torch.zeros(B*h*w,32); fx[:,:Cn]=torch.softmax(torch.randn(B*h*w,Cn,generator
 p1,p2,fx=p1.to(dev),p2.to(dev),fx.to(dev)
 _,lab=ms.synthetic_batch(B,H,W,ms.load_class_dist(),seed=3,device=dev)
 T=[torch.softmax(torch.randn(Q,Cn,generator=g),1).to(dev) for _ in range(2)]
-nblk=lib.simt_head_nblk(B,H,W)
+nblk=max(l.simt_head_nblk(B,H,W) for l in libs)      # (the libraries may size the partial-sum rows differently)
 part=torch.zeros(nblk,lib.simt_head_part_floats(Q,Cn),device=dev); keys=torch.zeros(lib.simt_head_keys_count(),device=dev,dtype=torch.int64)
 hout=torch.zeros(lib.simt_head_hout_floats(Q,Cn),device=dev); g1=torch.zeros(2,B,H,w,24,device=dev)
 d1=torch.zeros(B*h*w,64,device=dev,dtype=torch.bfloat16); d2=torch.zeros_like(d1)

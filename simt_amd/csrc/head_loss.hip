@@ -231,8 +231,9 @@ struct HeadArgs {
   float* part;                 // [nblk][NSCAL + 2*Q*C]
   unsigned long long* keys;    // [2*QMAX] anchor keys, [2*QMAX .. 2*QMAX+1] exist masks (zeroed per call)
   float* hout;                 // finalize output (see simt_head_out_* offsets)
-  float* g1;                   // [2][B][H][w][QP] x-reduced gradients
+  float* g1;                   // rows == 1: [2][B][H][w][QP] x-reduced gradients;  rows > 1: [2][B][H / rows][3][w][QP], see head_pass2_kernel
   int QP;
+  int rows;                    // image rows per pass-2 block (head_rows_per_block)
   float gscale;
   int mode;                    // 0 = SimT loss block; 1 = warm-up stage: plain CE of both heads against `label`
   unsigned char* conf_out;     // optional [B][H][W]: the confidence label decided per pixel (255 = none)
@@ -618,8 +619,13 @@ __device__ __forceinline__ float run_sum(const float* G, int GP, const float* sL
 }
 
 // --------------------------------------------------------------------------------------------------------
-// pass 2: gradient w.r.t. the upsampled logits, reduced along x inside the block.  One block per (b, y) row.
+// pass 2: gradient w.r.t. the upsampled logits, reduced along x inside the block.  One block per group of a.rows consecutive image rows.
 // --------------------------------------------------------------------------------------------------------
+// rows > 1 (round 4; the production sizes run 6 or 8): the block also folds its rows along y -- (rows - 1) * sy < 1, so they touch at most
+// THREE low-res rows, first = the low-res row of the group's first image row; each thread keeps its share of the three [2][w][Q] window rows
+// in registers (P2_NACC x 3) and adds every finished row's x-reduced sums with the row's two interpolation weights.  g1 shrinks from
+// H to 3 * H / rows rows (57 -> 28.6 MB at 4 x 768 x 768, written once, read once by the y-reduction), in a fixed order.
+#define P2_NACC 18              // window entries per thread: 2 * w * Q <= 256 * P2_NACC (else rows = 1)
 // launch bounds: at most 2 waves per SIMD are asked for.  The run-time-count builds need it (at 3 the QM = 24 build spilled 272 B per lane to
 // scratch: round 1's "256 MB of HBM traffic per launch" against ~30 MB algorithmic); the compile-time-count builds come out at ~160
 // VGPRs without spills.  At 4 x 768 x 768 on cold operands, pass 2 + y-reduction: 1 016 us (round 1) -> 826 (no spill) -> 680 (compile-time
@@ -639,9 +645,18 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
   int* sStart = (int*)(sL1 + 256);           // [XR_MAX + 1] first pixel of the chunk whose low-res column is >= xl_lo + k
   const int tid = threadIdx.x;
   const int lbid = xcd_remap(blockIdx.x, gridDim.x);      // an XCD's blocks take consecutive image rows (L2 locality of the gathers; pass 1)
-  const int b = lbid / g.H, y = lbid % g.H;
+  // (the run-time-count builds keep one row per block: the window registers would spill there; head_rows_per_block)
+  constexpr bool GROUPED = QT != 0;
+  constexpr int NACC = GROUPED ? P2_NACC : 1;
+  const int R = GROUPED ? a.rows : 1;
+  const int b = (lbid * R) / g.H, y0 = (lbid * R) % g.H;   // (R divides H: a group never straddles two images)
+  const int iy_first = min((int)src_coord(g.half, g.sy, y0), g.h - 1);
+  float gacc[3][NACC];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) gacc[k][i] = 0.f;
   for (int i = tid; i < QC; i += 256) { sT[i] = a.mode == 0 ? a.T1[i] : 0.f; sT[QC + i] = a.mode == 0 ? a.T2[i] : 0.f; }
-  for (int i = tid; i < 2 * g.w * Q; i += 256) sAcc[i] = 0.f;
   const float* o = a.hout;
   const float Np = o[6], Nk1 = o[7], Nk2 = o[8], Ny = o[9];
   const float gs = a.gscale;
@@ -649,6 +664,9 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
   const float gk1 = gs * a.lambda_seg / Nk1, gk2 = gs / Nk2;
   const float gu1 = gk1 * a.lambda_place, gu2 = gk2 * a.lambda_place;
   const float gy1 = gs * a.lambda_seg / Ny, gy2 = gs / Ny;
+  for (int rr = 0; rr < R; ++rr) {
+  const int y = y0 + rr;
+  for (int i = tid; i < 2 * g.w * Q; i += 256) sAcc[i] = 0.f;
   __syncthreads();
 
   for (int x0 = 0; x0 < g.W; x0 += 256) {
@@ -800,20 +818,59 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
     }
     __syncthreads();
   }
-  // write g1[hd][b][y][xl][0..QP)
-  for (int idx = tid; idx < 2 * g.w * QP; idx += 256) {
-    int hd = idx / (g.w * QP);
-    int r = idx - hd * g.w * QP;
-    int xl = r / QP, j = r - xl * QP;
-    float v = (j < Q) ? sAcc[(hd * g.w + xl) * Q + j] : 0.f;
-    a.g1[((((long)hd * g.B + b) * g.H + y) * g.w + xl) * QP + j] = v;
+  if (!GROUPED || R == 1) {
+    // write g1[hd][b][y][xl][0..QP)
+    for (int idx = tid; idx < 2 * g.w * QP; idx += 256) {
+      int hd = idx / (g.w * QP);
+      int r = idx - hd * g.w * QP;
+      int xl = r / QP, j = r - xl * QP;
+      float v = (j < Q) ? sAcc[(hd * g.w + xl) * Q + j] : 0.f;
+      a.g1[((((long)hd * g.B + b) * g.H + y) * g.w + xl) * QP + j] = v;
+    }
+  } else {
+    // fold the finished row into the window: its two taps (i0, i1) carry (1 - l1, l1), like head_yreduce_kernel weighs a row
+    const float fy = src_coord(g.half, g.sy, y);
+    int i0 = (int)fy;
+    if (i0 > g.h - 1) i0 = g.h - 1;
+    const int i1 = i0 + (i0 < g.h - 1 ? 1 : 0);
+    const float l1 = fy - (float)i0, l0 = 1.f - l1;
+    float wk[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wk[k] = (i0 == iy_first + k ? l0 : 0.f) + (i1 == iy_first + k ? l1 : 0.f);
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < 2 * g.w * Q) {
+        const float sv = sAcc[idx];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gacc[k][i] += wk[k] * sv;
+      }
+    }
+    __syncthreads();       // (sAcc is zeroed for the next row)
+  }
+  }
+  if (GROUPED && R > 1) {
+    // g1[hd][b][group][k][xl][0..Q): the three window rows of this group (pad columns Q..QP are never read)
+    const int NG = g.H / R, gy = y0 / R;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < 2 * g.w * Q) {
+        const int hd = idx / (g.w * Q);
+        const int r = idx - hd * g.w * Q;
+        const int xl = r / Q, j = r - xl * Q;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          a.g1[(((((long)hd * g.B + b) * NG + gy) * 3 + k) * g.w + xl) * QP + j] = gacc[k][i];
+      }
+    }
   }
 }
 
 // y-reduction: d[hd][b][yl][xl][j] = sum_y wgt(y, yl) * g1[hd][b][y][xl][j]
 template <typename T>
 __global__ void head_yreduce_kernel(const float* g1, float* d32_1, float* d32_2, T* dT_1, T* dT_2, HeadGeom g, int QP,
-                                    int ldo32, int ldoT, long total) {
+                                    int ldo32, int ldoT, long total, int R) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   int j = (int)(idx % QP);
@@ -826,6 +883,15 @@ __global__ void head_yreduce_kernel(const float* g1, float* d32_1, float* d32_2,
   int lo, hi;
   dst_range(yl, g.H, g.sy, lo, hi);
   float s = 0.f;
+  if (R > 1) {
+    // pass 2 folded its groups of R rows already: add the window rows that are low-res row yl, in ascending group order
+    const int NG = g.H / R;
+    if (j < g.Q)
+      for (int gy = lo / R; gy <= hi / R; ++gy) {
+        const int k = yl - min((int)src_coord(g.half, g.sy, gy * R), g.h - 1);
+        if (k >= 0 && k < 3) s += g1[(((((long)hd * g.B + b) * NG + gy) * 3 + k) * g.w + xl) * QP + j];
+      }
+  } else
   for (int yy = lo; yy <= hi; ++yy) {
     float fy = src_coord(g.half, g.sy, yy);
     int i0 = (int)fy;
@@ -851,6 +917,16 @@ static size_t pass2_lds(int Q, int C, int w) {
   return (2 * QC + 2 * 256 * (size_t)(Q + 1) + 2 * (size_t)w * Q + 512 + XR_MAX + 1) * 4;
 }
 
+// image rows per pass-2 block: the largest R <= 8 that divides H, keeps a group inside three low-res rows ((R - 1) * sy <= 0.95) and still
+// leaves two blocks per CU; 1 when the window does not fit the per-thread registers
+static int head_rows_per_block(const simt_head_desc* d, float sy) {
+  const bool fixed_counts = d->C == 19 && (d->Q == 22 || d->Q == 25);      // the compile-time-count instantiations (simt_head_grad's dispatch)
+  if (!fixed_counts || 2l * d->w * d->Q > 256l * P2_NACC) return 1;
+  for (int R = 8; R >= 2; --R)
+    if (d->H % R == 0 && (float)(R - 1) * sy <= 0.95f && (long)d->B * d->H / R >= 512) return R;
+  return 1;
+}
+
 static int fill_args(const simt_head_desc* d, HeadArgs& a) {
   SIMT_CHECK(d && d->pred2 && d->label && d->part && d->keys && d->hout);
   SIMT_CHECK(d->single ? (d->mode == 0) : (d->pred1 != nullptr));
@@ -873,6 +949,7 @@ static int fill_args(const simt_head_desc* d, HeadArgs& a) {
   a.th_high = d->th_high; a.th_low = d->th_low; a.lambda_seg = d->lambda_seg; a.lambda_place = d->lambda_place;
   a.part = d->part; a.keys = (unsigned long long*)d->keys; a.hout = d->hout; a.g1 = d->g1; a.QP = d->QP;
   a.gscale = d->gscale;
+  a.rows = head_rows_per_block(d, a.g.sy);
   a.mode = d->mode;
   a.conf_out = d->conf_out;
   SIMT_CHECK(d->mode == 0 || d->mode == 1);
@@ -882,7 +959,7 @@ static int fill_args(const simt_head_desc* d, HeadArgs& a) {
 extern "C" int simt_head_nblk(int B, int H, int W) {
   long P = (long)B * H * W;
   long n = (P + 255) / 256;
-  if (n > 2048) n = 2048;
+  if (n > 512) n = 512;      // two blocks per CU, one round (round 4: 2048 -> 512 blocks; the partial-sum rows the reduction reads shrink 4x)
   return (int)n;
 }
 extern "C" int simt_head_part_floats(int Q, int C) { return NSCAL + 2 * Q * C; }
@@ -940,7 +1017,7 @@ extern "C" int simt_head_grad(const simt_head_desc* d, simt_stream_t stream) {
     P2ATTR(24, 22, 19); P2ATTR(28, 25, 19); P2ATTR(24, 0, 0); P2ATTR(QMAX, 0, 0);
 #undef P2ATTR
   }
-#define P2(QM, QT, CT) hipLaunchKernelGGL((head_pass2_kernel<QM, QT, CT>), dim3(d->B * d->H), dim3(256), lds2, st, a)
+#define P2(QM, QT, CT) hipLaunchKernelGGL((head_pass2_kernel<QM, QT, CT>), dim3(d->B * d->H / a.rows), dim3(256), lds2, st, a)
   if (d->Q == 22 && d->C == 19) P2(24, 22, 19);
   else if (d->Q == 25 && d->C == 19) P2(28, 25, 19);
   else if (d->Q <= 24) P2(24, 0, 0);
@@ -951,10 +1028,10 @@ extern "C" int simt_head_grad(const simt_head_desc* d, simt_stream_t stream) {
   unsigned grid = (unsigned)((total + 255) / 256);
   if (d->grad_dtype == SIMT_BF16)
     hipLaunchKernelGGL(head_yreduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, d->g1, d->dpred1_f32, d->dpred2_f32,
-                       (bf16_t*)d->dpred1_t, (bf16_t*)d->dpred2_t, a.g, d->QP, d->ld_f32, d->ld_t, total);
+                       (bf16_t*)d->dpred1_t, (bf16_t*)d->dpred2_t, a.g, d->QP, d->ld_f32, d->ld_t, total, a.rows);
   else
     hipLaunchKernelGGL(head_yreduce_kernel<float>, dim3(grid), dim3(256), 0, st, d->g1, d->dpred1_f32, d->dpred2_f32,
-                       (float*)d->dpred1_t, (float*)d->dpred2_t, a.g, d->QP, d->ld_f32, d->ld_t, total);
+                       (float*)d->dpred1_t, (float*)d->dpred2_t, a.g, d->QP, d->ld_f32, d->ld_t, total, a.rows);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
