@@ -265,6 +265,9 @@ typedef struct {
                          * trainV2_simt.py:354 computes for a model that upsamples inside.  0: fixp = low-res probabilities */
   uint8_t* conf_out;    /* optional (may be NULL): [B][H][W] the per-pixel `Conf_label_target` of trainV2_simt.py:357-362,387-393
                          * as simt_head_loss decided it: class index 0..Q-1, 255 = no confidence label (mode 1: the label itself) */
+  uint8_t* label_ws;    /* optional workspace (may be NULL): [B][H][W].  With conf_out AND label_ws given, simt_head_loss also stores each pixel's
+                         * checked noisy label and simt_head_grad reads the two byte maps back (they must still hold what simt_head_loss of the
+                         * same inputs wrote) instead of deciding the labels again from fixp and the 8-byte labels: same values, fewer bytes */
 } simt_head_desc;
 int simt_head_nblk(int B, int H, int W);
 int simt_head_part_floats(int Q, int C);

@@ -27,6 +27,9 @@ hd.dpred1_f32,hd.dpred2_f32,hd.dpred1_t,hd.dpred2_t=None,None,d1.data_ptr(),d2.d
 hd.B,hd.h,hd.w,hd.H,hd.W,hd.C,hd.Q=B,h,w,H,W,Cn,Q
 hd.ldp,hd.ldf,hd.QP,hd.ld_f32,hd.ld_t,hd.grad_dtype=32,32,24,0,64,L.SIMT_BF16
 hd.th_high,hd.th_low,hd.lambda_seg,hd.lambda_place,hd.gscale=0.8,0.2,0.1,0.1,1.0
+if os.environ.get("AB_HEAD_WS") == "1":      # the trainers' form: both byte maps given (a library older than label_ws ignores the trailing field)
+    conf_ws = torch.zeros(B, H, W, device=dev, dtype=torch.uint8); lab_ws = torch.zeros(B, H, W, device=dev, dtype=torch.uint8)
+    hd.conf_out, hd.label_ws = conf_ws.data_ptr(), lab_ws.data_ptr()
 flush = torch.empty(1 << 28, device=dev, dtype=torch.uint8)
 def t(fn,n=8):
     ts=[]

@@ -65,7 +65,7 @@ class HeadDesc(C.Structure):
                 ("B", i32), ("h", i32), ("w", i32), ("H", i32), ("W", i32), ("C", i32), ("Q", i32), ("ldp", i32),
                 ("ldf", i32), ("QP", i32), ("ld_f32", i32), ("ld_t", i32), ("grad_dtype", i32),
                 ("th_high", f32), ("th_low", f32), ("lambda_seg", f32), ("lambda_place", f32), ("gscale", f32), ("mode", i32),
-                ("single", i32), ("up_half_pixel", i32), ("fix_logits", i32), ("conf_out", c_p)]
+                ("single", i32), ("up_half_pixel", i32), ("fix_logits", i32), ("conf_out", c_p), ("label_ws", c_p)]
 
 
 class NtmInnerDesc(C.Structure):

@@ -237,6 +237,7 @@ struct HeadArgs {
   float gscale;
   int mode;                    // 0 = SimT loss block; 1 = warm-up stage: plain CE of both heads against `label`
   unsigned char* conf_out;     // optional [B][H][W]: the confidence label decided per pixel (255 = none)
+  unsigned char* label_ws;     // optional [B][H][W]: the checked noisy label (255 = ignored / invalid / warm-up mode), pass 1 -> pass 2
 };
 
 // Full-wave sum with DPP row operations (no LDS crossbar): result valid in lane 63.
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(256, (QM <= 24 ? SIMT_HEAD_P1_WAVES : 2)) void head
 
     if (live) {
       if (a.conf_out) a.conf_out[p] = (unsigned char)conf;
+      if (a.label_ws) a.label_ws[p] = lab_ok ? (unsigned char)labi : (unsigned char)255;
       if (conf != 255) {
         float l1 = 0.f, l2 = 0.f;
 #pragma unroll
@@ -692,9 +694,13 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
             for (int k = i0 - xl_lo_ + 1; k <= nxl_; ++k) sStart[k] = nlive;
         }
       }
+      // the confidence label and the checked noisy label: read back from pass 1 when the caller gave both byte maps (1 + 1 bytes per pixel
+      // instead of the frozen posterior's 4 x C gathers + arg-max and the 8-byte label), else decided again
+      const bool from_p1 = a.conf_out != nullptr && a.label_ws != nullptr;
+      const long pix = ((long)b * g.H + y) * g.W + x;
       float fm = 0.f;
       int fa = 0;
-      if (a.mode == 0) fixed_posterior<CM>(g, C, a.fixp, tp, fm, fa);
+      if (a.mode == 0 && !from_p1) fixed_posterior<CM>(g, C, a.fixp, tp, fm, fa);
       asm volatile("" ::: "memory");
       int conf = (fm > a.th_high) ? fa : 255;
       if (fm < a.th_low) conf = C;
@@ -710,11 +716,20 @@ __global__ __launch_bounds__(256, 2) void head_pass2_kernel(HeadArgs a) {
       eval_head<QM>(v2, Q, C, a.th_high, e2);
       eval_head<QM>(v1, Q, C, a.th_high, e1);
       if (conf == C) conf = (e2.arg >= C) ? e2.arg : 255;
-      long long lab = live ? a.label[((long)b * g.H + y) * g.W + x] : 255;
-      bool lab_ok = live && lab >= 0 && lab != 255 && lab < C;
-      const int labi = lab_ok ? (int)lab : 0;
+      bool lab_ok;
+      int labi;
+      if (from_p1) {
+        conf = live ? (int)a.conf_out[pix] : 255;
+        const int l8 = live ? (int)a.label_ws[pix] : 255;
+        lab_ok = l8 != 255;
+        labi = lab_ok ? l8 : 0;
+      } else {
+        const long long lab = live ? a.label[pix] : 255;
+        lab_ok = live && lab >= 0 && lab != 255 && lab < C;
+        labi = lab_ok ? (int)lab : 0;
+      }
       if (a.mode == 1) {
-        conf = lab_ok ? labi : 255;
+        if (!from_p1) conf = lab_ok ? labi : 255;
         e1.pseudo1 = 255;
         e2.pseudo1 = 255;
         lab_ok = false;
@@ -922,7 +937,7 @@ static size_t pass2_lds(int Q, int C, int w) {
 static int head_rows_per_block(const simt_head_desc* d, float sy) {
   const bool fixed_counts = d->C == 19 && (d->Q == 22 || d->Q == 25);      // the compile-time-count instantiations (simt_head_grad's dispatch)
   if (!fixed_counts || 2l * d->w * d->Q > 256l * P2_NACC) return 1;
-  for (int R = 8; R >= 2; --R)
+  for (int R = 8; R >= 3; --R)        // (R >= 3: the three window rows per group must fit the caller's [H]-row workspace)
     if (d->H % R == 0 && (float)(R - 1) * sy <= 0.95f && (long)d->B * d->H / R >= 512) return R;
   return 1;
 }
@@ -952,6 +967,7 @@ static int fill_args(const simt_head_desc* d, HeadArgs& a) {
   a.rows = head_rows_per_block(d, a.g.sy);
   a.mode = d->mode;
   a.conf_out = d->conf_out;
+  a.label_ws = d->label_ws;
   SIMT_CHECK(d->mode == 0 || d->mode == 1);
   return SIMT_OK;
 }

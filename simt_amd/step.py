@@ -144,6 +144,8 @@ class SimTTrainer:
         # per-pixel Conf_label_target of the last (micro-)batch (trainV2_simt.py:357-362,387-393), 255 = none: 1 byte per pixel
         self.conf_label = torch.full((B, H, W), 255, device=dev, dtype=torch.uint8)
         hd.conf_out = self.conf_label.data_ptr()
+        self._label_ws = torch.full((B, H, W), 255, device=dev, dtype=torch.uint8)          # checked noisy labels, loss pass -> gradient pass
+        hd.label_ws = self._label_ws.data_ptr()
         self.head_desc = hd
         # ---- NTM descriptors
         ni = L.NtmInnerDesc()

@@ -104,6 +104,8 @@ class SimTSingleTrainer:
         hd.gscale, hd.mode, hd.single, hd.up_half_pixel, hd.fix_logits = 1.0 / hp.iter_size, 0, 1, half, fix_logits
         self.conf_label = torch.full((B, H, W), 255, device=dev, dtype=torch.uint8)      # per-pixel Conf_label_target, 255 = none
         hd.conf_out = self.conf_label.data_ptr()
+        self._label_ws = torch.full((B, H, W), 255, device=dev, dtype=torch.uint8)          # checked noisy labels, loss pass -> gradient pass
+        hd.label_ws = self._label_ws.data_ptr()
         self.head_desc = hd
         ni = L.NtmInnerDesc()
         ni.ntm[1], ni.w[1], ni.ntm_grad[1] = self.ntm.data_ptr(), self.wraw.data_ptr(), self.ntm_grad.data_ptr()

@@ -32,7 +32,7 @@ def nhwc_pad(x, ld):
     return out
 
 
-def run_head(dev, d, pred1, pred2, fixed2, label, ntm, *, steps=10, lr_T=None):
+def run_head(dev, d, pred1, pred2, fixed2, label, ntm, *, steps=10, lr_T=None, label_ws=False):
     """Drives the head/NTM kernels exactly like SimTTrainer.step does, on explicit low-res logits."""
     K = int(d["K"]); Cn = 19; Q = Cn + K
     B, _, h, w = pred1.shape
@@ -81,6 +81,9 @@ def run_head(dev, d, pred1, pred2, fixed2, label, ntm, *, steps=10, lr_T=None):
     hd.lambda_seg, hd.lambda_place, hd.gscale = float(d["lambda_seg"]), float(d["lambda_place"]), 1.0
     conf = torch.full((B, H, W), 77, dtype=torch.uint8, device=dev)       # per-pixel Conf_label_target (optional export)
     hd.conf_out = conf.data_ptr()
+    if label_ws:          # the trainers' form: the gradient pass reads both byte maps back instead of deciding the labels again
+        lws = torch.full((B, H, W), 77, dtype=torch.uint8, device=dev)
+        hd.label_ws = lws.data_ptr()
     L.call("simt_head_loss", C.byref(hd), st)
     npd = L.NtmPostDesc()
     for k in range(2):
@@ -145,15 +148,18 @@ def test_head_against_reference_golden(dev, name):
 # (B, h, w, H, W): pass 2's x-reduction takes a different route per geometry -- runs of <= 8 pixels per low-res column (the production
 # 8x upsample: all terms of a run in flight), 9..12, longer (looped), and more low-res columns than a 256-pixel chunk's run table
 # holds (logits WIDER than the image: the scanning form)
+# rows4 / rows6: enough image rows that pass 2 takes groups of 4 / 6 rows per block and folds them along y in registers (the production form;
+# head_rows_per_block in csrc/head_loss.hip: needs B * H / rows >= 512)
 HEAD_GEOMS = {"up8_two_chunks": (2, 13, 37, 97, 289), "up10": (1, 3, 13, 16, 128), "up16_looped": (1, 3, 9, 16, 144),
-              "down_scanning": (1, 3, 330, 8, 272)}
+              "down_scanning": (1, 3, 330, 8, 272), "rows4": (4, 65, 4, 512, 24), "rows6": (4, 97, 3, 768, 16)}
 # K = 3 and 6 run the builds with compile-time channel counts (Q = 22, 25); K = 4 the run-time-count build of the same width (Q = 23),
 # K = 15 the wide one (Q = 34)
-HEAD_KS = [("up8_two_chunks", 3), ("up10", 3), ("up16_looped", 3), ("down_scanning", 3), ("up8_two_chunks", 4), ("up10", 6), ("up10", 15)]
+HEAD_KS = [("up8_two_chunks", 3, False), ("up10", 3, False), ("up16_looped", 3, True), ("down_scanning", 3, False), ("up8_two_chunks", 4, True),
+           ("up10", 6, True), ("up10", 15, False), ("rows4", 3, False), ("rows4", 6, True), ("rows6", 3, True), ("rows6", 3, False)]
 
 
-@pytest.mark.parametrize("geom,K", HEAD_KS)
-def test_head_bigger_than_one_block_vs_oracle(dev, geom, K):
+@pytest.mark.parametrize("geom,K,lws", HEAD_KS)
+def test_head_bigger_than_one_block_vs_oracle(dev, geom, K, lws):
     """Head kernels against the oracle on explicit low-res logits: several blocks per pass, W > 256 (two x-chunks in pass 2),
     non-square, every route of the x-reduction, every instantiation of the kernels."""
     Cn = 19
@@ -167,7 +173,7 @@ def test_head_bigger_than_one_block_vs_oracle(dev, geom, K):
     ntm = [so.ntm_init(Cn, K, 1), so.ntm_init(Cn, K, 2)]
     d = {"K": K, "lam": np.array([0.5, 0.1, 0.5]), "lr_T": 6e-3, "th": np.array([0.8, 0.2]), "lambda_seg": 0.1,
          "lambda_place": 0.1}
-    r = run_head(dev, d, p1, p2, f2, lab, ntm)
+    r = run_head(dev, d, p1, p2, f2, lab, ntm, label_ws=lws)
     # oracle
     hp = so.Hyper(num_classes=Cn, open_classes=K, lambda_convex=0.5, lambda_volume=0.1, lambda_anchor=0.5)
     n = [x.clone().requires_grad_(True) for x in ntm]
