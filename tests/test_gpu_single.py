@@ -45,12 +45,18 @@ def nhwc_pad(x, ld):
     return out
 
 
-@pytest.mark.parametrize("flavour,K", [("v3", 6), ("vgg", 3), ("v3", 15)])
+@pytest.mark.parametrize("flavour,K", [("v3", 6), ("vgg", 3), ("v3", 15), ("v3rows", 6), ("vggrows", 3)])
 def test_single_head_kernel_vs_oracle(dev, flavour, K):
+    """*rows: enough image rows (B * H >= 1536) that the gradient pass takes groups of 4 (v3, half-pixel) / 8 (vgg, align_corners) rows per block,
+    folds them along y in registers and reads the two label byte maps back from the loss pass (csrc/head_loss.hip head_rows_per_block)."""
     Cn = 19
     Q = Cn + K
     g = torch.Generator().manual_seed(17 + K)
     B, h, w, H, W = 2, 11, 19, 88 if flavour == "v3" else 81, 152 if flavour == "v3" else 145
+    rows = flavour.endswith("rows")
+    if rows:
+        flavour = flavour[:-4]
+        B, h, w, H, W = (4, 32, 2, 512, 32) if flavour == "v3" else (8, 64, 3, 512, 24)
     pred = torch.randn(B, Q, h, w, generator=g) * 3
     fix = torch.randn(B, Cn, h, w, generator=g) * 4
     _, lab = so.synthetic_batch(B, H, W, CD.numpy(), seed=11, block=8)
@@ -89,6 +95,9 @@ def test_single_head_kernel_vs_oracle(dev, flavour, K):
     hd.ldp, hd.ldf, hd.QP, hd.ld_f32, hd.ld_t, hd.grad_dtype = ldp, 32, QP, ldp, 0, L.SIMT_F32
     hd.th_high, hd.th_low, hd.lambda_seg, hd.lambda_place, hd.gscale = 0.8, 0.2, 0.0, 0.1, 1.0
     hd.mode, hd.single, hd.up_half_pixel, hd.fix_logits = 0, 1, int(half), int(half)
+    if rows:
+        conf_ws, lab_ws = (torch.full((B, H, W), 77, dtype=torch.uint8, device=dev) for _ in range(2))
+        hd.conf_out, hd.label_ws = conf_ws.data_ptr(), lab_ws.data_ptr()
     L.call("simt_head_loss", C.byref(hd), st)
     npd = L.NtmPostDesc()
     npd.ntm[1], npd.w[1], npd.ntm_grad[1] = ntm_d.data_ptr(), wraw.data_ptr(), ngrad.data_ptr()
