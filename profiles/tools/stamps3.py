@@ -17,11 +17,16 @@ def make(Cin, Cout, epi):
     if "stats" in epi: kw["stats"] = torch.zeros((M + 127) // 128, 2, Cout, device=dev)
     if "res" in epi: kw["res"] = torch.randn(M, Cout, device=dev).to(BF)
     if "bias" in epi: kw["bias"] = torch.randn(Cout, device=dev); kw["relu"] = True
+    if "rbits" in epi: kw["res_bits"] = torch.randint(0, 256, (M, Cout // 8), dtype=torch.uint8, device=dev)
+    if "bnr3" in epi:
+        kw["bnr"] = {"y": torch.randn(M, Cout, device=dev).to(BF), "mean": torch.randn(Cout, device=dev) * 0.2, "rstd": torch.rand(Cout, device=dev) + 0.5,
+                     "scale": torch.rand(Cout, device=dev) + 0.5, "shift": torch.randn(Cout, device=dev) * 0.3,
+                     "bits": torch.randint(0, 256, (M, Cout // 8), dtype=torch.uint8, device=dev), "mode": 3, "part": torch.zeros(M // 128 + 2, 3, Cout, device=dev)}
     d = ops.make_conv_desc(x.view(B, H, W, Cin), wp, y, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=Cout, taps=[(0, 0)], Npad=npad, tile_n=256, **kw)
     return d, (x, wp, y, kw)
 st = torch.cuda.current_stream().cuda_stream
 flush = torch.empty(1 << 28, device=dev, dtype=torch.uint8)
-for (Cin, Cout, epi) in ((256, 1024, "stats"), (256, 1024, "bias res")):
+for (Cin, Cout, epi) in ((256, 1024, "stats"), (256, 1024, "bias res"), (256, 1024, "res rbits bnr3")):
     d, keep = make(Cin, Cout, epi)
     for _ in range(2):
         flush.zero_(); torch.cuda.synchronize()
