@@ -354,17 +354,17 @@ __global__ __launch_bounds__((NCW + NSW) * 64, (KS == 32 ? 2 : 3)) void conv1x1_
   float bias8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = (has_bias && ncol_ok && (n + e) < a.Cout) ? a.bias[n + e] : 0.f;
-  float bmu[8], brs[8];                                        // fused BN-backward reduce (bit-mask flavour): constants of the BatchNorm whose dz this is
+  // fused BN-backward reduce (bit-mask flavour): the mean of the BatchNorm whose dz this is.  S2 = sum g * xhat is taken as rstd * sum g * (y - mean),
+  // the factor applied once per 128-row tile and column (sums_out) -- the order PyTorch's batch_norm backward uses, and one multiply per element less
+  // in store waves that are bound by their vector work
+  float bmu[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { bmu[e] = 0.f; brs[e] = 0.f; }
-  if (has_bnr && ncol_ok) {
-    load8(a.bnr_mean + n, bmu);
-    load8(a.bnr_rstd + n, brs);
-  }
+  for (int e = 0; e < 8; ++e) bmu[e] = 0.f;
+  if (has_bnr && ncol_ok) load8(a.bnr_mean + n, bmu);
   // Pin the waits of these loads HERE: left to the compiler, its s_waitcnt vmcnt(0) lands at the head of the slab loop, where it would
   // also wait for every output store of the previous slab to be acknowledged by HBM.
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { asm volatile("" : "+v"(bias8[e])); if (AUX) { asm volatile("" : "+v"(bmu[e]), "+v"(brs[e])); } }
+  for (int e = 0; e < 8; ++e) { asm volatile("" : "+v"(bias8[e])); if (AUX) { asm volatile("" : "+v"(bmu[e])); } }
   const bool plain = !has_bias && !has_res && !has_relu;
   const bool want_sums = has_stats || has_bnr;
   float s1[8], s2[8];
@@ -420,7 +420,7 @@ __global__ __launch_bounds__((NCW + NSW) * 64, (KS == 32 ? 2 : 3)) void conv1x1_
       for (int w = 0; w < NSW; ++w) { t1 += sR[(w * 2 + 0) * BN + st]; t2 += sR[(w * 2 + 1) * BN + st]; }
       if (has_bnr) {                                           // [m-tile][3][Cout]: S1, S2 and the (unused) second-BN row
         a.bnr_part[((long)mt * 3 + 0) * a.Cout + nn] = t1;
-        a.bnr_part[((long)mt * 3 + 1) * a.Cout + nn] = t2;
+        a.bnr_part[((long)mt * 3 + 1) * a.Cout + nn] = t2 * a.bnr_rstd[nn];
         a.bnr_part[((long)mt * 3 + 2) * a.Cout + nn] = 0.f;
       } else {
         a.stats[((long)mt * 2 + 0) * a.Cout + nn] = t1;
@@ -582,13 +582,18 @@ __global__ __launch_bounds__((NCW + NSW) * 64, (KS == 32 ? 2 : 3)) void conv1x1_
           for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
         }
         if (!plain) {
+          if (has_bias) {                                      // (x + 0.0f is not a no-op the compiler may drop: 8 adds per row in the bias-free flavours)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+            for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+          }
           if (has_res) {
             float rv[8];
             unpack8(cur.res, rv);
+            // bit e of the mask as an all-ones / all-zeros word (one v_bfe_i32) ANDed onto the value: 2 vector instructions per element where
+            // test + compare + select take 3 -- these store waves are bound by their vector work (profiles/tools/stamps3.py)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (!has_rbits || ((cur.rbits >> e) & 1u)) ? rv[e] : 0.f;
+            for (int e = 0; e < 8; ++e)
+              v[e] += has_rbits ? __uint_as_float(__float_as_uint(rv[e]) & (unsigned)__builtin_amdgcn_sbfe((int)cur.rbits, e, 1)) : rv[e];
           }
           if (has_relu) {
 #pragma unroll
@@ -602,9 +607,9 @@ __global__ __launch_bounds__((NCW + NSW) * 64, (KS == 32 ? 2 : 3)) void conv1x1_
           float yv[8];
           unpack8(cur.by, yv);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = ((cur.ybits >> e) & 1u) ? v[e] : 0.f;
+          for (int e = 0; e < 8; ++e) v[e] = __uint_as_float(__float_as_uint(v[e]) & (unsigned)__builtin_amdgcn_sbfe((int)cur.ybits, e, 1));
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * ((yv[e] - bmu[e]) * brs[e]); }
+          for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * (yv[e] - bmu[e]); }
         }
       }
       unsigned yo = (unsigned)(row0 + p * RGS) * y_pitch + y_c;
