@@ -382,11 +382,15 @@ __global__ __launch_bounds__((NCW + NSW) * 64, (KS == 32 ? 2 : 3)) void conv1x1_
   const unsigned b_c = (unsigned)rg * b_pitch + (unsigned)n * 2u;
   const bool all_cols = n0 + BN <= a.Nstore;                   // uniform
   Aux q[g::PASSES];
-  auto aux_load = [&](Aux& d, int slab_row0, int p, bool guard) {
-    d.res = d.by = make_uint4(0u, 0u, 0u, 0u);
-    d.rbits = d.ybits = 0xffu;
-    if (!AUX) return;
-    if (guard && !(ncol_ok && slab_row0 + rg + p * RGS < a.M)) return;
+  auto aux_load = [&](Aux& d, int slab_row0, int p, bool guard) {      // guard: uniform (false for full slabs of full-width tiles: no zero fill, no exec masking)
+    if (!AUX || (guard && !(ncol_ok && slab_row0 + rg + p * RGS < a.M))) {
+      d.res = d.by = make_uint4(0u, 0u, 0u, 0u);
+      d.rbits = d.ybits = 0xffu;
+      return;
+    }
+    if (!has_res) { d.res = make_uint4(0u, 0u, 0u, 0u); d.rbits = 0xffu; }
+    if (!has_bnr) { d.by = make_uint4(0u, 0u, 0u, 0u); d.ybits = 0xffu; }
+    if (has_res && !has_rbits) d.rbits = 0xffu;
     if (has_res) {
       const unsigned o = (unsigned)(slab_row0 + p * RGS) * r_pitch + r_c;
       d.res = *(const uint4*)(resb + o);
@@ -569,9 +573,10 @@ __global__ __launch_bounds__((NCW + NSW) * 64, (KS == 32 ? 2 : 3)) void conv1x1_
 #endif
     // full slabs of full-width tiles take the branch-free path (uniform test); only the last tile / a narrow last column tile is guarded
     const bool guard_cur = !(all_cols && row0 + g::RS <= a.M);
+    const bool guard_next = !(all_cols && nrow0 + g::RS <= a.M);        // uniform
     auto pass = [&](int p, bool guard) {
       const Aux cur = q[p];
-      if (AUX && more) aux_load(q[p], nrow0, p, true);
+      if (AUX && more) aux_load(q[p], nrow0, p, guard_next);
       if (guard && !(ncol_ok && row0 + rg + p * RGS < a.M)) return;
       uint4 o = AUX ? *(const uint4*)(sl + (rg + p * RGS) * CP + vcol * 2) : ov[p];
       if (!plain || want_sums) {
@@ -616,7 +621,7 @@ __global__ __launch_bounds__((NCW + NSW) * 64, (KS == 32 ? 2 : 3)) void conv1x1_
       if (SIMT_ROWS_ABL & 32) yo = (yo & 0x3fffu) + blockIdx.x * 0x4000u;        // ablation: every store hits the same 16 KB per workgroup (L2-resident)
       if (!(SIMT_ROWS_ABL & 2) || o.x == 0x12345678u) *(uint4*)(const_cast<char*>(yb) + yo) = o;
     };
-    if (AUX || guard_cur) {                                    // (one copy of the pass code in the aux flavours: registers)
+    if (guard_cur || FL == FL_GEN_AUX) {                       // (one copy of the pass code in the run-time-flag aux flavour: registers)
 #pragma unroll
       for (int p = 0; p < g::PASSES; ++p) pass(p, true);
     } else {
