@@ -156,13 +156,16 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
       if (plain) {
         if (!(FBN && a.fbn_mode)) *(uint4*)(a.y + (long)m * a.ldy + n) = o;      // fused BatchNorm: the rows go out AFTER the tile sums are published (forward) / never (backward: dy instead)
       } else {
+        if (fl.bias()) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+          for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+        }
         if (fl.res()) {
           float rv[8];
           unpack(cur.res, rv);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += ((cur.rbits >> e) & 1u) ? rv[e] : 0.f;
+          for (int e = 0; e < 8; ++e)          // (bit e as an all-ones / all-zeros word: v_bfe_i32 + and instead of test + compare + select)
+            v[e] += __uint_as_float(__float_as_uint(rv[e]) & (unsigned)__builtin_amdgcn_sbfe((int)cur.rbits, e, 1));
         }
         if (fl.relu()) {
 #pragma unroll
@@ -189,7 +192,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
           for (int e = 0; e < 8; ++e) v[e] = (yv[e] * bsc[e] + bsh[e]) > 0.f ? v[e] : 0.f;
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = ((cur.ybits >> e) & 1u) ? v[e] : 0.f;
+          for (int e = 0; e < 8; ++e) v[e] = __uint_as_float(__float_as_uint(v[e]) & (unsigned)__builtin_amdgcn_sbfe((int)cur.ybits, e, 1));
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * ((yv[e] - bmu[e]) * brs[e]); }
