@@ -403,7 +403,10 @@ class TrunkPlan:
         bn_, tm_, nst_ = C.c_int(), C.c_int(), C.c_int()
         gen = L.load().simt_conv_variant(C.byref(d), C.byref(bn_), C.byref(tm_), C.byref(nst_))
         fb = 0
-        if fbn is not None and self._fbn_on and fbn["mode"] in self._fbn_dirs and gen == 2 and L.load().simt_conv_fbn_ok(C.byref(d)):
+        # narrow (128- / 64-column) tiles only where the caller asks: worth +1 % on DeepLabv3's small maps (engine_v3), -0.04 ms on layer 2 of the
+        # two-stream DeepLab-v2 step (profiles/r04_bn_fusion.txt)
+        if (fbn is not None and self._fbn_on and fbn["mode"] in self._fbn_dirs and gen == 2 and (bn_.value == 256 or fbn.get("narrow"))
+                and L.load().simt_conv_fbn_ok(C.byref(d))):
             sb = self.bn[fbn["bname"]]
             fd = L.FbnDesc()
             fd.mode, fd.ldo, fd.out = fbn["mode"], fbn["out"].shape[-1], fbn["out"].data_ptr()

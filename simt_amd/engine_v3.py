@@ -326,7 +326,7 @@ class V3Plan(TrunkPlan):
             epilogue, and on a co-resident grid the whole BatchNorm backward in the launch (simt_fbn_desc mode 2)."""
             bnr = self._bnr(bname, y, 2)
             dsc = self._conv(b, x, wi, dz, Bn=B, Hi=h, Wi=w, Ho=h, Wo=w, Cout=ac, taps=[(0, 0)], bnr=bnr,
-                             fbn=dict(mode=2, out=dy, bname=bname, coef=coef, affine=True) if bnr else None, **kw)
+                             fbn=dict(mode=2, out=dy, bname=bname, coef=coef, affine=True, narrow=True) if bnr else None, **kw)
             if dsc.fbn:
                 self.grad_ready[bname + ".weight"] = self.grad_ready[bname + ".bias"] = len(b)
             else:
@@ -393,7 +393,7 @@ class V3Plan(TrunkPlan):
             # on the small maps (the launch is one co-resident round of the chip) the whole BatchNorm backward rides in the dgrad launch:
             # simt_fbn_desc mode 2, d gamma / d beta written by its owner workgroups (engine.TrunkPlan._conv)
             dsc = self._conv(b, dy3, wt3[:3], da2, Bn=B, Hi=Ho, Wi=Wo, Cin=wt3[3], Ho=Ho, Wo=Wo, Cout=p, taps=[(0, 0)], bnr=bnr,
-                             fbn=dict(mode=2, out=dy2, bname=name + ".bn2", coef=coef, affine=True) if bnr else None)
+                             fbn=dict(mode=2, out=dy2, bname=name + ".bn2", coef=coef, affine=True, narrow=True) if bnr else None)
             if dsc.fbn:
                 self.grad_ready[name + ".bn2.weight"] = self.grad_ready[name + ".bn2.bias"] = len(b)
             else:
@@ -414,7 +414,7 @@ class V3Plan(TrunkPlan):
             dy1 = self.new(Mi, p)
             dsc = self._conv(b, src, wt2[:3], da1, Bn=B, Hi=Hi, Wi=Wi, Cin=p, Ho=Hi, Wo=Wi, Cout=p, taps=[(-a, -c) for (a, c) in t3],
                              alg_flops=2.0 * Mo * p * 9 * p, bnr=bnr,
-                             fbn=dict(mode=2, out=dy1, bname=name + ".bn1", coef=coef, affine=True) if bnr else None)
+                             fbn=dict(mode=2, out=dy1, bname=name + ".bn1", coef=coef, affine=True, narrow=True) if bnr else None)
             if dsc.fbn:
                 self.grad_ready[name + ".bn1.weight"] = self.grad_ready[name + ".bn1.bias"] = len(b)
             else:
