@@ -52,6 +52,7 @@ for (Cin, Cout, k, dil) in ((256, 256, 3, 2), (1024, 256, 1, 1)):
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
+        print(f"== {Cin} -> {Cout} k{k} {'fused BatchNorm' if fused else 'statistics flavour'}: launch {np.median(ts):.1f} us (cold caches, median of 4)")
         buf = np.zeros((256, 8), np.uint64)
         assert lib.simt_debug_stamps(buf.ctypes.data, 256) == 0
         b = buf.astype(np.int64)

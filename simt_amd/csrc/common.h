@@ -66,17 +66,43 @@ __device__ __forceinline__ void raw8_unpack(const Raw8<bf16_t>& q, float* v) {
   v[4] = __uint_as_float(q.r.z << 16); v[5] = __uint_as_float(q.r.z & 0xffff0000u);
   v[6] = __uint_as_float(q.r.w << 16); v[7] = __uint_as_float(q.r.w & 0xffff0000u);
 }
-__device__ __forceinline__ void store8(float* p, const float* v) {
-  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
-  *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+// Large outputs are written with NON-TEMPORAL stores (global_store ... nt).  A kernel's ordinary stores stay dirty in its XCD's L2 until the
+// release at the END of the kernel writes them back (MI355X_MICROARCH.md: + bytes / ~6 TB/s on the kernel boundary) -- for a conv that leaves
+// 19 MB per launch that is ~3 us on a 45-us kernel, and the consumer (any XCD) reads from the fabric either way.  Streamed out as the epilogue
+// produces them, the rows cost the boundary less: the step -0.13 ms with the conv family's rows non-temporal (round 4, same-box A/B).  NOT as
+// inline asm: a volatile-asm store measured another 0.5 ms faster and was WRONG -- the compiler does not wait for the LDS read that feeds an asm
+// operand (stale dwords in single rows; tests/test_gpu_bn_fused.py caught it), and what it gained was exactly that missing wait.
+// Other kernels (rows, BatchNorm passes, weight-gradient slabs) measured no gain or a loss with non-temporal outputs: per translation unit.
+#ifndef SIMT_NT_STORES
+#define SIMT_NT_STORES 0          // per translation unit: a file that wants them defines SIMT_NT_STORES 1 before including this header
+#endif
+__device__ __forceinline__ void st_out16(void* p, const uint4& v) {
+  typedef unsigned simt_u32x4 __attribute__((ext_vector_type(4)));
+  const simt_u32x4 w = {v.x, v.y, v.z, v.w};
+#if SIMT_NT_STORES
+  __builtin_nontemporal_store(w, (simt_u32x4*)p);
+#else
+  *(simt_u32x4*)p = w;
+#endif
 }
-__device__ __forceinline__ void store8(bf16_t* p, const float* v) {
+__device__ __forceinline__ void st_out8(bf16_t* p, const float* v) {
   uint4 r;
-  r.x = pack_bf16x2(v[0], v[1]);
-  r.y = pack_bf16x2(v[2], v[3]);
-  r.z = pack_bf16x2(v[4], v[5]);
-  r.w = pack_bf16x2(v[6], v[7]);
-  *(uint4*)p = r;
+  r.x = pack_bf16x2(v[0], v[1]); r.y = pack_bf16x2(v[2], v[3]); r.z = pack_bf16x2(v[4], v[5]); r.w = pack_bf16x2(v[6], v[7]);
+  st_out16(p, r);
+}
+__device__ __forceinline__ void st_out8(float* p, const float* v) {
+  st_out16(p, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
+  st_out16(p + 4, make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])));
+}
+
+__device__ __forceinline__ void store8(float* p, const float* v) { st_out8(p, v); }
+__device__ __forceinline__ void store8(bf16_t* p, const float* v) { st_out8(p, v); }
+__device__ __forceinline__ void st_out16f(float* p, const f32x4& v) {      // an accumulator quad (fp32 results: the tap-expanded head GEMMs, weight-gradient slabs)
+#if SIMT_NT_STORES
+  __builtin_nontemporal_store(v, (f32x4*)p);
+#else
+  *(f32x4*)p = v;
+#endif
 }
 
 // Blocks b and b+8 share an XCD (observed round-robin dispatch). Remap so that each XCD works on a

@@ -483,7 +483,7 @@ __global__ __launch_bounds__((NCW + NSW) * 64, (KS == 32 ? 2 : 3)) void conv1x1_
           }
           unsigned yo = (unsigned)(row0 + p * RGS) * y_pitch + y_c;
           if (SIMT_ROWS_ABL & 32) yo = (yo & 0x3fffu) + blockIdx.x * 0x4000u;
-          if (!(SIMT_ROWS_ABL & 2) || o.x == 0x12345678u) *(uint4*)(const_cast<char*>(yb) + yo) = o;
+          if (!(SIMT_ROWS_ABL & 2) || o.x == 0x12345678u) st_out16(const_cast<char*>(yb) + yo, o);
         }
       }
 #ifdef SIMT_ABLATION
@@ -619,7 +619,7 @@ __global__ __launch_bounds__((NCW + NSW) * 64, (KS == 32 ? 2 : 3)) void conv1x1_
       }
       unsigned yo = (unsigned)(row0 + p * RGS) * y_pitch + y_c;
       if (SIMT_ROWS_ABL & 32) yo = (yo & 0x3fffu) + blockIdx.x * 0x4000u;        // ablation: every store hits the same 16 KB per workgroup (L2-resident)
-      if (!(SIMT_ROWS_ABL & 2) || o.x == 0x12345678u) *(uint4*)(const_cast<char*>(yb) + yo) = o;
+      if (!(SIMT_ROWS_ABL & 2) || o.x == 0x12345678u) st_out16(const_cast<char*>(yb) + yo, o);
     };
     if (guard_cur || FL == FL_GEN_AUX) {                       // (one copy of the pass code in the run-time-flag aux flavour: registers)
 #pragma unroll

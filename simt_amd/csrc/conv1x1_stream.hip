@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NT, 4) void conv1x1_stream_kernel(Conv2KArgs a, int
         }
       }
 #if !(SIMT_STREAM_ABL & 2)
-      *(uint4*)(a.y + (long)m * a.ldy + n) = o;
+      st_out16(a.y + (long)m * a.ldy + n, o);
 #else
       if (o.x == 0x12345678u && o.y == 0x9abcdef0u) *(uint4*)(a.y + (long)m * a.ldy + n) = o;
 #endif

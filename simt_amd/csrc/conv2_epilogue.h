@@ -6,6 +6,16 @@
 #include "conv2_common.h"
 #include <type_traits>
 
+// Output rows go out as NON-TEMPORAL stores (st_out16 / st_out8, common.h): see there.
+// Workgroup barriers BEHIND global stores are LDS-only (lds_barrier): __syncthreads() is a workgroup-scope release + acquire fence around the barrier,
+// and the release makes the compiler drain vmcnt to 0 -- every row store of the tile acknowledged by the memory system (2-3 us) before the row-group
+// sums may be combined through LDS.  Nothing in these kernels communicates through global memory inside a workgroup (the fused BatchNorm's granules are
+// self-validating atomics), so the barrier only has to order LDS.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 // 8-byte {value, tag} granules: ONE naturally aligned write-through store / L1-bypassing load each (never torn)
 __device__ __forceinline__ void st_gran(unsigned long long* p, unsigned long long v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -55,7 +65,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
       for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * TM * 16 + i * 16 + (lane & 15);
         const int c = n0 + wn * TN * 16 + j * 16 + (lane >> 4) * 4;
-        if (m < m_end && c < a.Nstore) *(f32x4*)(yf + (long)m * a.ldy + c) = acc[j][i];
+        if (m < m_end && c < a.Nstore) st_out16f(yf + (long)m * a.ldy + c, acc[j][i]);
       }
     return;
   }
@@ -144,7 +154,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
       const uint2 hi = *(const uint2*)(sC + r * CP + vcol * 2 + 8);
       const uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
       if (plain && !fl.stats() && !fl.bnr()) {
-        *(uint4*)(a.y + (long)m * a.ldy + n) = o;
+        st_out16(a.y + (long)m * a.ldy + n, o);
         continue;
       }
       float v[8];
@@ -154,7 +164,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
         for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
       }
       if (plain) {
-        if (!(FBN && a.fbn_mode)) *(uint4*)(a.y + (long)m * a.ldy + n) = o;      // fused BatchNorm: the rows go out AFTER the tile sums are published (forward) / never (backward: dy instead)
+        if (!(FBN && a.fbn_mode)) st_out16(a.y + (long)m * a.ldy + n, o);      // fused BatchNorm: the rows go out AFTER the tile sums are published (forward) / never (backward: dy instead)
       } else {
         if (fl.bias()) {
 #pragma unroll
@@ -177,7 +187,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
         }
-        store8(a.y + (long)m * a.ldy + n, v);
+        st_out8(a.y + (long)m * a.ldy + n, v);
       }
       if (fl.bnr()) {
         // backward: S1 = sum g, S2 = sum g * xhat on the value as stored (bf16), masked like the backward masks it
@@ -203,10 +213,16 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
   if (fl.stats() || fl.bnr()) {
     // combine the RPP row groups in fixed order: sR[rg][2][BN] floats behind the tile
     float* sR = (float*)(smem + BM * CP);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      sR[(rg * 2 + 0) * BN + vcol + e] = s1[e];
-      sR[(rg * 2 + 1) * BN + vcol + e] = s2[e];
+    {
+      // LDS stores as inline asm: in a kernel that uses LDS-DMA the compiler drains vmcnt to 0 in front of every C++ LDS store (it cannot tell an
+      // outstanding global store from a global_load_lds that may still write LDS) -- here that would be a wait for the acknowledgement of every
+      // row store of the tile (2-3 us).  No LDS-DMA is in flight in the epilogue (drained before the tile went to LDS).
+      typedef float f4_t __attribute__((ext_vector_type(4)));
+      const unsigned ad = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(sR + (rg * 2) * BN + vcol);
+      const f4_t a0 = {s1[0], s1[1], s1[2], s1[3]}, a1 = {s1[4], s1[5], s1[6], s1[7]};
+      const f4_t b0 = {s2[0], s2[1], s2[2], s2[3]}, b1 = {s2[4], s2[5], s2[6], s2[7]};
+      asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16" :: "v"(ad), "v"(a0), "v"(a1) : "memory");
+      asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16" :: "v"(ad + (unsigned)(BN * 4)), "v"(b0), "v"(b1) : "memory");
     }
     [[maybe_unused]] unsigned* sTag = (unsigned*)(smem + BM * CP + RPP * 2 * BN * 4 + 32 * 8 * 3 * 8);      // behind sRed (below)
     if constexpr (FBN != 0) {
@@ -215,7 +231,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
         sTag[0] = (unsigned)(fbn_ticket / cnt_s) + 1u;
       }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(6);
     if (tid < BN) {
       const int nn = n0 + tid;
@@ -269,7 +285,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
             if (r >= BM || m >= m_end) break;
             const uint2 lo = *(const uint2*)(sC + r * CP + vcol * 2);
             const uint2 hi = *(const uint2*)(sC + r * CP + vcol * 2 + 8);
-            *(uint4*)(a.y + (long)m * a.ldy + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            st_out16(a.y + (long)m * a.ldy + n, make_uint4(lo.x, lo.y, hi.x, hi.y));
           }
         }
         STAMP(2);
@@ -322,7 +338,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
 #pragma unroll
             for (int j = 0; j < 3; ++j) sRed[(r * 8 + cl) * 3 + j] = sj[j];       // (constant trip counts: a run-time index puts the array in scratch)
           }
-          __syncthreads();
+          lds_barrier();
           if (tid < 8 && c < a.Cout) {
             double t[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -391,7 +407,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
           for (int u = 0; u < PER; ++u)
             if (lane + 64 * u < 2 * BN) sCst[lane + 64 * u] = cv[u];
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(7);                                                  // (constants published and seen)
         // ---- apply: the tile is still in LDS (bf16, as stored)
         if (n < a.Nstore) {
@@ -427,7 +443,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
               for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-              store8(a.fbn_out + (long)m * a.fbn_ldo + n, v);
+              st_out8(a.fbn_out + (long)m * a.fbn_ldo + n, v);
             } else {                                               // bn_bwd_apply_kernel, mask_mode 2
               float yv[8], o[8];
               unpack8(q[it].by, yv);
@@ -435,7 +451,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
               for (int e = 0; e < 8; ++e) v[e] = (yv[e] * sc[e] + sh[e]) > 0.f ? v[e] : 0.f;
 #pragma unroll
               for (int e = 0; e < 8; ++e) o[e] = sc[e] * (v[e] - c1[e] - ((yv[e] - mu[e]) * rs[e]) * c2[e]);
-              store8(a.fbn_out + (long)m * a.fbn_ldo + n, o);
+              st_out8(a.fbn_out + (long)m * a.fbn_ldo + n, o);
             }
           }
         }

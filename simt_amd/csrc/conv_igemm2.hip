@@ -21,6 +21,9 @@
 //     wave's global_load_lds issue + ds_read latency (MI355X_MICROARCH "two waves per SIMD", item 9).
 // LDS rows are 128 B; the 16-B chunk index is XOR-swizzled with (row>>1)&7 on the global SOURCE address and on the
 // ds_read_b128 side (conflict-free 16-lane groups), the LDS image itself stays lane-linear as global_load_lds needs.
+#ifndef SIMT_NT_STORES
+#define SIMT_NT_STORES 1      // output rows as non-temporal stores (common.h)
+#endif
 #include "conv2_common.h"
 #include "conv2_epilogue.h"
 #include <stdlib.h>

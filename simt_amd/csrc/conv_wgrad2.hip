@@ -245,7 +245,7 @@ __device__ __forceinline__ void conv_wgrad2_body(const Wgrad2KArgs& a, const int
     for (int j = 0; j < 4; ++j) {
       const int co = co0 + wm * 64 + i * 16 + (lane & 15);
       const int k = k0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-      if (co < a.Cd && k < a.Ktot) *(f32x4*)(out + (long)co * a.Ktot + k) = acc[i][j];
+      if (co < a.Cd && k < a.Ktot) st_out16f(out + (long)co * a.Ktot + k, acc[i][j]);
     }
 }
 
@@ -444,7 +444,7 @@ __device__ __forceinline__ void conv_wgrad3_body(const Wgrad2KArgs& a, const int
     for (int j = 0; j < 4; ++j) {
       const int co = co0 + wm * 128 + i * 16 + (lane & 15);
       const int k = k0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-      if (co < a.Cd && k < a.Ktot) *(f32x4*)(out + (long)co * a.Ktot + k) = acc[i][j];
+      if (co < a.Cd && k < a.Ktot) st_out16f(out + (long)co * a.Ktot + k, acc[i][j]);
     }
 }
 

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void tap_scatter_kernel(TapArgs a) {
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
       v = *(const uint4*)(d + (m - ((long)a.dy[t] * a.W + a.dx[t])) * a.lds + g * 8);
-    *(uint4*)(G + m * a.ldd + t * a.QP + g * 8) = v;
+    st_out16(G + m * a.ldd + t * a.QP + g * 8, v);
   }
 }
 
