@@ -383,6 +383,21 @@ def main():
             extra["skip_unapplied_grads_pass"] = {"value": round(a.batch * world * n2 / dt4, 3), "ms_per_step": round(dt4 / n2 * 1e3, 3), "steps": n2,
                                                   "what": "NOT the headline: backward stopped at layer3's input (the gradients of conv1 / layer1 / layer2 "
                                                           "are never applied by the SimT stage; identical parameter trajectory); Hyper(skip_unapplied_grads=True)"}
+        # ---- the price of the parity mode: the SAME iteration in fp32 storage / fp32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the bf16 matrix
+        # rate) -- the mode whose losses the 1e-4 parity claims are made in (tests/test_gpu_configs.py, smoke()).  A labelled secondary
+        # number, never the headline.
+        if a.dtype == "bf16" and world == 1:
+            del tr
+            torch.cuda.empty_cache()
+            init = ms.reference_init
+            tr = SimTTrainer(init(ms.state_shapes(19, K, True), seed=1234), init(ms.state_shapes(19, 0, False), seed=1234), ms.ntm_init(19, K, 1),
+                             ms.ntm_init(19, K, 2), hp, cd, a.batch, H, W, dtype=torch.float32, device=dev, process_group=pg)
+            n5 = 4
+            dt5, _ = timed(tr, resident(1234 + rank), n5, 2)
+            extra["f32_parity_mode_pass"] = {"value": round(a.batch * world * n5 / dt5, 3), "ms_per_step": round(dt5 / n5 * 1e3, 3), "steps": n5,
+                                             "dtype": "f32",
+                                             "what": "NOT the headline: the same iteration in the fp32 parity mode (fp32 storage, fp32 MFMA with a k-ordered "
+                                                     "fmaf chain; the kernels that carry 'loss within 1e-4'): what the parity mode costs"}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(K, a.cpu_iters)

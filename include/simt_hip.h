@@ -80,9 +80,14 @@ typedef struct {
  *   mode 2 (backward; needs d->bnr_mode 2): out = scale * (g - c1 - xhat * c2)          replaces simt_bn_bwd; d->y (the raw dz) is NOT written
  * (d->stats / d->bnr_part themselves are not written in fused launches.)  Only a launch on the stream that owns the plan may wait like
  * this: kernels of the other streams (frozen forward, weight gradients) never wait on anything, so the co-residency the polling needs
- * always resolves (a workgroup traps after ~2 s of polling instead of hanging).  `work` belongs to ONE BatchNorm and direction: its
- * ticket counters only ever grow and give every launch its generation = the granules' tag. */
+ * always resolves.  A workgroup that has polled for ~2 s (another process's waiting launch on the same GPU, persistent collective kernels holding
+ * CUs) does NOT trap: it sets the sticky error word (`err`, or work[SIMT_FBN_ERR_WORD]), every other poller of the launch sees it and the launch ends
+ * without writing `out`; later fused launches that share the word bail out at their first failed poll.  The caller reads the word (simt_amd:
+ * TrunkPlan.fbn_error(), raised by losses()) and rebuilds the plan with the two-pass BatchNorm; an optimiser step given the same word
+ * (simt_sgd_desc.skip_if) leaves the weights untouched.  `work` belongs to ONE BatchNorm and direction: its ticket counters only ever grow and
+ * give every launch its generation = the granules' tag. */
 #define SIMT_FBN_BAR_WORDS 144            /* uint64 words at the head of `work`: 8 ticket counters, one 128-byte line each (+ spare) */
+#define SIMT_FBN_ERR_WORD 136             /* spare word of the head used as the error word when simt_fbn_desc.err is NULL */
 typedef struct simt_fbn_desc {
   int32_t mode;          /* 1 forward, 2 backward */
   int32_t ldo;           /* row pitch of out in elements */
@@ -94,6 +99,8 @@ typedef struct simt_fbn_desc {
   float *mean, *rstd, *scale, *shift;     /* forward: OUT [C] each (the backward reads them) */
   float* coef;                            /* backward: OUT [3][C] = (sum g, sum g*xhat, 0) / count */
   float *dgamma, *dbeta;                  /* backward, trainable affine (model/deeplabv3.py's BatchNorm): OUT [C] = sum g*xhat, sum g; or NULL */
+  uint64_t* err;                          /* optional: sticky error word shared by the fused launches of a plan (zeroed once by the caller; set
+                                           * non-zero by a launch whose polling timed out); NULL: work[SIMT_FBN_ERR_WORD] */
 } simt_fbn_desc;
 int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);
 /* 1 if simt_conv_fprop can run d with a fused BatchNorm (d->fbn): bf16 v2 kernel with the 3-slot ring -- 256-column tiles in both directions,
@@ -111,7 +118,10 @@ int simt_conv_wants_frag(const simt_conv_desc* d);
  * 4 (conv1x1_stream_kernel) or 5 (conv1x1_rows_kernel): the short-reduction / wide-output 1x1 shapes */
 int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int* nst);
 /* compile-time epilogue flavour of the bf16 v2 kernel the launch for d runs (the last template argument of conv_igemm2_kernel<bn, tm, nst,
- * fbn, epi>): 0 generic (run-time flags), 1 BatchNorm statistics, 2 fused BatchNorm-backward reduce, 3 bias + ReLU; same results either way */
+ * fbn, epi>): 0 generic (run-time flags), 1 BatchNorm statistics, 2 fused BatchNorm-backward reduce (mask from y * scale + shift), 3 bias + ReLU,
+ * 4 bit-masked residual + BatchNorm-backward reduce with the bit mask, 5 plain, 6 residual only, 7 BatchNorm-backward reduce with the bit mask
+ * (+ optional plain residual), 8 ReLU-mask operand only (the BatchNorm-free VGG dgrads); the 2-slot short-K kernels are instantiated for 0 and
+ * 4-8 only (1-3 are reported as 0 there); same results either way */
 int simt_conv_epilogue_flavour(const simt_conv_desc* d);
 /* number of pixel tiles (= statistics / bnr_part slots) the launch for d uses; 0 if d does not run on the bf16 v2 kernel */
 int simt_conv_mtiles(const simt_conv_desc* d);
@@ -318,6 +328,7 @@ typedef struct {
   float lr[4], wd[4];  /* per param group */
   float momentum, dampening;
   int32_t first_step;  /* 1: momentum buffers are created (= d_p) like torch's first step */
+  const uint64_t* skip_if;   /* optional device word (simt_fbn_desc.err): the launch changes nothing while it is non-zero; NULL: always update */
 } simt_sgd_desc;
 int simt_sgd_multi(const simt_sgd_desc* d, simt_stream_t stream);
 /* dst[i] (+)= src[i], fp32: bias of the fused 2-branch ASPP GEMM = sum of the branch biases (deeplab_multi.py:115-119) */

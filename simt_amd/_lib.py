@@ -29,13 +29,15 @@ class ConvDesc(C.Structure):
 
 
 FBN_BAR_WORDS = 144
+FBN_ERR_WORD = 136
 
 
 class FbnDesc(C.Structure):
     """simt_fbn_desc (include/simt_hip.h): the train-mode BatchNorm behind a conv, fused into the producing launch."""
     _fields_ = [("mode", i32), ("ldo", i32), ("out", c_p), ("work", c_p), ("gamma", c_p), ("beta", c_p),
                 ("running_mean", c_p), ("running_var", c_p), ("momentum", f32), ("eps", f32),
-                ("mean", c_p), ("rstd", c_p), ("scale", c_p), ("shift", c_p), ("coef", c_p), ("dgamma", c_p), ("dbeta", c_p)]
+                ("mean", c_p), ("rstd", c_p), ("scale", c_p), ("shift", c_p), ("coef", c_p), ("dgamma", c_p), ("dbeta", c_p),
+                ("err", c_p)]
 
 
 class WgradDesc(C.Structure):
@@ -90,7 +92,7 @@ class TapDesc(C.Structure):
 
 class SgdDesc(C.Structure):
     _fields_ = [("segs", c_p), ("chunks", c_p), ("nchunks", i32), ("chunk", i32), ("lr", f32 * 4), ("wd", f32 * 4),
-                ("momentum", f32), ("dampening", f32), ("first_step", i32)]
+                ("momentum", f32), ("dampening", f32), ("first_step", i32), ("skip_if", c_p)]
 
 
 # name -> (restype, argtypes); every symbol include/simt_hip.h declares

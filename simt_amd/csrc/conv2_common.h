@@ -33,6 +33,7 @@ struct Conv2KArgs {
   int fbn_mode, fbn_ldo;
   bf16_t* fbn_out;
   unsigned long long* fbn_bar;         // [SIMT_FBN_BAR_WORDS] ticket counters
+  unsigned long long* fbn_err;         // sticky error word (simt_fbn_desc.err or work[SIMT_FBN_ERR_WORD]): set by a poller that timed out
   unsigned long long *fbn_cgran, *fbn_slots;   // [2][Cout] constants granules; [ntiles_m][2 | 3][Cout] tile-sum granules
   const float *fbn_gamma, *fbn_beta;
   float *fbn_rmean, *fbn_rvar;

@@ -24,8 +24,19 @@ __device__ __forceinline__ unsigned long long ld_gran(const unsigned long long* 
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Polling loops below: the other workgroups of the launch must become resident for a poll to end.  If something keeps them off the chip
-// for ~2 s (two waiting launches of different processes starving each other: engine.py SIMT_BN_GRID), the kernel traps -- the process
-// dies loudly instead of hanging the GPU.  s_memrealtime = constant 100 MHz (s_memtime counts core clocks).
+// for ~2 s (two waiting launches of different processes starving each other, a collective's persistent kernels holding CUs: engine.py
+// SIMT_BN_GRID), the poller does NOT trap (round 5): it sets the sticky error word of the plan and leaves its loop with whatever it read; every
+// other poller checks the word every 256 polls and leaves too, so the launch -- and every later fused launch that shares the word -- ends within
+// a poll period, its BatchNorm output undefined.  The host reads the word (TrunkPlan.fbn_error(); the trainers' losses() raise) and the optimiser
+// kernels skip their update while it is set (simt_sgd_desc.skip_if).  s_memrealtime = constant 100 MHz (s_memtime counts core clocks).
+__device__ __forceinline__ bool fbn_poll_gives_up(unsigned long long* err, unsigned long long t0) {
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return true;
+  if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+    __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+  }
+  return false;
+}
 // FBN = 1: the instantiation can also run the fused train-mode BatchNorm (simt_fbn_desc, a.fbn_mode 1 / 2): the tail of this function.
 // EPI: compile-time epilogue flavour.  0 = generic (every option a run-time flag: ~4 000 instructions, of which a launch executes ~1 000 per
 // wave -- at two waves per SIMD that is 8 k clocks = 3.9 us of a 50 us conv, stamps in profiles/r04_bn_fusion.txt); 1 = BatchNorm
@@ -307,6 +318,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
                 const unsigned off0 = (unsigned)(r * decltype(NJC)::value) * (unsigned)a.Cout + (unsigned)c;
                 const unsigned ostep = 32u * decltype(NJC)::value * (unsigned)a.Cout;
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned spins = 0;
                 bool ok;
                 do {
                   ok = true;
@@ -324,7 +336,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
                     }
                   if (!ok) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) __builtin_trap();      // ~2 s (see the top of this file)
+                    if ((++spins & 255u) == 0u && fbn_poll_gives_up(a.fbn_err, t0)) break;      // ~2 s, or another poller's bail-out
                   }
                 } while (!ok);
 #pragma unroll
@@ -381,6 +393,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
         if (tid < 64) {
           constexpr int PER = (2 * BN + 63) / 64;                  // granules per lane
           const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+          unsigned spins = 0;
           float cv[PER];
           bool ok;
           do {
@@ -400,7 +413,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
             ok = __all(ok);
             if (!ok) {
               __builtin_amdgcn_s_sleep(1);
-              if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) __builtin_trap();
+              if ((++spins & 255u) == 0u && __any(fbn_poll_gives_up(a.fbn_err, t0))) break;
             }
           } while (!ok);
 #pragma unroll

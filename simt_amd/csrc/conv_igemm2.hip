@@ -40,7 +40,7 @@ extern "C" int simt_debug_stamps(unsigned long long* out, int n) {
 // what they measured is in DESIGN.md section 9 and profiles/r03_conv_experiments.txt.  This file is the product kernel only.
 // FBN = 1: the same kernel with the fused train-mode BatchNorm tail compiled in (conv2_epilogue.h; a.fbn_mode selects forward / backward).
 // A separate instantiation so that the plain kernels keep their code (the main loop is sensitive to what surrounds it).
-// EPI: compile-time epilogue flavour (conv2_epilogue.h): 0 generic, 1 statistics, 2 BatchNorm-backward reduce, 3 bias + ReLU.
+// EPI: compile-time epilogue flavour (conv2_epilogue.h): 0 generic, 1 statistics, 2 BatchNorm-backward reduce, 3 bias + ReLU, 4-8 the dgrad forms.
 template <int BN, int TMP, int NSTP, int FBN = 0, int EPI = 0>
 __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(Conv2KArgs a) {
   constexpr int NT = 512, NST = NSTP;   // NST = 3: one workgroup per CU, two stages in flight; NST = 2 (short-K, output-
@@ -373,7 +373,7 @@ extern "C" int simt_conv_wants_frag(const simt_conv_desc* d) {
 }
 
 // Which compile-time epilogue flavour (conv2_epilogue.h EPI) the launch for d runs: 0 generic, 1 statistics, 2 BatchNorm-backward reduce,
-// 3 bias + ReLU (reporting: the kernel name is conv_igemm2_kernel<bn, tm, nst, fbn, epi>)
+// 3 bias + ReLU, 4-8 the dgrad forms listed there (reporting: the kernel name is conv_igemm2_kernel<bn, tm, nst, fbn, epi>)
 extern "C" int simt_conv_epilogue_flavour(const simt_conv_desc* d) {
   int bn, tm, nst;
   if (!d || simt_conv_variant(d, &bn, &tm, &nst) != 2) return 0;
@@ -445,6 +445,7 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
     if (f->mode == 1) SIMT_CHECK(d->stats && !d->bnr_mode && f->mean && f->rstd && f->scale && f->shift && (!f->running_mean || f->running_var));
     else SIMT_CHECK(f->mode == 2 && d->bnr_mode == 2 && f->coef);
     k.fbn_mode = f->mode; k.fbn_ldo = f->ldo; k.fbn_out = (bf16_t*)f->out; k.fbn_bar = (unsigned long long*)f->work;
+    k.fbn_err = f->err ? (unsigned long long*)f->err : k.fbn_bar + SIMT_FBN_ERR_WORD;
     k.fbn_cgran = k.fbn_bar + SIMT_FBN_BAR_WORDS; k.fbn_slots = k.fbn_cgran + 2l * d->Cout;
     k.fbn_gamma = f->gamma; k.fbn_beta = f->beta; k.fbn_rmean = f->running_mean; k.fbn_rvar = f->running_var;
     k.fbn_momentum = f->momentum; k.fbn_eps = f->eps;

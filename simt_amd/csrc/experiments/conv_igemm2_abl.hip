@@ -69,7 +69,23 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_regs8(u32x4* w) {
 // pixel pieces in flight also covers them).  Per stage and wave: 2-3 LDS-DMA pieces instead of 6-7, 10 fragment reads instead of 18,
 // LDS traffic 100 KB instead of 196 KB per CU; the two pixel halves of the 2 x 4 wave grid fetch the same 8 KB of weights (the second
 // request hits L1/L2).  Why: profiles/microbench/fillbench.hip and DESIGN.md section 9.
-template <int BN, int TMP, int NSTP, int MODE, int LW = 0, int WD = 0>
+// KS = 1 (round 5, SIMT_CONV2_KSTAMP=1; modes 0 and 2 of the wide tile only): s_memtime stamps INSIDE the K loop, of one middle stage, kept in
+// scalar registers and written after the loop (no vector-memory instruction is added to the loop: the counted vmcnt waits stay exact) --
+// where a stage's time goes for an early wave (wave 0) and a late wave (wave 4) of every workgroup.  g_kstamps[(block * 2 + late) * 8 + i]:
+//   early: 0 barrier exit, 1 fragment reads + LDS-DMA pieces issued, 2 fragments landed (lgkmcnt 0), 3 MFMA burst issued, 4 next barrier exit
+//   late : 0 barrier exit, 1 MFMA burst (previous stage's fragments) issued, 2 pieces + fragment reads issued, 3 fragments landed, 4 next barrier exit
+//   5 / 6: s_memtime / s_memrealtime (100 MHz) at kernel start, 7: s_memtime after the loop (clock = (7 - 5) / ((realtime delta) / 100 MHz))
+static __device__ unsigned long long g_kstamps[8192 * 16];
+extern "C" int simt_debug_kstamps(unsigned long long* out, int nblocks) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kstamps), (size_t)nblocks * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+extern "C" int simt_debug_stamps_abl(unsigned long long* out, int n) {      // g_stamps of THIS translation unit (STAMP in conv2_common.h)
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#define KST(i) do { if constexpr (KS != 0) { if (kt == kmid) { asm volatile("" ::: "memory"); kst[i] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } } } while (0)
+#define KST_NEXT() do { if constexpr (KS != 0) { if (kt == kmid + 1) { asm volatile("" ::: "memory"); kst[4] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } } } while (0)
+#define KST_LANDED(i) do { if constexpr (KS != 0) { if (kt == kmid) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); kst[i] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } } } while (0)
+template <int BN, int TMP, int NSTP, int MODE, int LW = 0, int WD = 0, int KS = 0>
 __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ? 4 : 2))) void conv_igemm2x_kernel(Conv2KArgs a) {
   constexpr int NT = 512, NST = NSTP;   // NST = 3: one workgroup per CU, two stages in flight; NST = 2 (short-K, output-
                                         // bound shapes): two workgroups per CU so one's epilogue overlaps the other's loads
@@ -90,6 +106,8 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
   const int wm = wave / WN, wn = wave % WN;
 
   STAMP(0);
+  [[maybe_unused]] unsigned long long kst[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  if constexpr (KS != 0) { kst[5] = __builtin_amdgcn_s_memtime(); kst[6] = __builtin_amdgcn_s_memrealtime(); }
   const int nwg = a.ntiles_m * a.ntiles_n;
   const int tile = xcd_remap(blockIdx.x, nwg);
   const int mt = tile / a.ntiles_n, nt = tile - mt * a.ntiles_n;
@@ -249,6 +267,7 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
     for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = a.ntaps * a.kc_per_tap;
+  [[maybe_unused]] const int kmid = nk / 2;
   const int sw = (lane >> 1) & 7;
   const int frag_row_off = (lane & 15) * 128;
   const int kq = lane >> 4;
@@ -402,19 +421,27 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (kt == 0) STAMP(2);
+      KST(0);
+      KST_NEXT();
       if constexpr (MODE == 0 || MODE == 11 || MODE == 13 || MODE == 3 || MODE == 4 || MODE == 5) {
         load_frags(buf);
         if (LW == 0 && kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
+        KST(1);
+        KST_LANDED(2);
         if (MODE == 13) __builtin_amdgcn_s_setprio(1);
         mma();
         if (MODE == 13) __builtin_amdgcn_s_setprio(0);
+        KST(3);
       } else {
         if (MODE != 2 && kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);     // stage kt+NST-1 -> buffer (buf-1) mod NST
         if (MODE != 1) {
           load_frags(buf);
+          KST(1);
+          KST_LANDED(2);
           if (MODE == 12) __builtin_amdgcn_s_setprio(1);
           mma();
           if (MODE == 12) __builtin_amdgcn_s_setprio(0);
+          KST(3);
         }
       }
       buf = (buf + 1 == NST) ? 0 : buf + 1;
@@ -426,23 +453,36 @@ __global__ __launch_bounds__(512 + LW * 64, (LW == 8 ? 4 : LW ? 1 : (NSTP == 2 ?
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my fragment reads of stage kt-1 are done before anyone refills
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      KST(0);
+      KST_NEXT();
       if (MODE != 1 && kt > 0) {
         if (MODE == 12 || MODE == 13) __builtin_amdgcn_s_setprio(1);
         mma();
         if (MODE == 12 || MODE == 13) __builtin_amdgcn_s_setprio(0);
       }
+      KST(1);
       if (MODE != 2 && LW == 0 && kt + NST - 1 < nk) issue(buf >= 1 ? buf - 1 : NST - 1);
       if (MODE != 1) load_frags(buf);
+      KST(2);
+      KST_LANDED(3);
       buf = (buf + 1 == NST) ? 0 : buf + 1;
     }
     if (MODE != 1) mma();
+  }
+  if constexpr (KS != 0) {
+    if ((tid == 0 || tid == 256) && blockIdx.x < 8192) {
+      kst[7] = __builtin_amdgcn_s_memtime();
+      unsigned long long* o = g_kstamps + (blockIdx.x * 2 + (tid == 256 ? 1 : 0)) * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = kst[i];
+    }
   }
 
   STAMP(3);
   conv2_epilogue<BN, BM, NT, TN, TM>(a, smem, acc, true, wm, wn, tid, lane, m0, n0, m_end, mt);
 }
 
-template <int BN, int TM, int NST, int MODE, int LW = 0, int WD = 0>
+template <int BN, int TM, int NST, int MODE, int LW = 0, int WD = 0, int KS = 0>
 static int launch_conv2m(const Conv2KArgs& k, hipStream_t st) {
   constexpr int WM = (BN == 64) ? 4 : 2;
   constexpr int BM = WM * TM * 16;
@@ -451,8 +491,8 @@ static int launch_conv2m(const Conv2KArgs& k, hipStream_t st) {
   const size_t lds = ring > epi ? ring : epi;
   static SimtLdsAttrCache attr_cache;
   if (simt_lds_attr_needed(&attr_cache, lds))
-    (void)hipFuncSetAttribute((const void*)conv_igemm2x_kernel<BN, TM, NST, MODE, LW, WD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((conv_igemm2x_kernel<BN, TM, NST, MODE, LW, WD>), dim3(k.ntiles_m * k.ntiles_n), dim3(512 + LW * 64), lds, st, k);
+    (void)hipFuncSetAttribute((const void*)conv_igemm2x_kernel<BN, TM, NST, MODE, LW, WD, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((conv_igemm2x_kernel<BN, TM, NST, MODE, LW, WD, KS>), dim3(k.ntiles_m * k.ntiles_n), dim3(512 + LW * 64), lds, st, k);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
@@ -463,7 +503,13 @@ bool simt_conv_igemm3_enabled();
 
 template <int BN, int TM, int NST>
 static bool abl_launch(const Conv2KArgs& k, hipStream_t st, int* rc) {
-  static const int mode = conv2_env("SIMT_CONV2_MODE"), lw = conv2_env("SIMT_CONV2_LW");
+  static const int mode = conv2_env("SIMT_CONV2_MODE"), lw = conv2_env("SIMT_CONV2_LW"), ks = conv2_env("SIMT_CONV2_KSTAMP");
+  if constexpr (BN == 256 && TM == 5 && NST == 3) {      // K-loop stamps: the dominant tile, product and compute-only builds
+    if (ks && mode == 0) { *rc = launch_conv2m<BN, TM, NST, 0, 0, 0, 1>(k, st); return true; }
+    if (ks && mode == 2) { *rc = launch_conv2m<BN, TM, NST, 2, 0, 0, 1>(k, st); return true; }
+    if (ks && mode == 1) { *rc = launch_conv2m<BN, TM, NST, 1, 0, 0, 1>(k, st); return true; }
+  }
+  if (mode == 0 && conv2_env("SIMT_CONV2_ABL0")) { *rc = launch_conv2m<BN, TM, NST, 0>(k, st); return true; }      // the experiments TU's copy of the product kernel (its own g_stamps)
   if (mode == 1) { *rc = launch_conv2m<BN, TM, NST, 1>(k, st); return true; }
   if (mode == 2) { *rc = launch_conv2m<BN, TM, NST, 2>(k, st); return true; }
   if (mode == 3) { *rc = launch_conv2m<BN, TM, NST, 3>(k, st); return true; }

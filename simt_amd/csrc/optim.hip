@@ -23,10 +23,13 @@ struct SgdArgs {
   float lr[4], wd[4];
   float momentum, dampening;
   int first_step;
+  const unsigned long long* skip_if;   // simt_sgd_desc.skip_if: the launch changes nothing while this device word is non-zero
 };
 
 __global__ __launch_bounds__(256) void sgd_multi_kernel(SgdArgs a) {
   const int ch = blockIdx.x;
+  // a fused-BatchNorm launch of this step bailed out (its polling timed out: conv2_epilogue.h): its gradients are not to be applied
+  if (a.skip_if && __hip_atomic_load(a.skip_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return;
   const SgdSeg s = a.segs[a.chunks[2 * ch]];
   const long long start = (long long)a.chunks[2 * ch + 1] * a.chunk;
   long long end = start + a.chunk;
@@ -72,6 +75,7 @@ extern "C" int simt_sgd_multi(const simt_sgd_desc* d, simt_stream_t stream) {
   a.segs = (const SgdSeg*)d->segs; a.chunks = (const int*)d->chunks; a.nchunks = d->nchunks; a.chunk = d->chunk;
   for (int i = 0; i < 4; ++i) { a.lr[i] = d->lr[i]; a.wd[i] = d->wd[i]; }
   a.momentum = d->momentum; a.dampening = d->dampening; a.first_step = d->first_step;
+  a.skip_if = (const unsigned long long*)d->skip_if;
   hipLaunchKernelGGL(sgd_multi_kernel, dim3(d->nchunks), dim3(256), 0, (hipStream_t)stream, a);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;

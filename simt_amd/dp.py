@@ -46,6 +46,8 @@ class BucketReducer:
         self.avg = backend == "nccl"
         self.handles = []
         self.next = 0
+        self.released = [None] * len(buckets)     # per bucket: the launch-list index the backward replay had reached when it was released
+        self.total_launches = None                # set by the trainer: entries of the backward launch list (for reading `released`)
         # self-diagnosis of a multi-GPU run (bench.py "comm"): per finish() an event pair around the wait of the calling stream
         self.measure = False
         self._waits = []          # [(event before the wait, event after it, host seconds spent in handle.wait())]
@@ -64,11 +66,18 @@ class BucketReducer:
         return {"bytes_per_step": int(self.bytes_per_step()), "buckets": len(self.buckets),
                 "bucket_bytes": [int((e - s) * self.flat.element_size()) for s, e, _ in self.buckets],
                 "extra_tensors": len(self.extra), "world": self.world, "op": "AVG" if self.avg else "SUM+div",
+                # when each bucket left for the all-reduce in the LAST step: the backward launch-list index the replay had reached (-1: at
+                # finish(), after the last hook) beside the index at which its last gradient becomes final, and the length of the list --
+                # a low scaling number reads as "exposed wait" (above) or as "late release" (released >> ready) without a second run
+                "bucket_ready_launch": [int(r) for _s, _e, r in self.buckets],
+                "bucket_released_launch": [(-1 if (x is None or x >= (1 << 59)) else int(x)) for x in self.released],
+                "backward_launches": self.total_launches,
                 "exposed_wait_ms_median": round(ms[len(ms) // 2], 4) if ms else None,
                 "exposed_wait_ms_max": round(ms[-1], 4) if ms else None, "steps_measured": len(ms)}
 
     def start(self):
         self.handles, self.next = [], 0
+        self.released = [None] * len(self.buckets)
 
     def _reduce(self, t):
         if self.world == 1:
@@ -83,6 +92,7 @@ class BucketReducer:
         event on the stream that writes the gradients (the plan's side stream) covering those entries."""
         while self.next < len(self.buckets) and self.buckets[self.next][2] <= launch_index:
             s, e, _ = self.buckets[self.next]
+            self.released[self.next] = launch_index
             self.next += 1
             if self.world == 1:
                 continue

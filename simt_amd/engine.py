@@ -249,7 +249,7 @@ class TrunkPlan:
     """
 
     def __init__(self, params, B, H, W, heads, *, dtype=torch.bfloat16, train=True, layers=LAYERS, device=None,
-                 need_input_grads=True, grad_names=None, grads_from_layer=0, stem_from=None):
+                 need_input_grads=True, grad_names=None, grads_from_layer=0, stem_from=None, data_parallel=False):
         self.p = params
         self.B, self.H, self.W = B, H, W
         self.heads = heads
@@ -278,11 +278,20 @@ class TrunkPlan:
         # sums through polled granules, so all of them must be resident at once.  Measured on the production step (profiles/
         # r04_bn_fusion.txt): the BACKWARD form (dgrad + BatchNorm backward in one launch) is worth -0.2 ms; the FORWARD form is +0.75 ms
         # slower in the step although it is 5 us faster per launch alone -- its waiting workgroups hold CUs the frozen forward on the side
-        # stream wants.  Default 3 = backward only.  ONE training plan per device may use it: two processes on one GPU (only the 1-GPU test
-        # rigs do that) must set SIMT_BN_GRID=0, or their waiting launches can starve each other (the kernel traps after ~2 s).
-        g = os.environ.get("SIMT_BN_GRID", "3")      # 0 off, 1 forward + backward, 2 forward only, 3 backward only
+        # stream wants.  Default 3 = backward only -- for a plan that has the GPU to itself.  A waiting launch needs ALL its workgroups resident
+        # (255 of 256 CUs, 156 KB of LDS each): under data parallelism the bucketed all-reduce's persistent RCCL kernels hold CUs and spin on
+        # remote peers during exactly these launches, and a second process on the same GPU can starve it outright.  So: `data_parallel` plans
+        # (the trainers pass process_group is not None) default to 0 = two-pass BatchNorm; SIMT_BN_GRID set explicitly always wins (opt in after a
+        # multi-GPU soak).  A launch whose polling times out (~2 s) no longer traps: it sets the plan's sticky error word `fbn_err` and ends;
+        # fbn_error() reports it, the trainers' losses() raise, and the optimiser kernels skip their update while it is set (skip_if).
+        g = os.environ.get("SIMT_BN_GRID")           # 0 off, 1 forward + backward, 2 forward only, 3 backward only
+        if g is None:
+            g = "0" if data_parallel else "3"
+        self.data_parallel = bool(data_parallel)
         self._fbn_on = train and dtype == torch.bfloat16 and g != "0"
         self._fbn_dirs = {"1": (1, 2), "2": (1,), "3": (2,)}.get(g, ())
+        self.fbn_err = None                          # one int64 device word shared by every fused launch of this plan (allocated on first use)
+        self.fbn_launches = 0                        # fused BatchNorm launches in the plan's lists (0: fbn_error() never synchronises)
         self.pack_list = LaunchList()
         self.fwd_list = LaunchList()
         self.bwd_list = LaunchList()
@@ -305,6 +314,17 @@ class TrunkPlan:
         sub.items = [it for it in self._pack_items_raw if it.fn is not lib.simt_pack_weight or it.args[0] in ptrs]
         sub._tables = sub.coalesce_packs(self.dev)
         return sub
+
+    def fbn_error(self):
+        """True if a fused-BatchNorm launch of this plan gave up polling (its workgroups were not all resident within ~2 s: another
+        process's waiting launch or a collective's persistent kernels held CUs).  Synchronises the device; the word is sticky."""
+        return self.fbn_err is not None and int(self.fbn_err.item()) != 0
+
+    def raise_on_fbn_error(self):
+        if self.fbn_error():
+            raise RuntimeError("a fused BatchNorm launch (SIMT_BN_GRID) timed out waiting for its workgroups to become co-resident: its outputs "
+                               "are undefined and the optimiser skipped the update; rebuild the trainer with SIMT_BN_GRID=0 (two-pass BatchNorm) -- "
+                               "required when several processes share a GPU, the default under data parallelism")
 
     # ------------------------------------------------------------------ buffers
     def buf(self, role, *shape, dtype=None, zero=False):
@@ -412,6 +432,10 @@ class TrunkPlan:
             fd.mode, fd.ldo, fd.out = fbn["mode"], fbn["out"].shape[-1], fbn["out"].data_ptr()
             # counters + granule buffers of THIS BatchNorm and direction (zeroed once; tags make every launch's granules its own)
             fd.work = self.new(L.load().simt_conv_fbn_words(C.byref(d)), dtype=torch.int64, zero=True).data_ptr()
+            if self.fbn_err is None:
+                self.fbn_err = self.new(1, dtype=torch.int64, zero=True)
+            fd.err = self.fbn_err.data_ptr()
+            self.fbn_launches += 1
             if fd.mode == 1:
                 bname = fbn["bname"]
                 fd.gamma, fd.beta = self.p[bname + ".weight"].data_ptr(), self.p[bname + ".bias"].data_ptr()

@@ -82,12 +82,12 @@ ASSP_BRANCHES = ((1, 1, 1), (2, 3, 6), (3, 3, 12), (4, 3, 18), (5, 1, 1))   # (i
 
 class V3Plan(TrunkPlan):
     def __init__(self, params, B, H, W, nc, openc=0, openset=False, *, dtype=torch.bfloat16, train=True, device=None,
-                 layers=(3, 4, 6), width=64, assp_ch=256):
+                 layers=(3, 4, 6), width=64, assp_ch=256, data_parallel=False):
         self.nc, self.openc, self.openset = nc, (openc if openset else 0), openset
         self.Q = self.nc + self.openc
         self.v3_layers, self.width, self.assp_ch = tuple(layers), width, assp_ch
         self.groups = [("conv", nc)] + ([("conv_1", openc)] if openset else [])
-        super().__init__(params, B, H, W, [], dtype=dtype, train=train, layers=(0, 0, 0, 0), device=device)
+        super().__init__(params, B, H, W, [], dtype=dtype, train=train, layers=(0, 0, 0, 0), device=device, data_parallel=data_parallel)
 
     # ------------------------------------------------------------------ helpers
     def _bn_conv_relu(self, f, x, cname, bname, y, a, *, M, cin, cout, Hi, Wi, Ho, Wo, k, dil=1, stride=1, Bn=None, taps=None,

@@ -76,7 +76,8 @@ class SimTTrainer:
                              for k, v in fixed_state.items()}
         kw = {"layers": layers} if layers is not None else {}
         self.plan = TrunkPlan(self.params, B, H, W, multi_heads(Cn, K, openset), dtype=dtype, train=True,
-                              grads_from_layer=3 if getattr(hp, "skip_unapplied_grads", False) else 0, **kw)
+                              grads_from_layer=3 if getattr(hp, "skip_unapplied_grads", False) else 0,
+                              data_parallel=process_group is not None, **kw)
         # the frozen model sees the same image: it reuses the trainable plan's stem im2col matrix (one im2col per micro-batch)
         self.fixed = TrunkPlan(self.fixed_params, B, H, W, multi_heads(Cn, 0, False), dtype=dtype, train=False,
                                stem_from=self.plan, **kw)
@@ -189,16 +190,26 @@ class SimTTrainer:
         self.reducer = None
         if self.pg is not None:
             from .dp import BucketReducer, make_buckets
-            sizes = {n: k for n, (_o, k) in self.plan.grad_offsets.items()}
-            # Only gradients the optimiser APPLIES cross xGMI: layer3, layer4 and the heads = the head of the flat buffer
-            # (174 of 180 MB).  conv1 / layer1 / layer2 gradients are computed like the reference computes them (unless
-            # skip_unapplied_grads) but the SimT stage's SGD never lists them (model/deeplab_multi.py:194-237): they stay rank-local.
-            applied = set(self.sgd_names)
-            order = [n for n in self.plan.grad_order if n in applied and self.plan.grad_ready.get(n, 0) > 0]
-            assert order == self.plan.grad_order[:len(order)], "applied gradients must form a prefix of the flat buffer"
-            end = sum(sizes[n] for n in order)
-            buckets = make_buckets(order, sizes, self.plan.grad_ready, bucket_elems=8 << 20)
-            self.reducer = BucketReducer(self.plan.flat_grad[:end], buckets, group=self.pg, extra=[self._ntm_grad_flat])
+            order, sizes, end = self.exchange_table()
+            buckets = make_buckets(order, sizes, self.plan.grad_ready, bucket_elems=self.BUCKET_ELEMS)
+            # the bad-label count (lout[12], accumulated by simt_ntm_post) rides in the same exchange: after the mean every rank holds
+            # total / world, so losses() needs no collective of its own and every rank raises in the same call
+            self.reducer = BucketReducer(self.plan.flat_grad[:end], buckets, group=self.pg, extra=[self._ntm_grad_flat, self.lout[12:13]])
+            self.reducer.total_launches = len(self.plan.bwd_list.items)
+
+    BUCKET_ELEMS = 8 << 20      # 32 MB of fp32 per all-reduce: few large messages for xGMI rings (dp.py)
+
+    def exchange_table(self):
+        """(order, sizes, end): the gradients the data-parallel exchange carries, in flat-buffer order, their padded spans in elements and
+        the length of the prefix of `plan.flat_grad` they form.  Only gradients the optimiser APPLIES cross xGMI: layer3, layer4
+        and the heads = the head of the flat buffer (169 of 180 MB).  conv1 / layer1 / layer2 gradients are computed like the reference
+        computes them (unless skip_unapplied_grads) but the SimT stage's SGD never lists them (model/deeplab_multi.py:194-237): they stay
+        rank-local.  (tests/golden/g16_dp_bucket_table.json is this table for BASELINE configs[1..2], profiles/tools/dump_bucket_table.py.)"""
+        sizes = {n: k for n, (_o, k) in self.plan.grad_offsets.items()}
+        applied = set(self.sgd_names)
+        order = [n for n in self.plan.grad_order if n in applied and self.plan.grad_ready.get(n, 0) > 0]
+        assert order == self.plan.grad_order[:len(order)], "applied gradients must form a prefix of the flat buffer"
+        return order, sizes, sum(sizes[n] for n in order)
 
     # ------------------------------------------------------------------ optimiser plumbing
     def _build_sgd(self, roots=("layer3", "layer4")):
@@ -224,6 +235,8 @@ class SimTTrainer:
         d = L.SgdDesc()
         d.segs, d.chunks, d.nchunks, d.chunk = self.sgd_segs.data_ptr(), self.sgd_chunks.data_ptr(), len(chunks), chunk
         d.momentum, d.dampening = self.hp.momentum, 0.0
+        if getattr(self.plan, "fbn_err", None) is not None:      # a fused BatchNorm launch that gave up polling: no update (engine.TrunkPlan.fbn_error)
+            d.skip_if = self.plan.fbn_err.data_ptr()
         self.sgd_desc = d
 
     # ------------------------------------------------------------------ one iteration
@@ -482,16 +495,17 @@ class SimTTrainer:
         return [self.fixed.fwd_list, self.plan.fwd_list, self.plan.bwd_list]
 
     def losses(self):
-        """Host copy of the scalars of the last step (synchronises)."""
+        """Host copy of the scalars of the last step.  Synchronises the device; LOCAL (no collective: under data parallelism the
+        bad-label count travels with the gradient exchange, so a rank may call this alone, e.g. rank 0 for logging -- but a rank that
+        raises alone leaves its peers blocked in their next all-reduce, so training loops call it on every rank at the same iterations).
+        Raises ValueError for labels outside [0, C) other than 255 seen in ANY micro-batch on ANY rank since the last call
+        (utils/loss.py:36 raises at once), RuntimeError if a fused BatchNorm launch timed out (TrunkPlan.fbn_error)."""
         v = self.lout.cpu().tolist()                  # ONE device-to-host copy: the scalars and the bad-label count (lout[12])
-        bad = int(v[12])                               # accumulated by simt_ntm_post over every micro-batch since the last call
+        self.plan.raise_on_fbn_error()
+        # accumulated by simt_ntm_post over every micro-batch since the last call; data parallel: the exchange leaves total / world on every rank
+        bad = int(round(v[12] * (self.reducer.world if self.reducer is not None else 1)))
         if bad:
             self.lout[12] = 0.0
-        if self.pg is not None:                        # data parallel: every rank calls losses() and every rank raises (a rank that
-            import torch.distributed as dist           # raised alone would leave the others blocked in the next all-reduce)
-            flag = torch.tensor([float(bad)], device=self.dev if dist.get_backend(self.pg) == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.pg)
-            bad = int(flag.item())
         if bad:          # utils/loss.py:36 / nn.CrossEntropyLoss raise on such a target; the kernels skip the pixel and count it
             raise ValueError(f"{bad} label value(s) outside [0, {self.hp.num_classes}) that are not the ignore value 255")
         keys = ["total", "loss_p1", "loss_p2", "loss_y1", "loss_y2", "place", "convex", "volume", "anchor", "vol_ok"]
@@ -512,12 +526,16 @@ class WarmupTrainer:
         f32 = torch.float32
         self.params = {k: v.detach().to(dev, f32 if v.dtype != torch.long else torch.long).clone() for k, v in state.items()}
         kw = {"layers": layers} if layers is not None else {}
-        self.plan = TrunkPlan(self.params, B, H, W, multi_heads(Cn, 0, False), dtype=dtype, train=True, **kw)
+        self.plan = TrunkPlan(self.params, B, H, W, multi_heads(Cn, 0, False), dtype=dtype, train=True,
+                              data_parallel=process_group is not None, **kw)
         h, w = self.plan.heads[1].h, self.plan.heads[1].w
         lib = L.load()
         self.part = torch.zeros(lib.simt_head_nblk(B, H, W), lib.simt_head_part_floats(Cn, Cn), device=dev)
         self.keys = torch.zeros(lib.simt_head_keys_count(), device=dev, dtype=torch.int64)
         self.hout = torch.zeros(lib.simt_head_hout_floats(Cn, Cn), device=dev)
+        # labels outside [0, C) other than 255, ACCUMULATED over every micro-batch of every step until losses() reads and clears it (hout[15]
+        # itself is overwritten by each head launch; nn.CrossEntropyLoss(ignore_index=255) raises on the first one, trainV1_warmup.py:217-224)
+        self.bad_labels = torch.zeros(1, device=dev)
         self.QP = ops.round_up(Cn, 8)
         self.g1 = torch.zeros(2, B, H, w, self.QP, device=dev)
         self.label = torch.zeros(B, H, W, device=dev, dtype=torch.int64)
@@ -540,7 +558,7 @@ class WarmupTrainer:
             from .dp import BucketReducer, make_buckets
             sizes = {n: k for n, (_o, k) in self.plan.grad_offsets.items()}
             buckets = make_buckets(self.plan.grad_order, sizes, self.plan.grad_ready, bucket_elems=8 << 20)
-            self.reducer = BucketReducer(self.plan.flat_grad, buckets, group=self.pg)
+            self.reducer = BucketReducer(self.plan.flat_grad, buckets, group=self.pg, extra=[self.bad_labels])
         self._grad_acc = None
 
     def step(self, image, label, it=None):
@@ -560,6 +578,7 @@ class WarmupTrainer:
             self.label.copy_(lab, non_blocking=True)
             self.plan.forward()
             L.call("simt_head_loss", C.byref(self.head_desc), st)
+            L.call("simt_vec_acc", self.bad_labels.data_ptr(), self.hout.data_ptr() + 4 * 15, 1, 1, st)      # every micro-batch counts
             L.call("simt_head_grad", C.byref(self.head_desc), st)
             if self.reducer is not None and hp.iter_size == 1:
                 self.reducer.start()
@@ -596,13 +615,13 @@ class WarmupTrainer:
         return sd
 
     def losses(self):
-        v = self.hout[:16].cpu().tolist()
-        bad = int(v[15])
-        if self.pg is not None:                        # data parallel: every rank calls losses(), every rank raises
-            import torch.distributed as dist
-            flag = torch.tensor([float(bad)], device=self.dev if dist.get_backend(self.pg) == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.pg)
-            bad = int(flag.item())
+        """Host copy of the last micro-batch's scalars; local (see SimTTrainer.losses).  The bad-label count covers EVERY micro-batch of every
+        step since the last call (a device-side accumulator; under data parallelism it rides in the gradient exchange)."""
+        v = torch.cat([self.hout[:16], self.bad_labels]).cpu().tolist()
+        self.plan.raise_on_fbn_error()
+        bad = int(round(v[16] * (self.reducer.world if self.reducer is not None else 1)))
+        if bad:
+            self.bad_labels.zero_()
         if bad:          # nn.CrossEntropyLoss(ignore_index=255) raises on such a target (trainV1_warmup.py:217-224)
             raise ValueError(f"{bad} label value(s) outside [0, {self.hp.num_classes}) that are not the ignore value 255")
         # `loss = loss / args.iter_size` (trainV1_warmup.py:227): the reported total is the scaled one, like SimTTrainer's

@@ -48,7 +48,7 @@ class SimTSingleTrainer:
         arch = dict(arch or {})
         if model == "v3":
             from .engine_v3 import V3Plan
-            self.plan = V3Plan(self.params, B, H, W, Cn, K, True, dtype=dtype, train=True, **arch)
+            self.plan = V3Plan(self.params, B, H, W, Cn, K, True, dtype=dtype, train=True, data_parallel=process_group is not None, **arch)
             self.fixed = V3Plan(self.fixed_params, B, H, W, Cn, 0, False, dtype=dtype, train=False, **arch)
             # the in-model upsample (last forward launch) and its adjoint (first backward launch) are fused into the head kernel
             assert self.plan.fwd_list.items[-1].tag == "simt_upsample_nchw" and self.fixed.fwd_list.items[-1].tag == "simt_upsample_nchw"
@@ -64,7 +64,7 @@ class SimTSingleTrainer:
             half, fix_logits = 1, 1
         else:
             from .engine_vgg import VggPlan
-            self.plan = VggPlan(self.params, B, H, W, Q, dtype=dtype, train=True, **arch)
+            self.plan = VggPlan(self.params, B, H, W, Q, dtype=dtype, train=True, data_parallel=process_group is not None, **arch)
             self.fixed = VggPlan(self.fixed_params, B, H, W, Cn, dtype=dtype, train=False, **arch)
             self._fwd, self._fix_fwd, self._bwd = self.plan.fwd_list, self.fixed.fwd_list, self.plan.bwd_list
             h, w = self.plan.heads[0].h, self.plan.heads[0].w
@@ -126,7 +126,7 @@ class SimTSingleTrainer:
             from .dp import BucketReducer, make_buckets
             sizes = {n: k for n, (_o, k) in self.plan.grad_offsets.items()}
             buckets = make_buckets(self.plan.grad_order, sizes, self.plan.grad_ready, bucket_elems=8 << 20)
-            self.reducer = BucketReducer(self.plan.flat_grad, buckets, group=self.pg, extra=[self.ntm_grad])
+            self.reducer = BucketReducer(self.plan.flat_grad, buckets, group=self.pg, extra=[self.ntm_grad, self.lout[12:13]])
 
     # ------------------------------------------------------------------ optimiser
     def optim_groups(self):
@@ -157,6 +157,8 @@ class SimTSingleTrainer:
         d = L.SgdDesc()
         d.segs, d.chunks, d.nchunks, d.chunk = self.sgd_segs.data_ptr(), self.sgd_chunks.data_ptr(), len(chunks), chunk
         d.momentum, d.dampening = self.hp.momentum, 0.0
+        if getattr(self.plan, "fbn_err", None) is not None:      # a fused BatchNorm launch that gave up polling: no update (engine.TrunkPlan.fbn_error)
+            d.skip_if = self.plan.fbn_err.data_ptr()
         self.sgd_desc = d
 
     # ------------------------------------------------------------------ one iteration
@@ -220,15 +222,13 @@ class SimTSingleTrainer:
         return [self._fix_fwd, self._fwd, self._bwd]
 
     def losses(self):
+        """Local (no collective): see SimTTrainer.losses."""
         v = self.lout.cpu().tolist()                  # ONE device-to-host copy: the scalars and the bad-label count (lout[12])
-        bad = int(v[12])                               # accumulated by simt_ntm_post over every micro-batch since the last call
+        self.plan.raise_on_fbn_error()
+        # accumulated by simt_ntm_post since the last call; data parallel: the gradient exchange leaves total / world on every rank
+        bad = int(round(v[12] * (self.reducer.world if self.reducer is not None else 1)))
         if bad:
             self.lout[12] = 0.0
-        if self.pg is not None:                        # data parallel: every rank calls losses() and every rank raises (a rank that
-            import torch.distributed as dist           # raised alone would leave the others blocked in the next all-reduce)
-            flag = torch.tensor([float(bad)], device=self.dev if dist.get_backend(self.pg) == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.pg)
-            bad = int(flag.item())
         if bad:          # the reference's nll_loss raises on such a target; the kernels skip the pixel and count it
             raise ValueError(f"{bad} label value(s) outside [0, {self.hp.num_classes}) that are not the ignore value 255")
         return {"total": v[0], "loss_p": v[2], "loss_y": v[4], "place": v[5], "convex": v[6], "volume": v[7], "anchor": v[8],

@@ -178,3 +178,164 @@ def test_dp_step_equals_oracle_on_mean_gradients_world2():
         loss_only = sum(r.ntm[k].grad - lk for r in singles) / 2
         assert lk.abs().max() > 1e-3
         assert torch.allclose(reps[0].ntm[k].grad, lk + loss_only, rtol=1e-5, atol=1e-7)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# World size 8 (BASELINE configs[2]: 8 x MI355X, global batch 32) on the REAL exchange table of the production plan
+# (tests/golden/g16_dp_bucket_table.json, written on a GPU box by profiles/tools/dump_bucket_table.py; tests/test_gpu_dp.py checks
+# that the live plan still produces it): 96 gradient tensors, 42.2 M fp32 = 168.7 MB, five buckets of 33 / 32 / 33 / 34 / 28 MB that
+# become ready at backward launches 41 / 77 / 125 / 197 / 238 of 322.  Eight gloo ranks release the buckets at the replay's real hook
+# points, exactly like TrunkPlan.backward(hook=...) with the early optimiser step does, and must end with the mean.
+# ----------------------------------------------------------------------------------------------------------------------
+def _real_table():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g16_dp_bucket_table.json")) as f:
+        return json.load(f)
+
+
+def test_real_bucket_table_shape():
+    t = _real_table()
+    sizes, ready = dict(zip(t["order"], t["sizes"])), dict(zip(t["order"], t["ready"]))
+    b = make_buckets(t["order"], sizes, ready, bucket_elems=t["bucket_elems"])
+    assert [list(x) for x in b] == t["buckets"]                                   # the committed cut is what make_buckets produces
+    assert b[0][0] == 0 and b[-1][1] == t["end"] == sum(t["sizes"]) and t["end"] <= t["flat_elems"]
+    assert all(e0 == s1 for (_s0, e0, _r0), (s1, _e1, _r1) in zip(b, b[1:]))      # contiguous cover of the applied prefix
+    assert [r for _s, _e, r in b] == sorted(r for _s, _e, r in b)                 # monotone readiness
+    assert all(e - s >= t["bucket_elems"] for s, e, _ in b[:-1]) and 0 < b[-1][1] - b[-1][0] < t["bucket_elems"]      # uneven last bucket
+    assert all(s % 4 == 0 for s, _e, _r in b)                                     # 16-byte aligned starts (float4 reduce kernels write them)
+    # every bucket is final strictly before the early optimiser step's cut, which itself lies inside the backward list: the whole exchange
+    # can overlap the rest of the backward (layer 2 / layer 1 / stem, whose gradients stay rank-local)
+    assert all(r in t["hook_points"] for _s, _e, r in b) and b[-1][2] <= t["early_cut"] < t["backward_launches"]
+    assert 160e6 < t["end"] * 4 < 180e6
+
+
+def _world8_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t = _real_table()
+        sizes, ready = dict(zip(t["order"], t["sizes"])), dict(zip(t["order"], t["ready"]))
+        n = t["end"]
+        # rank r holds (r + 1) * g(i) + r: the mean over 8 ranks is 4.5 * g(i) + 3.5 in closed form (no 1.3 GB all-gather to check it)
+        g = ((torch.arange(n, dtype=torch.float32) % 1021.0) - 510.0) / 64.0
+        flat = g * float(rank + 1) + float(rank)
+        ntm = torch.full((2, 22, 19), float(rank + 1))
+        bad = torch.tensor([3.0 if rank == 5 else 0.0])      # rank 5 saw three bad labels this step (lout[12]; step.SimTTrainer)
+        red = BucketReducer(flat, make_buckets(t["order"], sizes, ready, bucket_elems=t["bucket_elems"]), group=dist.group.WORLD,
+                            extra=[ntm, bad])
+        red.total_launches = t["backward_launches"]
+        red.measure = True
+        red.start()
+        released_at = []
+        for hp in t["hook_points"]:                    # the replay's cut points, in order; the early optimiser step fires at early_cut
+            before = red.next
+            red.ready_upto(hp)
+            released_at += [hp] * (red.next - before)
+            if hp >= t["early_cut"]:
+                break
+        assert red.next == len(red.buckets), "a bucket would only leave at finish()"
+        red.finish()
+        rep = red.report()
+        ok = (torch.allclose(flat, g * 4.5 + 3.5, rtol=1e-6, atol=1e-5) and torch.allclose(ntm, torch.full_like(ntm, 4.5))
+              and abs(float(bad) * world - 3.0) < 1e-5                       # losses(): total = mean * world on EVERY rank, no collective
+              and rep["bucket_released_launch"] == released_at == rep["bucket_ready_launch"]      # released at the very hook that made them final
+              and rep["backward_launches"] == t["backward_launches"] and rep["buckets"] == 5 and rep["world"] == 8
+              and rep["bytes_per_step"] == (n + ntm.numel() + 1) * 4)
+        q.put((rank, bool(ok), released_at))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_reducer_world8_real_table():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_world8_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [(r, ok) for r, ok, _ in res] == [(r, True) for r in range(8)]
+    assert all(rel == res[0][2] for _r, _ok, rel in res)
+
+
+# oracle_dp_step at world size 8: eight micro-batches, one mean (toy trunk; the full-size exchange is the test above)
+def _dp8_worker(rank, world, port, q):
+    from oracle import simt_oracle as so
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mk, _ = _dp_case()
+        cd = so.load_class_dist()
+        batch = so.synthetic_batch(1, 65, 65, cd.numpy(), seed=300 + 7 * rank, block=8)
+        orc = mk()
+        orc.step(*batch, 0, apply=False)
+        grads = orc.applied_grads()
+        names = [n for n in grads if not n.startswith("NTM")]
+        sizes = {n: grads[n].numel() for n in names}
+        flat = torch.cat([grads[n].flatten() for n in names])
+        extra = torch.stack([grads["NTM1"], grads["NTM2"]]).clone()
+        red = BucketReducer(flat, make_buckets(names, sizes, {n: i for i, n in enumerate(names)}, bucket_elems=1 << 15),
+                            group=dist.group.WORLD, extra=[extra])
+        red.start()
+        for k in range(0, len(names), 3):
+            red.ready_upto(k)
+        red.finish()
+        off = 0
+        with torch.no_grad():
+            for n in names:
+                grads[n].copy_(flat[off:off + sizes[n]].view_as(grads[n]))
+                off += sizes[n]
+            grads["NTM1"].copy_(extra[0])
+            grads["NTM2"].copy_(extra[1])
+        orc.apply_update(0)
+        keep = ("layer6.conv2d_list.0.weight", "layer5.conv2d_list.1.bias", "layer3.0.conv1.weight", "layer4.0.conv2.weight")
+        res = {n: orc.st[n].detach().clone().numpy() for n in keep}
+        res["NTM1"], res["NTM2"] = orc.ntm[0].detach().clone().numpy(), orc.ntm[1].detach().clone().numpy()
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_step_equals_oracle_on_mean_gradients_world8():
+    from oracle import simt_oracle as so
+    import numpy as np
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp8_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    mk, _ = _dp_case()
+    cd = so.load_class_dist()
+    batches = [so.synthetic_batch(1, 65, 65, cd.numpy(), seed=300 + 7 * r, block=8) for r in range(8)]
+    reps = [mk() for _ in range(8)]
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(1)            # like the workers: fp32 CPU convs differ in the last bits between thread counts
+    try:
+        so.oracle_dp_step(reps, [b[0] for b in batches], [b[1] for b in batches], 0)
+    finally:
+        torch.set_num_threads(nthr)
+    res = sorted((q.get(timeout=900) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, params in res:
+        for n, v in params.items():
+            ref = {"NTM1": reps[rank].ntm[0], "NTM2": reps[rank].ntm[1]}.get(n)
+            ref = (ref if ref is not None else reps[rank].st[n]).detach().numpy()
+            assert np.allclose(v, ref, rtol=2e-6, atol=2e-7), (rank, n, np.abs(v - ref).max())
+        for n in params:                               # replicas bit-identical
+            assert np.array_equal(params[n], res[0][1][n]), n

@@ -10,6 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -199,3 +201,14 @@ def test_two_rank_dp_step_matches_oracle_on_mean_gradients(dev, case):
     n = "layer6.conv2d_list.0.weight"
     p0, ps = st[n].double().numpy(), solo.st[n].detach().double().numpy()
     assert np.linalg.norm(res[0][1][n] - ps) / np.linalg.norm(ps - p0) > 5e-2
+
+
+def test_live_plan_produces_the_committed_bucket_table(dev):
+    """tests/golden/g16_dp_bucket_table.json (what the world-size-8 gloo test on CPU replays) is the production plan's table."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
+    import dump_bucket_table
+    with open(os.path.join(ROOT, "tests", "golden", "g16_dp_bucket_table.json")) as f:
+        ref = json.load(f)
+    assert dump_bucket_table.table() == ref

@@ -38,6 +38,49 @@ def _rel(a, b):
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
 
 
+# ---- the bf16 per-op bar, tied to the STORAGE FORMAT (round 5) -------------------------------------------------------------
+# `_rel < 1e-2 of max|ref|` is 10-50x looser than one bf16 ulp of a typical element: round 4's stale-dword store bug passed it.  Here every
+# element is compared with the float64 result of the same op on the same bf16 operands (shifted float64 matmuls on the device: test
+# infrastructure, the product never calls a vendor GEMM):
+#     |got - ref| <= 1 ulp_bf16(ref) + 16 * sqrt(K) * 2^-24 * rms(ref)        (one rounding of an fp32 sum of K products)
+# for EVERY element, and got == bf16(ref) exactly for at least `exact_min` of them (what is left are round-to-nearest ties decided by the
+# last bits of the fp32 sum).  ulp_bf16(v) = 2^(floor(log2 |v|) - 7), floored at the ulp of rms * 2^-6 so that near-zero results are held to
+# the accumulation slack, not to a vanishing ulp.
+def _conv64(x_nhwc, w_oihw, stride, pad, dil):
+    """float64 conv of NHWC x (any float dtype, on the device) with OIHW weights -> [B, Ho, Wo, Cout] float64, as k*k shifted matmuls."""
+    B, H, W, Cin = x_nhwc.shape
+    Cout, _, kh, kw = w_oihw.shape
+    Ho, Wo = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1, (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    xp = F.pad(x_nhwc.double(), (0, 0, pad, pad, pad, pad))
+    wd = w_oihw.double().to(x_nhwc.device)
+    out = torch.zeros(B * Ho * Wo, Cout, device=x_nhwc.device, dtype=torch.float64)
+    for r in range(kh):
+        for c in range(kw):
+            xs = xp[:, r * dil:r * dil + (Ho - 1) * stride + 1:stride, c * dil:c * dil + (Wo - 1) * stride + 1:stride, :]
+            out += xs.reshape(-1, Cin) @ wd[:, :, r, c].t()
+    return out.view(B, Ho, Wo, Cout)
+
+
+def _ulp_bf16(ref64, floor_at):
+    mag = ref64.abs().clamp_min(floor_at)
+    return torch.exp2(torch.floor(torch.log2(mag)) - 7.0)
+
+
+def _tight_bf16(got_bf16, ref64, K, what, exact_min=0.995):
+    """got: bf16 tensor as stored by the kernel; ref64: float64 result before the final rounding (same shape, same device)."""
+    assert got_bf16.dtype == BF and ref64.dtype == torch.float64 and got_bf16.shape == ref64.shape
+    g = got_bf16.double()
+    rms = ref64.pow(2).mean().sqrt().item()
+    tol = _ulp_bf16(ref64, rms * 2.0 ** -6) + 16.0 * (K ** 0.5) * 2.0 ** -24 * rms
+    bad = (g - ref64).abs() > tol
+    nbad = int(bad.sum().item())
+    exact = (got_bf16 == ref64.float().to(BF)).double().mean().item()
+    assert nbad == 0, (f"{what}: {nbad} of {bad.numel()} elements off by more than 1 bf16 ulp + fp32 accumulation slack (worst "
+                       f"{((g - ref64).abs() / tol).max().item():.1f} x the bound; first at {bad.nonzero()[0].tolist()})")
+    assert exact >= exact_min, f"{what}: only {exact:.5f} of the elements equal the float64 result rounded to bf16 (bar {exact_min})"
+    return exact
+
+
 def _variant(d):
     bn_, tm_, nst_ = C.c_int(), C.c_int(), C.c_int()
     gen = L.load().simt_conv_variant(C.byref(d), C.byref(bn_), C.byref(tm_), C.byref(nst_))
@@ -165,6 +208,19 @@ def test_conv_production_shapes_bf16(dev, case):
     got = y_d.float().cpu().permute(0, 3, 1, 2)
     assert torch.isfinite(got).all()
     assert _rel(got, ref) < 1e-2, f"{_id}: {_rel(got, ref)}"
+    # ---- the storage-format bar: every element within 1 bf16 ulp (+ fp32 accumulation slack) of the float64 result, >= 99.5 % exactly equal
+    r64 = _conv64(x_d, w.to(BF), stride, pad, dil)
+    if "bias" in kw:
+        r64 = r64 + kw["bias"].double().view(1, 1, 1, -1)
+    if "res" in kw:
+        rr = kw["res"].double()
+        if "res_bits" in kw:
+            rr = rr * keep.permute(0, 2, 3, 1).to(dev)
+        r64 = r64 + rr
+    if kw.get("relu"):
+        r64 = torch.relu(r64)
+    exact = _tight_bf16(y_d, r64, len(taps) * Cin, _id)
+    print(f"{_id}: {exact:.5f} of the elements equal bf16(float64 result)")
     stored = y_d.double().reshape(M, Cout)
     if stats is not None:                                  # BN batch statistics of the STORED bf16 values, every slot summed
         s = stats.double().sum(0)
@@ -185,6 +241,34 @@ def test_conv_production_shapes_bf16(dev, case):
         s1, s2 = gm.sum(0), (gm * ((yy - bnr["mean"].double()) * bnr["rstd"].double())).sum(0)
         part = bnr["part"][:nblk].double().sum(0)
         assert _rel(part[0].cpu(), s1.cpu()) < 2e-3 and _rel(part[1].cpu(), s2.cpu()) < 2e-3
+
+
+def test_storage_format_bar_is_red_on_a_corrupted_row(dev):
+    """The bar above must catch what the 1e-2-of-max bar let through in round 4 (stale dwords in single rows of a conv output): one row of a
+    correct 3x3 256 -> 256 output overwritten with its neighbour row's values differs by ~rms on 256 of 9.6 M elements -- 1e-2 of max|ref| can
+    miss it when the neighbour is close, the element-wise bar cannot; and a SINGLE element moved by two bf16 ulps passes 1e-2 and fails here."""
+    B, H, W, Cin, Cout, k, dil = B4, HW, HW, 256, 256, 3, 2
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev, BF)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k)) ** 0.5)
+    taps = ops.conv_taps(k, k, dil, dil)
+    wp = torch.zeros(Cout, len(taps) * Cin, device=dev, dtype=BF)
+    ops.pack_weight(w.to(dev).contiguous(), wp, Cout=Cout, Cin=Cin, RS=k * k, ldk=len(taps) * Cin, mode=0)
+    y = torch.empty(B, H, W, Cout, device=dev, dtype=BF)
+    ops.conv_fprop_desc(ops.make_conv_desc(x, wp, y, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=Cout, taps=taps, Npad=Cout, tile_n=256))
+    torch.cuda.synchronize()
+    r64 = _conv64(x, w.to(BF), 1, dil, dil)
+    _tight_bf16(y, r64, len(taps) * Cin, "clean output")                     # green
+    two_ulps = y.clone()
+    v = two_ulps[2, 40, 17, 100].float()
+    two_ulps[2, 40, 17, 100] = (v + 2.5 * float(_ulp_bf16(v.double().abs(), 1e-30)) * (1 if v >= 0 else -1)).to(BF)
+    assert _rel(two_ulps.float(), r64) < 1e-2                                # the old bar does not see it
+    with pytest.raises(AssertionError, match="off by more than 1 bf16 ulp"):
+        _tight_bf16(two_ulps, r64, len(taps) * Cin, "one element moved by two ulps")
+    stale = y.clone()
+    stale[1, 50, 33, 64:72] = y[1, 50, 31, 64:72]                            # eight channels (one 16-byte store) of one row from the row two pixels back
+    with pytest.raises(AssertionError, match="off by more than 1 bf16 ulp"):
+        _tight_bf16(stale, r64, len(taps) * Cin, "one stale 16-byte store")
 
 
 def test_tap_expanded_head_gemm_production(dev):
@@ -261,6 +345,19 @@ def test_wgrad_production_shapes_bf16(dev, case):
     torch.cuda.synchronize()
     assert torch.isfinite(dw).all()
     assert _rel(dw.cpu(), ref) < 1e-2, f"{_id} split {nsplit}: {_rel(dw.cpu(), ref)}"
+    # element-wise against float64 (shifted float64 matmuls on the device): an fp32 result of a sum of M products of bf16 values, split in
+    # nsplit fp32 slabs -> |got - ref| <= 16 sqrt(M) 2^-24 rms(ref) + 2^-22 |ref| for EVERY element (the 1e-2-of-max bar above is ~1000x looser)
+    xp = F.pad(x_d.double(), (0, 0, pad, pad, pad, pad))
+    dyf = dy_d.double().reshape(M, Cd)
+    r64 = torch.empty(Cd, Cin, k, k, device=dev, dtype=torch.float64)
+    for r_ in range(k):
+        for c_ in range(k):
+            xs = xp[:, r_ * dil:r_ * dil + H, c_ * dil:c_ * dil + W, :].reshape(M, Cin)
+            r64[:, :, r_, c_] = dyf.t() @ xs
+    rms = r64.pow(2).mean().sqrt().item()
+    tol = 16.0 * (M ** 0.5) * 2.0 ** -24 * rms + 2.0 ** -22 * r64.abs()
+    worst = ((dw.double() - r64).abs() / tol).max().item()
+    assert worst <= 1.0, f"{_id}: an element of the weight gradient is {worst:.1f} x its fp32 accumulation bound away from float64"
     # bitwise reproducible (fixed-order slab sum): a second launch gives the same bits
     dw2 = torch.empty_like(dw)
     ops.conv_wgrad_desc(wd)
@@ -275,6 +372,50 @@ def test_bn_production_size_bf16(dev, Cn, mode):
     from test_gpu_bn_pool import test_bn_train_forward_backward
     _threads()
     test_bn_train_forward_backward(dev, BF, Cn, B4, HW, HW, mode)
+
+
+@pytest.mark.parametrize("Cn,with_res", [(256, False), (1024, True)], ids=["bn2_256", "bn3_1024_residual_bits"])
+def test_bn_passes_storage_format_bar(dev, Cn, with_res):
+    """The element-wise BatchNorm passes at M = 37 636 held to the storage format: forward z = bf16(relu(y * scale + shift [+ x])), backward
+    dy = bf16(scale * (g - c1 - xhat * c2)) with the coefficients the kernel itself derived, both against float64 of the same expression on
+    the same bf16 operands (one rounding: K = 1), >= 99.9 % of the elements exactly equal; the ReLU bit mask equals z > 0 bit for bit."""
+    M = B4 * HW * HW
+    g = torch.Generator().manual_seed(Cn)
+    y = (torch.randn(M, Cn, generator=g) * 1.7 + 0.3).to(dev, BF)
+    scale, shift = (torch.rand(Cn, generator=g) + 0.5).to(dev), (torch.randn(Cn, generator=g) * 0.3).to(dev)
+    res = torch.randn(M, Cn, generator=g).to(dev, BF) if with_res else None
+    z = torch.empty(M, Cn, device=dev, dtype=BF)
+    bits = torch.empty(M, Cn // 8, device=dev, dtype=torch.uint8) if with_res else None
+    ops.bn_apply(y, scale, shift, z, M=M, Cn=Cn, relu=True, res=res, bits=bits)
+    torch.cuda.synchronize()
+    r64 = y.double() * scale.double() + shift.double()
+    if with_res:
+        r64 = r64 + res.double()
+    exact = _tight_bf16(z, torch.relu(r64), 1, f"bn_apply C={Cn}", exact_min=0.999)
+    print(f"bn_apply C={Cn}: {exact:.6f} exactly equal")
+    if with_res:
+        assert torch.equal(bits, _bits((z > 0).cpu()).to(dev))
+    # backward apply (mask from the bits / from y * scale + shift), coefficients from the kernel's own reduce + finalize
+    dz = (torch.randn(M, Cn, generator=g) * 1e-3).to(dev, BF)
+    mean, rstd = (torch.randn(Cn, generator=g) * 0.2).to(dev), (torch.rand(Cn, generator=g) + 0.5).to(dev)
+    part = torch.empty(ops.bn_bwd_nblk(M, Cn), 3, Cn, device=dev)
+    coef = torch.empty(3, Cn, device=dev)
+    dy = torch.empty(M, Cn, device=dev, dtype=BF)
+    d = ops.make_bn_bwd_desc(dz=dz, y=y, mean=mean, rstd=rstd, scale=scale, shift=shift, part=part, coef=coef, dy=dy, M=M, Cn=Cn,
+                             mask_mode=3 if with_res else 2, z=bits)
+    ops.bn_bwd_desc(d)
+    torch.cuda.synchronize()
+    if with_res:
+        msk = ((bits.unsqueeze(-1).to(torch.int32) >> torch.arange(8, device=dev, dtype=torch.int32)) & 1).reshape(M, Cn).bool()
+    else:
+        msk = (y.float() * scale + shift) > 0
+    gm = dz.double() * msk
+    xhat = (y.double() - mean.double()) * rstd.double()
+    c64 = torch.stack([gm.sum(0), (gm * xhat).sum(0)]) / M
+    assert _rel(coef[:2].double(), c64) < 1e-5                                # fp32 partials, double finalize
+    d64 = scale.double() * (gm - coef[0].double() - xhat * coef[1].double())
+    exact = _tight_bf16(dy, d64, 4, f"bn_bwd_apply C={Cn}", exact_min=0.999)
+    print(f"bn_bwd_apply C={Cn}: {exact:.6f} exactly equal")
 
 
 def test_stem_production_size_bf16(dev):
