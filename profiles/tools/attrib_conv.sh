@@ -3,7 +3,7 @@
 # the SQ counter passes (rocprofv3 --pmc, counters in their own runs with --kernel-trace only) of the same launches.  Output: gpurun_out/attrib/.
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/attrib; rm -rf $OUT; mkdir -p $OUT
-LIB=$ROOT/simt_amd/libsimt_hip_abl.so
+LIB=$ROOT/profiles/ab_libs/libsimt_abl.so      # (csrc/build.sh ABLATION=1, copied here: simt_amd/libsimt_hip_abl.so is gpurun-ignored)
 for m in 0 2 1; do
   SIMT_CONV2_MODE=$m SIMT_CONV2_KSTAMP=1 python3 profiles/tools/attrib_conv.py $LIB >> $OUT/stamps.txt 2>$OUT/stamps_$m.err
   SIMT_CONV2_MODE=$m SIMT_CONV2_ABL0=1 python3 profiles/tools/conv_modes.py $LIB >> $OUT/modes.txt 2>>$OUT/modes.err
