@@ -26,6 +26,13 @@ enum { SIMT_F32 = 0, SIMT_BF16 = 1 };
 #define SIMT_MAX_TAPS 36
 
 const char* simt_last_error(void);
+/* Device-scope events for ordering two HIP streams of ONE device (the launch lists of simt_amd/engine.py): like hipEventCreateWithFlags /
+ * hipEventRecord / hipStreamWaitEvent (which torch.cuda.Event wraps), but recorded with a device-scope release instead of the default
+ * system-scope fence (system_scope = 0) -- the host never inspects them.  Replaces torch.cuda.Event().record() / stream.wait_event(). */
+int simt_event_create(void** ev, int system_scope);
+int simt_event_destroy(void* ev);
+int simt_event_record(void* ev, simt_stream_t stream);
+int simt_stream_wait_event(simt_stream_t stream, void* ev);
 int simt_abi_version(void);
 
 /* ---- convolution: fprop / dgrad (implicit GEMM, MFMA) --------------------------------------------------

@@ -146,6 +146,10 @@ SIGNATURES = {
     "simt_sig_w": (_I, [c_p, c_p, c_p, c_p, _I, c_p]),
     "simt_adam_step": (_I, [c_p, c_p, c_p, c_p, _L, f32, f32, f32, f32, _I, c_p]),
     "simt_sgd_multi": (_I, [C.POINTER(SgdDesc), c_p]),
+    "simt_event_create": (_I, [C.POINTER(c_p), _I]),
+    "simt_event_destroy": (_I, [c_p]),
+    "simt_event_record": (_I, [c_p, c_p]),
+    "simt_stream_wait_event": (_I, [c_p, c_p]),
     "simt_vec_acc": (_I, [c_p, c_p, _I, _I, c_p]),
     "simt_tap_gather_sum": (_I, [C.POINTER(TapDesc), c_p]),
     "simt_tap_scatter": (_I, [C.POINTER(TapDesc), c_p]),

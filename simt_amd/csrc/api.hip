@@ -12,3 +12,30 @@ void simt_set_error(const char* file, int line, const char* msg) {
 
 extern "C" const char* simt_last_error(void) { return g_err; }
 extern "C" int simt_abi_version(void) { return 1; }
+
+// ---- device-scope events (round 5).  The launch lists order their two HIP streams with events (weight gradients behind the dgrad chain,
+// BatchNorm passes beside the frozen model's convs).  A default hipEvent performs a SYSTEM-scope release when it is recorded -- write-back
+// and invalidation of the caches so that the host could read the data -- and the stream's next kernel waits for it: ~6.5 us of idle queue
+// behind every record, ~12 us for a cross-stream wait (rocprofv3 kernel trace, profiles/r05_events.txt).  Both streams of a plan live on
+// one device: hipEventDisableTiming | hipEventReleaseToDevice | hipEventDisableSystemFence is all the ordering they need.
+extern "C" int simt_event_create(void** ev, int system_scope) {
+  SIMT_CHECK(ev);
+  hipEvent_t e;
+  // (the runtime accepts ONE of the release flags: hipEventReleaseToDevice together with hipEventDisableSystemFence is rejected)
+  hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming | (system_scope ? 0u : hipEventDisableSystemFence));
+  if (err != hipSuccess && !system_scope) { (void)hipGetLastError(); err = hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice); }
+  if (err != hipSuccess) { (void)hipGetLastError(); simt_set_error(__FILE__, __LINE__, "hipEventCreateWithFlags"); return SIMT_ERR_LAUNCH; }
+  *ev = (void*)e;
+  return SIMT_OK;
+}
+extern "C" int simt_event_destroy(void* ev) { return (ev && hipEventDestroy((hipEvent_t)ev) == hipSuccess) ? SIMT_OK : SIMT_ERR_INVALID; }
+extern "C" int simt_event_record(void* ev, simt_stream_t stream) {
+  SIMT_CHECK(ev);
+  if (hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) != hipSuccess) { simt_set_error(__FILE__, __LINE__, "hipEventRecord"); return SIMT_ERR_LAUNCH; }
+  return SIMT_OK;
+}
+extern "C" int simt_stream_wait_event(simt_stream_t stream, void* ev) {
+  SIMT_CHECK(ev);
+  if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0) != hipSuccess) { simt_set_error(__FILE__, __LINE__, "hipStreamWaitEvent"); return SIMT_ERR_LAUNCH; }
+  return SIMT_OK;
+}

@@ -230,6 +230,9 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
 bool simt_conv2_abl_launch(const Conv2KArgs& k, int bn, int tm, int nst, hipStream_t st, int* rc);
 int simt_conv2_abl_wants_frag(const simt_conv_desc* d);
 #endif
+#ifdef SIMT_ABLATION
+bool simt_conv2_roles_launch(const Conv2KArgs& k, int tm, int epi, size_t lds, hipStream_t st, int* rc);      // round-5 experiment, ablation builds only
+#endif
 template <int BN, int TM, int NST = 3, int FBN = 0, int EPI = 0>
 static int launch_conv2e(const Conv2KArgs& k, hipStream_t st) {
   constexpr int WM = (BN == 64) ? 4 : 2;
@@ -237,6 +240,12 @@ static int launch_conv2e(const Conv2KArgs& k, hipStream_t st) {
   const size_t ring = NST * (size_t)(BM * 128 + BN * 128);
   const size_t epi = (size_t)BM * (BN * 2 + 8) + (size_t)(512 / (BN / 8)) * 2 * BN * 4 + (FBN ? 32 * 8 * 3 * sizeof(double) + 16 + 2 * BN * sizeof(float) : 0);
   const size_t lds = ring > epi ? ring : epi;
+#ifdef SIMT_ABLATION
+  if constexpr (NST == 3 && BN == 256 && FBN == 0 && (EPI == 1 || EPI == 2 || EPI == 3 || EPI == 5)) {
+    int rc;
+    if (simt_conv2_roles_launch(k, TM, EPI, lds, st, &rc)) return rc;      // csrc/experiments/conv_igemm2_roles.hip (SIMT_CONV2_ROLES=1 | 2)
+  }
+#endif
   static SimtLdsAttrCache attr_cache;
   if (simt_lds_attr_needed(&attr_cache, lds))
     (void)hipFuncSetAttribute((const void*)conv_igemm2_kernel<BN, TM, NST, FBN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

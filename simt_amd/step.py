@@ -255,7 +255,12 @@ class SimTTrainer:
         #    second, its first conv reached the GPU 3.6 ms into the step (rocprofv3 kernel trace) -- and the frozen forward is one
         #    hipGraph launch when SIMT_FIXED_GRAPH != 0.
         order = self._fwd_order
-        if self._fixed_graph or order != "interleave":
+        if order in ("bnside", "bnside2") and not self._fixed_graph:
+            if self._fwd_both is None:
+                self._fwd_both = self._bn_side_forwards()
+            with trace.range("forward + frozen-forward (convs on the main stream, BatchNorm passes on the side stream)"):
+                self._fwd_both.run()
+        elif self._fixed_graph or order != "interleave":
             main = torch.cuda.current_stream()
             side = side_stream(self.dev)
             ev_in = torch.cuda.Event()
@@ -342,6 +347,74 @@ class SimTTrainer:
             pa, pb = ia[k], ib[k]
         ev_fix = both.record(1)
         both.wait(ev_fix, 0)
+        return both
+
+    def _bn_side_forwards(self):
+        """Both forwards as ONE launch list (round 5, SIMT_FWD_ORDER=bnside): EVERY conv -- the trainable net's and the frozen net's, alternating
+        layer by layer -- on the main stream, and only the trainable net's BatchNorm launches (finalize, apply, the stem's BN + max-pool) on
+        the side stream, released by an event behind the conv that feeds them and awaited by the trainable net's next conv.  While the
+        statistics are finalised and the HBM-bound apply pass streams (53 VGPRs, no LDS: it shares a CU with a conv workgroup), the main
+        queue runs the FROZEN net's conv of the same layer, which depends on nothing of it.  The two queues never hold two convs at once
+        (each conv workgroup takes a whole CU's LDS, so two conv queues only take turns: profiles/r02_step_timeline.txt), which is what the
+        alternating-convs experiments of round 4 (SIMT_FWD_ORDER=interleave) paid for; this is the backward's pattern (weight gradients
+        released by events) applied to the forward."""
+        from .engine import _Launch
+        lib = L.load()
+        both = LaunchList()
+        conv_fns = (lib.simt_conv_fprop,)
+        t_items = list(self._fwd_rest.items)
+        f_items = list(self.fixed.fwd_list.items)
+        f_items.append(_Launch(lib.simt_softmax_rows, (ops._p(self.fixed.out["x2"]), self.ldf, ops._p(self.fixp), self.ldf, self.B * self.h * self.w,
+                                                       self.C), (self.fixed.out["x2"], self.fixp), "simt_softmax_rows"))
+        assert all(it.fn is not None and it.stream == 0 for it in t_items + f_items)
+        fi = 0
+
+        def frozen_upto_next_conv():
+            """the frozen net's next conv and whatever non-conv launches follow it (main stream)"""
+            nonlocal fi
+            if fi >= len(f_items):
+                return
+            both.items.append(f_items[fi])
+            fi += 1
+            while fi < len(f_items) and f_items[fi].fn not in conv_fns:
+                both.items.append(f_items[fi])
+                fi += 1
+        # the frozen net may start with non-conv launches (none today): flush them
+        while fi < len(f_items) and f_items[fi].fn not in conv_fns:
+            both.items.append(f_items[fi])
+            fi += 1
+        ev_bn = None
+        i = 0
+        while i < len(t_items):
+            it = t_items[i]
+            if it.fn in conv_fns:
+                if ev_bn is not None:
+                    both.wait(ev_bn, 0)
+                    ev_bn = None
+                both.items.append(it)
+                j = i + 1
+                while j < len(t_items) and t_items[j].fn not in conv_fns:
+                    j += 1
+                group = t_items[i + 1:j]
+                # "bnside2": the (tiny, LDS-using) finalize stays on the main stream right behind its conv; only the streaming pass moves
+                if self._fwd_order == "bnside2":
+                    while group and group[0].fn is lib.simt_bn_finalize:
+                        both.items.append(group.pop(0))
+                if group:
+                    ev_conv = both.record(0)
+                    both.wait(ev_conv, 1)
+                    for g in group:
+                        both.items.append(_Launch(g.fn, g.args, g.keep, g.tag, g.flops, g.bytes, g.shape, stream=1))
+                    ev_bn = both.record(1)
+                frozen_upto_next_conv()
+                i = j
+            else:                                   # (a non-conv launch before the first conv: main stream)
+                both.items.append(it)
+                i += 1
+        while fi < len(f_items):
+            frozen_upto_next_conv()
+        if ev_bn is not None:
+            both.wait(ev_bn, 0)
         return both
 
     def _capture_graphs(self):
