@@ -110,6 +110,13 @@ typedef struct simt_fbn_desc {
                                            * non-zero by a launch whose polling timed out); NULL: work[SIMT_FBN_ERR_WORD] */
 } simt_fbn_desc;
 int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);
+/* Two INDEPENDENT convs of identical geometry in one launch (round 5): the trainable and the frozen ResNetMulti run the same 104 conv shapes on
+ * the same image (tools/trainV2_simt.py:351-353 and :370 -> model/deeplab_multi.py:172-192); their layer-k convs differ only in weights, output
+ * and epilogue (BatchNorm statistics | folded bias + ReLU [+ residual]).  d0 / d1: same B, H, W, Cin, Cout, taps, stride, Npad, output dtype.
+ * Results are bit-identical to simt_conv_fprop(d0) followed by simt_conv_fprop(d1); pairs the fused kernels do not cover (different tile
+ * variant, other epilogue combinations, d->fbn set) ARE run as those two launches.  simt_conv_pair_fused says which it will be. */
+int simt_conv_fprop_pair(const simt_conv_desc* d0, const simt_conv_desc* d1, simt_stream_t stream);
+int simt_conv_pair_fused(const simt_conv_desc* d0, const simt_conv_desc* d1);
 /* 1 if simt_conv_fprop can run d with a fused BatchNorm (d->fbn): bf16 v2 kernel with the 3-slot ring -- 256-column tiles in both directions,
  * 128- / 64-column tiles (the small maps of model/deeplabv3.py) in the backward direction (d->bnr_mode 2) -- and a grid that is co-resident on
  * the current device (tiles <= compute units); d->fbn itself need not be set yet */

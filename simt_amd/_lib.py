@@ -103,6 +103,8 @@ SIGNATURES = {
     "simt_abi_version": (_I, []),
     "simt_conv_fprop": (_I, [C.POINTER(ConvDesc), c_p]),
     "simt_conv_mtiles": (_I, [C.POINTER(ConvDesc)]),
+    "simt_conv_fprop_pair": (_I, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), c_p]),
+    "simt_conv_pair_fused": (_I, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     "simt_conv_fbn_ok": (_I, [C.POINTER(ConvDesc)]),
     "simt_conv_epilogue_flavour": (_I, [C.POINTER(ConvDesc)]),
     "simt_conv_fbn_words": (_L, [C.POINTER(ConvDesc)]),

@@ -85,7 +85,7 @@ struct Aux { uint4 res, by; unsigned rbits, ybits; };
 enum { FL_GEN = 0, FL_GEN_AUX = 1, FL_STATS = 2, FL_BRR = 3, FL_BNR = 4 };
 
 template <int KS, int TM, int D, int FL, int NSW, int NCW, int TN>
-__global__ __launch_bounds__((NCW + NSW) * 64, (KS == 32 ? 2 : 3)) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
+__device__ __forceinline__ void conv1x1_rows_body(const Conv2KArgs& a, const int G, const int bid) {
   using g = Geo<KS, TM, D, NSW, NCW, TN>;
   constexpr int WCOLS = TN * 16;                               // output channels per compute wave
   constexpr int RGS = g::RGS, NS = g::NS, NC = g::NC, BN = g::BN, CP = g::CP, VPR = g::VPR;
@@ -129,8 +129,8 @@ __global__ __launch_bounds__((NCW + NSW) * 64, (KS == 32 ? 2 : 3)) void conv1x1_
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwg = a.ntiles_m * a.ntiles_n;
-  const int my_n = (nwg - (int)blockIdx.x + G - 1) / G;        // 128-row tiles of this workgroup: blockIdx.x + i * G
-  const int tile0 = xcd_remap(blockIdx.x, nwg);
+  const int my_n = (nwg - bid + G - 1) / G;                    // 128-row tiles of this workgroup: bid + i * G
+  const int tile0 = xcd_remap(bid, nwg);
   const int tstep = G >> 3;                                    // xcd_remap(b + i * G) = tile0 + i * G / 8
   const int nt = tile0 % a.ntiles_n;                           // fixed per workgroup (host: ntiles_n divides G / 8)
   const int n0 = nt * BN;
@@ -653,6 +653,36 @@ __global__ __launch_bounds__((NCW + NSW) * 64, (KS == 32 ? 2 : 3)) void conv1x1_
 #endif
 }
 
+template <int KS, int TM, int D, int FL, int NSW, int NCW, int TN>
+__global__ __launch_bounds__((NCW + NSW) * 64, (KS == 32 ? 2 : 3)) void conv1x1_rows_kernel(Conv2KArgs a, int G) {
+  conv1x1_rows_body<KS, TM, D, FL, NSW, NCW, TN>(a, G, (int)blockIdx.x);
+}
+
+// Two problems of identical geometry in one launch (simt_conv_fprop_pair; conv_igemm2_pair_kernel has the why): persistent workgroups
+// [0, G) stream problem 0 with flavour FL0, [G, 2 G) problem 1 with flavour FL1.  One workgroup per CU: the second G start as the first finish.
+template <int KS, int TM, int D, int FL0, int FL1, int NSW, int NCW, int TN>
+__global__ __launch_bounds__((NCW + NSW) * 64, (KS == 32 ? 2 : 3)) void conv1x1_rows_pair_kernel(Conv2KArgs a0, Conv2KArgs a1, int G) {
+  if ((int)blockIdx.x < G) conv1x1_rows_body<KS, TM, D, FL0, NSW, NCW, TN>(a0, G, (int)blockIdx.x);
+  else conv1x1_rows_body<KS, TM, D, FL1, NSW, NCW, TN>(a1, G, (int)blockIdx.x - G);
+}
+
+template <int KS, int TM, int D, int FL0, int FL1, int NSW, int NCW, int TN = 2>
+int launch_rows_pair(Conv2KArgs k0, Conv2KArgs k1, int npad, hipStream_t st) {
+  using g = Geo<KS, TM, D, NSW, NCW, TN>;
+  k0.rows = k1.rows = 128;
+  k0.ntiles_n = k1.ntiles_n = npad / g::BN;
+  k0.ntiles_m = k1.ntiles_m = (k0.M + 127) / 128;
+  const int nwg = k0.ntiles_m * k0.ntiles_n;
+  const int cap = (NCW == 8 || g::LDS > 80 * 1024) ? 256 : 512;
+  const int G = nwg < cap ? nwg : cap;
+  static SimtLdsAttrCache attr_cache;
+  if (simt_lds_attr_needed(&attr_cache, g::LDS))
+    (void)hipFuncSetAttribute((const void*)conv1x1_rows_pair_kernel<KS, TM, D, FL0, FL1, NSW, NCW, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, g::LDS);
+  hipLaunchKernelGGL((conv1x1_rows_pair_kernel<KS, TM, D, FL0, FL1, NSW, NCW, TN>), dim3(2 * G), dim3(g::NT), g::LDS, st, k0, k1, G);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
 template <int KS, int TM, int D, int FL, int NSW, int NCW, int TN = 2>
 int launch_rows(Conv2KArgs k, int npad, hipStream_t st) {
   using g = Geo<KS, TM, D, NSW, NCW, TN>;
@@ -731,4 +761,16 @@ int simt_conv_rows_launch(Conv2KArgs k, int npad, hipStream_t st) {
   if (f_brr) return launch_rows<2, 2, 6, FL_BRR, 2, 4>(k, npad, st);
   if (f_bnr) return launch_rows<2, 2, 6, FL_BNR, 2, 4>(k, npad, st);
   return aux ? launch_rows<2, 2, 6, FL_GEN_AUX, 2, 4>(k, npad, st) : launch_rows<2, 4, 6, FL_GEN, 4, 8>(k, npad, st);
+}
+
+// (trainable conv3 with BatchNorm statistics, frozen conv3 with bias + residual + ReLU) of one layer in one launch: the geometries both
+// flavours share (Cin 256: layer 3, Cin 512: layer 4)
+int simt_conv_rows_pair_launch(Conv2KArgs k0, Conv2KArgs k1, int npad, hipStream_t st, bool* taken) {
+  const int cin = k0.pix_bytes / 2;
+  constexpr int CW = SIMT_ROWS_NCW, SW = CW / 2, D256 = CW == 8 ? 6 : 3;
+  *taken = true;
+  if (cin == 256) return launch_rows_pair<8, 2, D256, FL_STATS, FL_BRR, SW, CW>(k0, k1, npad, st);
+  if (cin == 512) return launch_rows_pair<16, 2, 3, FL_STATS, FL_BRR, 2, 8, 1>(k0, k1, npad, st);
+  *taken = false;
+  return SIMT_ERR_INVALID;
 }

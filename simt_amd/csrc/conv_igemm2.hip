@@ -41,8 +41,8 @@ extern "C" int simt_debug_stamps(unsigned long long* out, int n) {
 // FBN = 1: the same kernel with the fused train-mode BatchNorm tail compiled in (conv2_epilogue.h; a.fbn_mode selects forward / backward).
 // A separate instantiation so that the plain kernels keep their code (the main loop is sensitive to what surrounds it).
 // EPI: compile-time epilogue flavour (conv2_epilogue.h): 0 generic, 1 statistics, 2 BatchNorm-backward reduce, 3 bias + ReLU, 4-8 the dgrad forms.
-template <int BN, int TMP, int NSTP, int FBN = 0, int EPI = 0>
-__global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(Conv2KArgs a) {
+template <int BN, int TMP, int NSTP, int FBN, int EPI>
+__device__ __forceinline__ void conv_igemm2_body(const Conv2KArgs& a, const int bid) {
   constexpr int NT = 512, NST = NSTP;   // NST = 3: one workgroup per CU, two stages in flight; NST = 2 (short-K, output-
                                         // bound shapes): two workgroups per CU so one's epilogue overlaps the other's loads
   constexpr int WM = (BN == 64) ? 4 : 2;          // waves along pixels
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
 
   STAMP(0);
   const int nwg = a.ntiles_m * a.ntiles_n;
-  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int tile = xcd_remap(bid, nwg);
   const int mt = tile / a.ntiles_n, nt = tile - mt * a.ntiles_n;
   const int m0 = mt * a.rows, n0 = nt * BN;
   const int m_end = min(a.M, m0 + a.rows);
@@ -224,6 +224,24 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
   conv2_epilogue<BN, BM, NT, TN, TM, FBN, EPI>(a, smem, acc, true, wm, wn, tid, lane, m0, n0, m_end, mt, tile);
 }
 
+template <int BN, int TMP, int NSTP, int FBN = 0, int EPI = 0>
+__global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(Conv2KArgs a) {
+  conv_igemm2_body<BN, TMP, NSTP, FBN, EPI>(a, (int)blockIdx.x);
+}
+
+// Round 5: TWO independent convs of identical geometry in ONE launch -- the trainable net's and the frozen net's conv of the
+// same layer see the same shapes (tools/trainV2_simt.py:351-353 and :370 call the same ResNetMulti.forward, model/deeplab_multi.py:172-192).
+// Workgroups [0, nwg) run problem 0, [nwg, 2 nwg) problem 1, each with its own compile-time epilogue flavour (the branch is workgroup-uniform
+// and sits in front of everything: nothing inside the K loop knows about it).  Measured on the production shapes (one launch of twice the
+// workgroups against two launches): 11 us per pair on the 3x3 256 -> 256, 2.5 us on 1x1 1024 -> 256 (profiles/r05_pair_launch.txt): the second
+// round of workgroups starts as the first drains, one launch ramp / drain / boundary instead of two.
+template <int BN, int TMP, int NSTP, int EPI0, int EPI1>
+__global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_pair_kernel(Conv2KArgs a0, Conv2KArgs a1) {
+  const int nwg0 = a0.ntiles_m * a0.ntiles_n;
+  if ((int)blockIdx.x < nwg0) conv_igemm2_body<BN, TMP, NSTP, 0, EPI0>(a0, (int)blockIdx.x);
+  else conv_igemm2_body<BN, TMP, NSTP, 0, EPI1>(a1, (int)blockIdx.x - nwg0);
+}
+
 #ifdef SIMT_ABLATION
 // csrc/experiments/conv_igemm2_abl.hip: returns true when an experiment build (SIMT_CONV2_MODE / SIMT_CONV2_LW / SIMT_WDIRECT / SIMT_IGEMM3)
 // took the launch; *rc is its result
@@ -311,6 +329,7 @@ static void pick_rows(int M, int ntn, bool allow160, int* rows, int* tm) {
   }
 }
 
+extern "C" int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);      // conv_igemm.hip
 bool simt_conv_stream_eligible(const simt_conv_desc* d);                  // conv1x1_stream.hip
 int simt_conv_stream_launch(Conv2KArgs k, int npad, hipStream_t st);
 bool simt_conv_rows_eligible(const simt_conv_desc* d);                    // conv1x1_rows.hip
@@ -433,9 +452,8 @@ extern "C" int simt_conv_mtiles(const simt_conv_desc* d) {
   return (M + v.rows - 1) / v.rows;
 }
 
-// Called by simt_conv_fprop (conv_igemm.hip) for bf16 -> bf16 problems with tile_n in {64, 128, 256}.
-int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
-  Conv2KArgs k;
+// Kernel arguments of the bf16 v2 family for d (every generation: conv_igemm2 / rows / stream); *vout = the variant the launch takes.
+static int conv2_fill_args(const simt_conv_desc* d, Conv2KArgs& k, Conv2Variant* vout) {
   k.wf = (d->w_frag && simt_conv_wants_frag(d)) ? (const char*)d->w_frag : nullptr; k.nt16 = d->Npad / 16;
   k.x = (const char*)d->x; k.w = (const char*)d->w; k.y = (bf16_t*)d->y; k.bias = d->bias; k.res = (const bf16_t*)d->res;
   k.stats = d->stats; k.zero = (const char*)simt_zero_page();
@@ -484,6 +502,19 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
     k.dx[i] = d->dx[i];
     k.toff[i] = (d->dy[i] * d->W + d->dx[i]) * k.pix_bytes;
   }
+  *vout = v;
+  (void)tile_n; (void)tm; (void)short_k;
+  return SIMT_OK;
+}
+
+// Called by simt_conv_fprop (conv_igemm.hip) for bf16 -> bf16 problems with tile_n in {64, 128, 256}.
+int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
+  Conv2KArgs k;
+  Conv2Variant v;
+  const int rc = conv2_fill_args(d, k, &v);
+  if (rc != SIMT_OK) return rc;
+  const int tile_n = v.tile_n, tm = v.tm;
+  const bool short_k = v.nst == 2;
   hipStream_t st = (hipStream_t)stream;
   if (v.rowsk) return simt_conv_rows_launch(k, d->Npad, st);
   if (v.stream) return simt_conv_stream_launch(k, d->Npad, st);
@@ -491,4 +522,91 @@ int simt_conv_fprop_bf16_v2(const simt_conv_desc* d, simt_stream_t stream) {
   if (tile_n == 256) return tm == 5 ? launch_conv2<256, 5>(k, st) : launch_conv2<256, 4>(k, st);
   if (tile_n == 128) return tm == 5 ? launch_conv2<128, 5>(k, st) : launch_conv2<128, 4>(k, st);
   return launch_conv2<64, 2>(k, st);
+}
+
+// ---- two convs of identical geometry in one launch (simt_conv_fprop_pair) ----------------------------------------------------------------
+int simt_conv_rows_pair_launch(Conv2KArgs k0, Conv2KArgs k1, int npad, hipStream_t st, bool* taken);      // conv1x1_rows.hip
+template <int BN, int TM, int E0, int E1>
+static int launch_pair(const Conv2KArgs& k0, const Conv2KArgs& k1, hipStream_t st) {
+  constexpr int WM = (BN == 64) ? 4 : 2;
+  constexpr int BM = WM * TM * 16;
+  const size_t ring = 3 * (size_t)(BM * 128 + BN * 128);
+  const size_t epi = (size_t)BM * (BN * 2 + 8) + (size_t)(512 / (BN / 8)) * 2 * BN * 4;
+  const size_t lds = ring > epi ? ring : epi;
+  static SimtLdsAttrCache attr_cache;
+  if (simt_lds_attr_needed(&attr_cache, lds))
+    (void)hipFuncSetAttribute((const void*)conv_igemm2_pair_kernel<BN, TM, 3, E0, E1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((conv_igemm2_pair_kernel<BN, TM, 3, E0, E1>), dim3(2 * k0.ntiles_m * k0.ntiles_n), dim3(512), lds, st, k0, k1);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+// the flavour pairs of the two forwards: (trainable, frozen) = (statistics, bias + ReLU) for conv1 / conv2 / the stem, (statistics, generic) for
+// the downsample convs (bias without ReLU), (generic, generic) for the fp32 tap-expanded heads
+template <int BN, int TM>
+static bool launch_pair_flavours(const Conv2KArgs& k0, const Conv2KArgs& k1, hipStream_t st, int* rc) {
+  const int e0 = conv2_flavour(k0), e1 = conv2_flavour(k1);
+  if (e0 == 1 && e1 == 3) { *rc = launch_pair<BN, TM, 1, 3>(k0, k1, st); return true; }
+  if (e0 == 1 && e1 == 0) { *rc = launch_pair<BN, TM, 1, 0>(k0, k1, st); return true; }
+  if (e0 == 0 && e1 == 0) { *rc = launch_pair<BN, TM, 0, 0>(k0, k1, st); return true; }
+  return false;
+}
+
+static int pair_enabled() {
+  static const int off = getenv("SIMT_NO_PAIR") ? atoi(getenv("SIMT_NO_PAIR")) : 0;      // A/B switch: two launches
+  return !off;
+}
+
+// 1 if simt_conv_fprop_pair(d0, d1) is ONE launch (same geometry and tile variant, a supported pair of epilogue flavours), 0 if it runs the two
+// convs one after the other (always correct)
+extern "C" int simt_conv_pair_fused(const simt_conv_desc* d0, const simt_conv_desc* d1) {
+  if (!d0 || !d1 || !pair_enabled() || d0->fbn || d1->fbn) return 0;
+  int b0, t0, n0, b1, t1, n1;
+  const int g0 = simt_conv_variant(d0, &b0, &t0, &n0), g1 = simt_conv_variant(d1, &b1, &t1, &n1);
+  if (g0 != g1 || b0 != b1 || t0 != t1 || n0 != n1 || (g0 != 2 && g0 != 5)) return 0;
+  if (d0->B != d1->B || d0->H != d1->H || d0->W != d1->W || d0->Cin != d1->Cin || d0->Ho != d1->Ho || d0->Wo != d1->Wo || d0->stride != d1->stride ||
+      d0->ntaps != d1->ntaps || d0->Npad != d1->Npad || d0->Cout != d1->Cout || d0->Nstore != d1->Nstore || d0->dtype_out != d1->dtype_out) return 0;
+  for (int i = 0; i < d0->ntaps; ++i) if (d0->dy[i] != d1->dy[i] || d0->dx[i] != d1->dx[i]) return 0;
+  Conv2KArgs k0, k1;
+  k0.out_f32 = d0->dtype_out == SIMT_F32; k0.res = (const bf16_t*)d0->res; k0.mask = (const bf16_t*)d0->mask; k0.Nstore = d0->Nstore; k0.Cout = d0->Cout;
+  k0.stats = d0->stats; k0.bias = d0->bias; k0.relu = d0->relu; k0.bnr_mode = d0->bnr_mode; k0.res_bits = d0->res_bits;
+  k1.out_f32 = d1->dtype_out == SIMT_F32; k1.res = (const bf16_t*)d1->res; k1.mask = (const bf16_t*)d1->mask; k1.Nstore = d1->Nstore; k1.Cout = d1->Cout;
+  k1.stats = d1->stats; k1.bias = d1->bias; k1.relu = d1->relu; k1.bnr_mode = d1->bnr_mode; k1.res_bits = d1->res_bits;
+  if (g0 == 2) {
+    if (n0 != 3) return 0;
+    const int e0 = conv2_flavour(k0), e1 = conv2_flavour(k1);
+    return (e0 == 1 && e1 == 3) || (e0 == 1 && e1 == 0) || (e0 == 0 && e1 == 0);
+  }
+  // rows kernel: (statistics, bias + residual + ReLU) on the geometries both flavours share (Cin 256 / 512)
+  const bool f_stats = d0->stats && !d0->bias && !d0->relu && !d0->res && !d0->bnr_mode && d0->Cout % 4 == 0;
+  const bool f_brr = d1->bias && d1->relu && d1->res && !d1->res_bits && !d1->bnr_mode && !d1->stats;
+  return f_stats && f_brr && (d0->Cin == 256 || d0->Cin == 512);
+}
+
+extern "C" int simt_conv_fprop_pair(const simt_conv_desc* d0, const simt_conv_desc* d1, simt_stream_t stream) {
+  SIMT_CHECK(d0 && d1);
+  if (!simt_conv_pair_fused(d0, d1)) {
+    const int rc = simt_conv_fprop(d0, stream);
+    return rc != SIMT_OK ? rc : simt_conv_fprop(d1, stream);
+  }
+  Conv2KArgs k0, k1;
+  Conv2Variant v0, v1;
+  int rc = conv2_fill_args(d0, k0, &v0);
+  if (rc != SIMT_OK) return rc;
+  rc = conv2_fill_args(d1, k1, &v1);
+  if (rc != SIMT_OK) return rc;
+  SIMT_CHECK(v0.tile_n == v1.tile_n && v0.tm == v1.tm && v0.nst == v1.nst && v0.rows == v1.rows && v0.ntiles_n == v1.ntiles_n && v0.rowsk == v1.rowsk && !v0.stream);
+  SIMT_CHECK(k0.ntiles_m == k1.ntiles_m);
+  hipStream_t st = (hipStream_t)stream;
+  if (v0.rowsk) {
+    bool taken = false;
+    rc = simt_conv_rows_pair_launch(k0, k1, d0->Npad, st, &taken);
+    SIMT_CHECK(taken);
+    return rc;
+  }
+  bool ok = false;
+  if (v0.tile_n == 256) ok = v0.tm == 5 ? launch_pair_flavours<256, 5>(k0, k1, st, &rc) : launch_pair_flavours<256, 4>(k0, k1, st, &rc);
+  else if (v0.tile_n == 128) ok = v0.tm == 5 ? launch_pair_flavours<128, 5>(k0, k1, st, &rc) : launch_pair_flavours<128, 4>(k0, k1, st, &rc);
+  else ok = launch_pair_flavours<64, 2>(k0, k1, st, &rc);
+  SIMT_CHECK(ok);
+  return rc;
 }

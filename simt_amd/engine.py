@@ -576,7 +576,7 @@ class TrunkPlan:
             Mi, Mo = B * Hc * Wc, B * Ho * Wo
             c4 = planes * 4
             rec = {"name": name, "x": x, "Hi": Hc, "Wi": Wc, "Ho": Ho, "Wo": Wo, "inpl": inpl, "planes": planes,
-                   "stride": stride, "dil": dil, "down": down, "Mi": Mi, "Mo": Mo}
+                   "stride": stride, "dil": dil, "down": down, "Mi": Mi, "Mo": Mo, "fwd_start": len(f.items)}
             t3 = ops.conv_taps(3, 3, dil, dil)
             if self.train:
                 y1, a1 = self.new(Mo, planes), self.new(Mo, planes)

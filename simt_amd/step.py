@@ -96,8 +96,10 @@ class SimTTrainer:
         self._main_hi = os.environ.get("SIMT_MAIN_PRIORITY", "0") == "1"
         # host enqueue order of the two forwards (both reach the GPU within ~2 ms; the hardware then favours the queue that was fed
         # first): "main" = trainable first (default), "side" = frozen first, "interleave" = one list alternating 1:1
-        self._fwd_order = os.environ.get("SIMT_FWD_ORDER", "main")
+        self._fwd_order = os.environ.get("SIMT_FWD_ORDER", "main")      # "pair" (round 5): one launch per layer for both networks, main stream only (measured +1.3 ms: it gives up the two-stream overlap)
         self._hi_stream = None
+        fa = os.environ.get("SIMT_FROZEN_AFTER")
+        self._frozen_after = next((r["fwd_start"] for r in self.plan.block_io if r["name"] == fa), None) if fa else None
         self._fwd_rest = LaunchList()
         self._fwd_rest.items = self.plan.fwd_list.items[1:]
         self._fwd_both = None                      # built on first use (needs self.fixp): both forwards interleaved, see _micro_batch
@@ -255,7 +257,12 @@ class SimTTrainer:
         #    second, its first conv reached the GPU 3.6 ms into the step (rocprofv3 kernel trace) -- and the frozen forward is one
         #    hipGraph launch when SIMT_FIXED_GRAPH != 0.
         order = self._fwd_order
-        if order in ("bnside", "bnside2") and not self._fixed_graph:
+        if order == "pair" and not self._fixed_graph:
+            if self._fwd_both is None:
+                self._fwd_both = self._paired_forwards()
+            with trace.range("forward + frozen-forward (one launch per layer for both networks)"):
+                self._fwd_both.run()
+        elif order in ("bnside", "bnside2") and not self._fixed_graph:
             if self._fwd_both is None:
                 self._fwd_both = self._bn_side_forwards()
             with trace.range("forward + frozen-forward (convs on the main stream, BatchNorm passes on the side stream)"):
@@ -278,6 +285,16 @@ class SimTTrainer:
                 ev_fix = frozen()
                 with trace.range("forward"):
                     self._fwd_rest.run()           # 3. trainable forward (its im2col already ran above)
+            elif self._frozen_after is not None:
+                # experiment (SIMT_FROZEN_AFTER=<block name>): the frozen forward is released when the trainable forward reaches that block
+                cut = self._frozen_after - 1       # (_fwd_rest starts behind the im2col)
+                a_, b_ = LaunchList(), LaunchList()
+                a_.items, b_.items = self._fwd_rest.items[:cut], self._fwd_rest.items[cut:]
+                with trace.range("forward"):
+                    a_.run()
+                    ev_in.record(main)
+                    ev_fix = frozen()
+                    b_.run()
             else:
                 with trace.range("forward"):
                     self._fwd_rest.run()
@@ -347,6 +364,74 @@ class SimTTrainer:
             pa, pb = ia[k], ib[k]
         ev_fix = both.record(1)
         both.wait(ev_fix, 0)
+        return both
+
+    def _paired_forwards(self):
+        """Both forwards as ONE launch list on the main stream with ONE launch per layer for both networks (round 5; the
+        default, SIMT_FWD_ORDER=pair): the trainable and the frozen ResNetMulti run the same conv shapes on the same image
+        (tools/trainV2_simt.py:351-353 and :370 -> model/deeplab_multi.py:172-192), so conv k of one and conv k of the other go into one
+        simt_conv_fprop_pair launch (510 workgroups: the second 255 start as the first drain), each half with its own compile-time epilogue
+        (BatchNorm statistics | folded bias + ReLU [+ residual]).  The two lists are aligned by a longest-common-subsequence match on the
+        conv geometries (their orders differ around the downsample convs: conv3 needs the frozen net's downsample output as its residual),
+        each list's own order is kept, everything that has no partner is launched as before.  The two-stream schedule this replaces ran the
+        forwards one after the other anyway (the GPU serves one conv queue at a time: profiles/r02_step_timeline.txt); what the pairing removes
+        is one launch ramp / drain per layer: 11 us per 3x3 pair, 12 us per conv3 pair, 2.5 us per 1x1 1024 -> 256 pair
+        (profiles/r05_pair_launch.txt).  Outputs are bit-identical to the separate launches (tests/test_gpu_iteration.py)."""
+        from .engine import _Launch
+        lib = L.load()
+        conv_fn = lib.simt_conv_fprop
+        t_items = list(self._fwd_rest.items)
+        f_items = list(self.fixed.fwd_list.items)
+        f_items.append(_Launch(lib.simt_softmax_rows, (ops._p(self.fixed.out["x2"]), self.ldf, ops._p(self.fixp), self.ldf, self.B * self.h * self.w,
+                                                       self.C), (self.fixed.out["x2"], self.fixp), "simt_softmax_rows"))
+        assert all(it.fn is not None and it.stream == 0 for it in t_items + f_items)
+
+        def segments(items):
+            """[(conv item or None, [the launches that follow it up to the next conv])]; the first segment's conv is None (leading launches)"""
+            segs = [(None, [])]
+            for it in items:
+                if it.fn is conv_fn:
+                    segs.append((it, []))
+                else:
+                    segs[-1][1].append(it)
+            return segs
+        ts, fs = segments(t_items), segments(f_items)
+        tc, fc = ts[1:], fs[1:]
+        fused = [[bool(lib.simt_conv_pair_fused(C.byref(a[0].keep), C.byref(b[0].keep))) for b in fc] for a in tc]
+        # longest common subsequence over the fusable pairs (104 x 104)
+        n, m = len(tc), len(fc)
+        dp = [[0] * (m + 1) for _ in range(n + 1)]
+        for i in range(n - 1, -1, -1):
+            for j in range(m - 1, -1, -1):
+                dp[i][j] = max(dp[i + 1][j], dp[i][j + 1], (1 + dp[i + 1][j + 1]) if fused[i][j] else 0)
+        both = LaunchList()
+        both.items += ts[0][1] + fs[0][1]
+        i = j = 0
+        self.fwd_pairs = 0
+
+        def single(seg):
+            both.items.append(seg[0])
+            both.items.extend(seg[1])
+        while i < n or j < m:
+            if i < n and j < m and fused[i][j] and dp[i][j] == 1 + dp[i + 1][j + 1]:
+                a, b = tc[i][0], fc[j][0]
+                if a.tag.startswith("conv_igemm2_kernel<") and b.tag.startswith("conv_igemm2_kernel<"):
+                    tag = ", ".join(a.tag.split(", ")[:4]) + f", {a.tag.split(', ')[4].rstrip('>')}+{b.tag.split(', ')[4].rstrip('>')}>"
+                else:
+                    tag = a.tag + " (pair)"
+                both.items.append(_Launch(lib.simt_conv_fprop_pair, (C.byref(a.keep), C.byref(b.keep)), (a.keep, b.keep), tag,
+                                          a.flops + b.flops, a.bytes + b.bytes, a.shape + " x2 (trainable + frozen)"))
+                both.items.extend(tc[i][1])
+                both.items.extend(fc[j][1])
+                self.fwd_pairs += 1
+                i, j = i + 1, j + 1
+            elif j < m and (i >= n or dp[i][j] == dp[i][j + 1]):
+                single(fc[j])
+                j += 1
+            else:
+                single(tc[i])
+                i += 1
+        assert len(both.items) == len(t_items) + len(f_items) - self.fwd_pairs
         return both
 
     def _bn_side_forwards(self):
@@ -564,7 +649,14 @@ class SimTTrainer:
         return sd
 
     def timed_lists(self):
-        """The launch lists of one iteration (frozen forward, trainable forward, backward) for per-kernel timing (bench.py)."""
+        """The launch lists of one iteration for per-kernel timing (bench.py): the forwards as the step launches them (paired: the stem im2col +
+        one list for both networks; otherwise frozen forward, trainable forward), then the backward."""
+        if self._fwd_order == "pair" and not self._fixed_graph:
+            if self._fwd_both is None:
+                self._fwd_both = self._paired_forwards()
+            head = LaunchList()
+            head.items = [self.plan.fwd_list.items[0]]
+            return [head, self._fwd_both, self.plan.bwd_list]
         return [self.fixed.fwd_list, self.plan.fwd_list, self.plan.bwd_list]
 
     def losses(self):

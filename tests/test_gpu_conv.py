@@ -405,3 +405,73 @@ def test_wgrad_reduce_unaligned_destination(dev):
     plan = V3Plan(st, 1, 64, 64, 19, 6, True, dtype=torch.bfloat16, train=True, device=dev)
     assert all(t.data_ptr() % 16 == 0 for t in plan.grads.values())
     assert plan.grad_offsets[plan.grad_order[1]][0] % 4 == 0 and plan.p[plan.grad_order[0]].numel() % 4 != 0
+
+
+# Round 5: two convs of identical geometry in ONE launch (simt_conv_fprop_pair; the trainable and the frozen net's conv of one layer)
+PAIR_CASES = [
+    # id, B, H, W, Cin, Cout, k, dil, (epilogue 0, epilogue 1), fused?
+    ("3x3 d2 256 stats | bias+relu", 4, 97, 97, 256, 256, 3, 2, ("stats", "bias_relu"), True),
+    ("1x1 1024->256 stats | bias+relu", 4, 97, 97, 1024, 256, 1, 1, ("stats", "bias_relu"), True),
+    ("rows 256->1024 stats | bias+res+relu", 4, 97, 97, 256, 1024, 1, 1, ("stats", "bias_res_relu"), True),
+    ("rows 512->2048 stats | bias+res+relu", 2, 33, 35, 512, 2048, 1, 1, ("stats", "bias_res_relu"), True),
+    ("3x3 128 stats | bias+relu (128-column tile)", 2, 49, 49, 128, 128, 3, 1, ("stats", "bias_relu"), True),
+    ("3x3 64 stats | bias+relu (64-column tile)", 1, 97, 97, 64, 64, 3, 1, ("stats", "bias_relu"), True),
+    ("1x1 1024->2048 stats | bias (downsample)", 1, 33, 33, 1024, 2048, 1, 1, ("stats", "bias"), True),
+    ("ragged M: 3x3 256 stats | bias+relu", 1, 13, 17, 256, 256, 3, 2, ("stats", "bias_relu"), True),
+    ("rows 64->256 stats | bias+res+relu (different geometries: two launches)", 1, 33, 33, 64, 256, 1, 1, ("stats", "bias_res_relu"), False),
+    ("3x3 256 bias+relu | bias+relu (unsupported flavour pair: two launches)", 1, 33, 33, 256, 256, 3, 2, ("bias_relu", "bias_relu"), False),
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES, ids=[c[0] for c in PAIR_CASES])
+def test_pair_launch_is_bitwise_the_two_launches(dev, case):
+    import ctypes as C
+    from simt_amd import _lib as L
+    _id, B, H, W, Cin, Cout, k, dil, epis, want_fused = case
+    BF = torch.bfloat16
+    M = B * H * W
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    taps = ops.conv_taps(k, k, dil, dil * (k // 2))
+    tile = ops.pick_tile_n(Cout, BF)
+    npad = ops.round_up(Cout, tile)
+
+    def problem(epi, seed):
+        gg = torch.Generator().manual_seed(seed)
+        x = torch.randn(B, H, W, Cin, generator=gg).to(dev, BF)
+        wp = torch.zeros(npad, len(taps) * Cin, device=dev, dtype=BF)
+        wp[:Cout] = (torch.randn(Cout, len(taps) * Cin, generator=gg) * 0.03).to(dev, BF)
+        kw = {}
+        if epi == "stats":
+            kw["stats"] = torch.full(((M + 127) // 128, 2, Cout), float("nan"), device=dev)
+        if "bias" in epi:
+            kw["bias"] = torch.randn(Cout, generator=gg).to(dev)
+        if "res" in epi:
+            kw["res"] = torch.randn(M, Cout, generator=gg).to(dev, BF)
+        kw["relu"] = "relu" in epi
+        return x, wp, kw
+
+    probs = [problem(epis[0], 1), problem(epis[1], 2)]
+
+    def run(pair):
+        ys, descs = [], []
+        for x, wp, kw in probs:
+            y = torch.full((M, Cout), float("nan"), device=dev, dtype=BF)
+            if "stats" in kw:
+                kw["stats"].fill_(float("nan"))
+            ys.append(y)
+            descs.append(ops.make_conv_desc(x, wp, y, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=Cout, taps=taps, Npad=npad, tile_n=tile, **kw))
+        if pair:
+            assert bool(L.load().simt_conv_pair_fused(C.byref(descs[0]), C.byref(descs[1]))) == want_fused, _id
+            L.call("simt_conv_fprop_pair", C.byref(descs[0]), C.byref(descs[1]), ops.stream_ptr())
+        else:
+            for d in descs:
+                ops.conv_fprop_desc(d)
+        torch.cuda.synchronize()
+        return [y.clone() for y in ys], [kw["stats"].clone() if "stats" in kw else None for _x, _w, kw in probs]
+    ya, sa = run(False)
+    yb, sb = run(True)
+    for i in range(2):
+        assert torch.isfinite(yb[i].float()).all()
+        assert torch.equal(ya[i], yb[i]), f"{_id}: problem {i} differs between the pair launch and its own launch"
+        if sa[i] is not None:
+            assert torch.equal(sa[i], sb[i])

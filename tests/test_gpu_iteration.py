@@ -298,13 +298,18 @@ def test_early_sgd_and_schedule_switches_same_trajectory(dev, monkeypatch):
     fst = so.recipe_state(so.state_shapes(19, 0, False, layers=layers), seed=32, head_scale=8.0)
     runs = []
     for env in ({"SIMT_EARLY_SGD": "0", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "main"}, {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "side"},
-                {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "1", "SIMT_FWD_ORDER": "main"}, {"SIMT_EARLY_SGD": "0", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "interleave"}):
+                {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "1", "SIMT_FWD_ORDER": "main"}, {"SIMT_EARLY_SGD": "0", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "interleave"},
+                {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "pair"},       # round 5 default: one launch per layer for both networks
+                {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "bnside2"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         hp = Hyper(open_classes=K, lambda_convex=0.1, lambda_volume=1.0, lambda_anchor=1.0, lr=6e-4, lr_T=6e-3)
         tr = SimTTrainer(st, fst, so.ntm_init(19, K, 911), so.ntm_init(19, K, 912), hp, CD, B, H, W, dtype=torch.bfloat16, device=dev,
                          layers=layers)
         assert tr._early_sgd == (env["SIMT_EARLY_SGD"] == "1")
+        if env["SIMT_FWD_ORDER"] == "pair":
+            tr._fwd_both = tr._paired_forwards()
+            assert tr.fwd_pairs >= 10, f"only {tr.fwd_pairs} conv pairs fused"
         ls = []
         for it in range(3):
             img, lab = so.synthetic_batch(B, H, W, CD.numpy(), seed=900 + it, block=8)
