@@ -10,7 +10,7 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -Xclang -ta
 # waves, weights-direct, role-split conv_igemm3; outputs of the timing modes are meaningless; never shipped).  OUT=path BUILD=dir: where to.
 SRCS=(*.hip)
 BUILD=${BUILD:-../_build}
-if [ "${ABLATION:-0}" = "1" ]; then FLAGS="$FLAGS -DSIMT_ABLATION"; SRCS+=(experiments/*.hip); BUILD=${BUILD}_abl; OUT=${OUT_ABL:-../libsimt_hip_abl.so}; fi
+if [ "${ABLATION:-0}" = "1" ]; then FLAGS="${FLAGS/-std=c++17/-std=c++20} -DSIMT_ABLATION"; SRCS+=(experiments/*.hip); BUILD=${BUILD}_abl; OUT=${OUT_ABL:-../libsimt_hip_abl.so}; fi
 mkdir -p $BUILD
 objs=()
 pids=()

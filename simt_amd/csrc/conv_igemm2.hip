@@ -261,7 +261,7 @@ static int launch_conv2e(const Conv2KArgs& k, hipStream_t st) {
 #ifdef SIMT_ABLATION
   if constexpr (NST == 3 && BN == 256 && FBN == 0 && (EPI == 1 || EPI == 2 || EPI == 3 || EPI == 5)) {
     int rc;
-    if (simt_conv2_roles_launch(k, TM, EPI, lds, st, &rc)) return rc;      // csrc/experiments/conv_igemm2_roles.hip (SIMT_CONV2_ROLES=1 | 2)
+    if (simt_conv2_roles_launch(k, TM, EPI, lds, st, &rc)) return rc;      // csrc/experiments/conv_igemm2_roles.hip (SIMT_CONV2_ROLES=1 | 2, SIMT_CONV2_INTER=1)
   }
 #endif
   static SimtLdsAttrCache attr_cache;

@@ -3,6 +3,9 @@
 // bit-identical to the product kernel (tests/test_gpu_conv.py, test_gpu_prod_shapes.py, test_gpu_bn_fused.py green with the switch set) and
 // NEITHER is faster: the role split is neutral within +-1 % on every shape (step 23.71 vs 23.82 ms), the pipelined reads are 4-17 % SLOWER
 // (3x3 256 -> 256: 42.4 -> 44.5 us, 1x1 2048 -> 512: 88 -> 101 us; step 24.08 -> 24.79 ms): profiles/r05_conv_attribution.txt.
+// SIMT_CONV2_INTER=1: the third schedule of the round, conv_igemm2i_kernel below -- every wave issues its LDS-DMA pieces INSIDE its MFMA burst
+// (one piece behind every fifth MFMA, sources computed in front of the burst): bit-identical, 1-1.5 % SLOWER on every shape (3x3 256: 41.8 ->
+// 42.4 us; step 23.80 vs 23.83 ms).  Three schedules, one time: what bounds the stage is not the order of issue.
 #include "../conv2_common.h"
 #include "../conv2_epilogue.h"
 #include <stdlib.h>
@@ -251,6 +254,197 @@ __global__ __launch_bounds__(512, 2) void conv_igemm2r_kernel(Conv2KArgs a) {
   conv2_epilogue<BN, BM, NT, TN, TM, FBN, EPI>(a, smem, acc, true, wm, wn, tid, lane, m0, n0, m_end, mt, tile);
 }
 
+// ---- experiment (SIMT_CONV2_INTER=1): the LDS-DMA pieces of a stage issued INSIDE the wave's MFMA burst (one piece behind every IV MFMAs, pinned
+// with sched_group_barrier), their source addresses computed in front of the burst (no VALU between the MFMAs), weight pieces from a scalar
+// row-group base + one per-lane offset.  Same ring / fragment reads / MFMA order as conv_igemm2_body: bit-identical.  Why: in-loop stamps
+// (profiles/r05_conv_attribution_stamps.txt) -- per 64-deep stage each wave spends ~440 clocks issuing its 6-7 pieces behind or in front of
+// its 680-clock MFMA burst, and the matrix pipe idles 26 % of the stage; a piece has no register destination, so it can leave between MFMAs.
+template <int BN, int TMP, int EPI>
+__global__ __launch_bounds__(512, 2) void conv_igemm2i_kernel(Conv2KArgs a) {
+  constexpr int NT = 512, NST = 3;
+  constexpr int WM = 2, WN = 4;
+  constexpr int TM = TMP, TN = BN / WN / 16;
+  constexpr int BM = WM * TM * 16;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_IT = (BM * 8 + NT - 1) / NT, B_IT = BN * 8 / NT;
+  constexpr bool A_TAIL = (BM * 8) % NT != 0;
+  constexpr int NP = A_IT + B_IT;                  // pieces per wave and stage (the tail pixel piece: waves 0-3 only)
+  constexpr int NM = 2 * TN * TM;                  // MFMAs per wave and stage
+  constexpr int IV = NM / (NP + 1);                // MFMAs in front of every piece
+  static_assert(BN == 256, "experiment: the wide tile only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nwg = a.ntiles_m * a.ntiles_n;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int mt = tile / a.ntiles_n, nt = tile - mt * a.ntiles_n;
+  const int m0 = mt * a.rows, n0 = nt * BN;
+  const int m_end = min(a.M, m0 + a.rows);
+  const int c_pos = tid & 7;
+  const int a_cg = c_pos ^ (((tid >> 3) >> 1) & 7);
+  const unsigned b_off0 = (unsigned)(tid >> 3) * (unsigned)a.wrow_bytes + (unsigned)(a_cg * 16);      // row group i adds the uniform i * 64 * wrow_bytes
+  unsigned a_off[A_IT];
+  unsigned long long a_ok[A_IT];
+  int tdy[9], tdx[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { tdy[t] = a.dy[t]; tdx[t] = a.dx[t]; }
+  const int ntaps = a.ntaps;
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int m = m0 + i * (NT / 8) + (tid >> 3);
+    a_ok[i] = 0ull;
+    a_off[i] = 0u;
+    if (m < m_end) {
+      int b, r, oy, ox;
+      fast_divmod(m, a.Ho * a.Wo, a.rcp_hw, b, r);
+      fast_divmod(r, a.Wo, a.rcp_wo, oy, ox);
+      const int iy = oy * a.stride, ix = ox * a.stride;
+      a_off[i] = (unsigned)(((b * a.H + iy) * a.W + ix)) * (unsigned)a.pix_bytes + (unsigned)(a_cg * 16);
+      unsigned long long msk = 0ull;
+      if (ntaps <= 9) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int yy = iy + tdy[t], xx = ix + tdx[t];
+          if (t < ntaps && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) msk |= (1ull << t);
+        }
+      } else {
+        for (int t = 0; t < ntaps; ++t) {
+          const int yy = iy + a.dy[t], xx = ix + a.dx[t];
+          if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) msk |= (1ull << t);
+        }
+      }
+      a_ok[i] = msk;
+    }
+  }
+  const char* zsrc = a.zero + a_cg * 16;
+  const bool a_tail_wave = !A_TAIL || wave < (BM * 8 - (A_IT - 1) * NT) / 64;
+  int ld_tap = 0, ld_kc = 0;
+  // sources of the NEXT stage's pieces, computed ahead of the burst that issues them
+  const char* asrc[A_IT];
+  unsigned bvo = 0u;
+  auto prep = [&]() {
+    const int toff = a.toff[ld_tap] + ld_kc * 128;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const bool ok = (a_ok[i] >> ld_tap) & 1ull;
+      asrc[i] = ok ? a.x + (unsigned)(a_off[i] + (unsigned)toff) : zsrc;
+    }
+    bvo = b_off0 + (unsigned)(ld_tap * a.kc_per_tap + ld_kc) * 128u;
+    if (++ld_tap == a.ntaps) { ld_tap = 0; ++ld_kc; }
+  };
+  auto fire = [&](auto PP, char* sbase) {          // piece PP of the prepared stage: pixel pieces first, then weight pieces
+    constexpr int P = decltype(PP)::value;
+    if constexpr (P < A_IT) {
+      if (P < A_IT - 1 || a_tail_wave)
+        __builtin_amdgcn_global_load_lds(GPTR(asrc[P]), LPTR(sbase + (P * NT + wave * 64) * 16), 16, 0, 0);
+    } else {
+      constexpr int i = P - A_IT;
+      const char* wrows = a.w + (size_t)(unsigned)(n0 + i * (NT / 8)) * (unsigned)a.wrow_bytes;      // uniform
+      __builtin_amdgcn_global_load_lds(GPTR(wrows + bvo), LPTR(sbase + A_BYTES + (i * NT + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+  auto fire_all = [&](char* sbase) {
+    [&]<int... P>(std::integer_sequence<int, P...>) { (fire(std::integral_constant<int, P>{}, sbase), ...); }(std::make_integer_sequence<int, NP>{});
+  };
+  auto wait_stage = [&](bool more) {
+    if (!more) { wait_vmcnt<0>(); return; }
+    if constexpr (A_TAIL) {
+      if (!a_tail_wave) { wait_vmcnt<A_IT - 1 + B_IT>(); return; }
+    }
+    wait_vmcnt<A_IT + B_IT>();
+  };
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nk = a.ntaps * a.kc_per_tap;
+  const int sw = (lane >> 1) & 7;
+  const int frag_row_off = (lane & 15) * 128;
+  const int kq = lane >> 4;
+  const int xbase = (wm * TM * 16) * 128 + frag_row_off;
+  const int wbase = A_BYTES + (wn * TN * 16) * 128 + frag_row_off;
+  bf16x8 xf[2][TM], wf[2][TN];
+  auto load_frags = [&](int buf) {
+    const char* px = smem + buf * STAGE + xbase;
+    const char* pw = smem + buf * STAGE + wbase;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int coff = ((4 * s + kq) ^ sw) << 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xf[s][i] = *(const bf16x8*)(px + i * 16 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[s][j] = *(const bf16x8*)(pw + j * 16 * 128 + coff);
+    }
+  };
+  // the MFMA burst of one stage with the prepared pieces (if any) inside it
+  auto burst = [&](char* sbase, bool pieces) {
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+      ([&] {
+        constexpr int sh = I / (TN * TM), j = (I / TM) % TN, i = I % TM;
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[sh][j], xf[sh][i], acc[j][i], 0, 0, 0);
+        if constexpr ((I + 1) % IV == 0 && (I + 1) / IV <= NP) {
+          if (pieces) fire(std::integral_constant<int, (I + 1) / IV - 1>{}, sbase);
+        }
+      }(), ...);
+    }(std::make_integer_sequence<int, NM>{});
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, IV, 0);      // IV MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // one vector-memory read (the LDS-DMA piece)
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM - NP * IV, 0);
+  };
+  prep();
+  fire_all(smem);
+  if (nk > 1) { prep(); fire_all(smem + STAGE); }
+  int buf = 0;
+  if (wave < 4) {
+    // ---- early half: [barrier] fragments(kt) -> sources(kt+2) -> { MFMA(kt) | pieces(kt+2) }
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_stage(kt + 1 < nk);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      load_frags(buf);
+      const bool more = kt + NST - 1 < nk;
+      if (more) prep();
+      burst(smem + (buf >= 1 ? buf - 1 : NST - 1) * STAGE, more);
+      buf = (buf + 1 == NST) ? 0 : buf + 1;
+    }
+  } else {
+    // ---- late half: [barrier] { MFMA(kt-1) | pieces(kt+2) } -> fragments(kt) -> sources(kt+3)
+    bool have = false;
+    {
+      // stage 0 has nothing to multiply: its pieces go out plainly
+      wait_stage(nk > 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (NST - 1 < nk) { prep(); fire_all(smem + (NST - 1) * STAGE); }
+      load_frags(0);
+      buf = 1;
+      have = 1 + NST - 1 < nk;
+      if (have) prep();
+    }
+    for (int kt = 1; kt < nk; ++kt) {
+      wait_stage(kt + 1 < nk);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      burst(smem + (buf >= 1 ? buf - 1 : NST - 1) * STAGE, have);
+      load_frags(buf);
+      buf = (buf + 1 == NST) ? 0 : buf + 1;
+      have = kt + 1 + NST - 1 < nk;
+      if (have) prep();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    burst(smem, false);
+  }
+  conv2_epilogue<BN, BM, NT, TN, TM, 0, EPI>(a, smem, acc, true, wm, wn, tid, lane, m0, n0, m_end, mt, tile);
+}
+
 template <int TM, int EPI, int PIPE>
 static int launch_roles(const Conv2KArgs& k, size_t lds, hipStream_t st) {
   static SimtLdsAttrCache attr_cache;
@@ -261,8 +455,24 @@ static int launch_roles(const Conv2KArgs& k, size_t lds, hipStream_t st) {
   return SIMT_OK;
 }
 
+template <int TM, int EPI>
+static int launch_inter(const Conv2KArgs& k, size_t lds, hipStream_t st) {
+  static SimtLdsAttrCache attr_cache;
+  if (simt_lds_attr_needed(&attr_cache, lds))
+    (void)hipFuncSetAttribute((const void*)conv_igemm2i_kernel<256, TM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((conv_igemm2i_kernel<256, TM, EPI>), dim3(k.ntiles_m * k.ntiles_n), dim3(512), lds, st, k);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
 bool simt_conv2_roles_launch(const Conv2KArgs& k, int tm, int epi, size_t lds, hipStream_t st, int* rc) {
   static const int v = getenv("SIMT_CONV2_ROLES") ? atoi(getenv("SIMT_CONV2_ROLES")) : 0;
+  static const int inter = getenv("SIMT_CONV2_INTER") ? atoi(getenv("SIMT_CONV2_INTER")) : 0;
+  if (inter && epi >= 1 && epi <= 3) {
+#define SIMT_INTER_CASE(T, E) if (tm == T && epi == E) { *rc = launch_inter<T, E>(k, lds, st); return true; }
+    SIMT_INTER_CASE(5, 1) SIMT_INTER_CASE(5, 2) SIMT_INTER_CASE(5, 3) SIMT_INTER_CASE(4, 1) SIMT_INTER_CASE(4, 2) SIMT_INTER_CASE(4, 3)
+#undef SIMT_INTER_CASE
+  }
   if (v != 1 && v != 2) return false;
 #define SIMT_ROLES_CASE(T, E) if (tm == T && epi == E) { *rc = v == 2 ? launch_roles<T, E, 1>(k, lds, st) : launch_roles<T, E, 0>(k, lds, st); return true; }
   SIMT_ROLES_CASE(5, 1) SIMT_ROLES_CASE(5, 2) SIMT_ROLES_CASE(5, 3) SIMT_ROLES_CASE(5, 5)
