@@ -16,7 +16,7 @@ extern "C" int simt_abi_version(void) { return 1; }
 // ---- device-scope events (round 5).  The launch lists order their two HIP streams with events (weight gradients behind the dgrad chain,
 // BatchNorm passes beside the frozen model's convs).  A default hipEvent performs a SYSTEM-scope release when it is recorded -- write-back
 // and invalidation of the caches so that the host could read the data -- and the stream's next kernel waits for it: ~6.5 us of idle queue
-// behind every record, ~12 us for a cross-stream wait (rocprofv3 kernel trace, profiles/r05_events.txt).  Both streams of a plan live on
+// behind every record, ~12 us for a cross-stream wait (rocprofv3 kernel trace, profiles/r05_conv_attribution.txt section 6).  Both streams of a plan live on
 // one device: hipEventDisableTiming | hipEventReleaseToDevice | hipEventDisableSystemFence is all the ordering they need.
 extern "C" int simt_event_create(void** ev, int system_scope) {
   SIMT_CHECK(ev);

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
 // same layer see the same shapes (tools/trainV2_simt.py:351-353 and :370 call the same ResNetMulti.forward, model/deeplab_multi.py:172-192).
 // Workgroups [0, nwg) run problem 0, [nwg, 2 nwg) problem 1, each with its own compile-time epilogue flavour (the branch is workgroup-uniform
 // and sits in front of everything: nothing inside the K loop knows about it).  Measured on the production shapes (one launch of twice the
-// workgroups against two launches): 11 us per pair on the 3x3 256 -> 256, 2.5 us on 1x1 1024 -> 256 (profiles/r05_pair_launch.txt): the second
+// workgroups against two launches): 11 us per pair on the 3x3 256 -> 256, 2.5 us on 1x1 1024 -> 256 (profiles/r05_conv_attribution.txt section 5): the second
 // round of workgroups starts as the first drains, one launch ramp / drain / boundary instead of two.
 template <int BN, int TMP, int NSTP, int EPI0, int EPI1>
 __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_pair_kernel(Conv2KArgs a0, Conv2KArgs a1) {

@@ -376,7 +376,7 @@ class SimTTrainer:
         each list's own order is kept, everything that has no partner is launched as before.  The two-stream schedule this replaces ran the
         forwards one after the other anyway (the GPU serves one conv queue at a time: profiles/r02_step_timeline.txt); what the pairing removes
         is one launch ramp / drain per layer: 11 us per 3x3 pair, 12 us per conv3 pair, 2.5 us per 1x1 1024 -> 256 pair
-        (profiles/r05_pair_launch.txt).  Outputs are bit-identical to the separate launches (tests/test_gpu_iteration.py)."""
+        (profiles/r05_conv_attribution.txt section 5).  Outputs are bit-identical to the separate launches (tests/test_gpu_iteration.py)."""
         from .engine import _Launch
         lib = L.load()
         conv_fn = lib.simt_conv_fprop
