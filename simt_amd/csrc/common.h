@@ -76,7 +76,9 @@ __device__ __forceinline__ void raw8_unpack(const Raw8<bf16_t>& q, float* v) {
 #ifndef SIMT_NT_STORES
 #define SIMT_NT_STORES 0          // per translation unit: a file that wants them defines SIMT_NT_STORES 1 before including this header
 #endif
-__device__ __forceinline__ void st_out16(void* p, const uint4& v) {
+// (`static`: the bodies differ per translation unit through SIMT_NT_STORES -- internal linkage keeps that from being one-definition-rule
+// roulette should a build ever stop inlining them or link relocatable device code)
+static __device__ __forceinline__ void st_out16(void* p, const uint4& v) {
   typedef unsigned simt_u32x4 __attribute__((ext_vector_type(4)));
   const simt_u32x4 w = {v.x, v.y, v.z, v.w};
 #if SIMT_NT_STORES
@@ -85,19 +87,19 @@ __device__ __forceinline__ void st_out16(void* p, const uint4& v) {
   *(simt_u32x4*)p = w;
 #endif
 }
-__device__ __forceinline__ void st_out8(bf16_t* p, const float* v) {
+static __device__ __forceinline__ void st_out8(bf16_t* p, const float* v) {
   uint4 r;
   r.x = pack_bf16x2(v[0], v[1]); r.y = pack_bf16x2(v[2], v[3]); r.z = pack_bf16x2(v[4], v[5]); r.w = pack_bf16x2(v[6], v[7]);
   st_out16(p, r);
 }
-__device__ __forceinline__ void st_out8(float* p, const float* v) {
+static __device__ __forceinline__ void st_out8(float* p, const float* v) {
   st_out16(p, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
   st_out16(p + 4, make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])));
 }
 
-__device__ __forceinline__ void store8(float* p, const float* v) { st_out8(p, v); }
-__device__ __forceinline__ void store8(bf16_t* p, const float* v) { st_out8(p, v); }
-__device__ __forceinline__ void st_out16f(float* p, const f32x4& v) {      // an accumulator quad (fp32 results: the tap-expanded head GEMMs, weight-gradient slabs)
+static __device__ __forceinline__ void store8(float* p, const float* v) { st_out8(p, v); }
+static __device__ __forceinline__ void store8(bf16_t* p, const float* v) { st_out8(p, v); }
+static __device__ __forceinline__ void st_out16f(float* p, const f32x4& v) {      // an accumulator quad (fp32 results: the tap-expanded head GEMMs, weight-gradient slabs)
 #if SIMT_NT_STORES
   __builtin_nontemporal_store(v, (f32x4*)p);
 #else

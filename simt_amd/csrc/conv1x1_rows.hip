@@ -424,6 +424,9 @@ __device__ __forceinline__ void conv1x1_rows_body(const Conv2KArgs& a, const int
       for (int w = 0; w < NSW; ++w) { t1 += sR[(w * 2 + 0) * BN + st]; t2 += sR[(w * 2 + 1) * BN + st]; }
       if (has_bnr) {                                           // [m-tile][3][Cout]: S1, S2 and the (unused) second-BN row
         a.bnr_part[((long)mt * 3 + 0) * a.Cout + nn] = t1;
+        // (S2 = rstd * sum g (y - mean): rstd once per tile and column.  conv2_epilogue.h / simt_bn_bwd keep sum g ((y - mean) rstd): the
+        // same BatchNorm backward through this kernel and through conv_igemm2 agrees to rounding (5e-6 per layer), not bit for bit --
+        // INTEGRATION.md, SIMT_NO_ROWS)
         a.bnr_part[((long)mt * 3 + 1) * a.Cout + nn] = t2 * a.bnr_rstd[nn];
         a.bnr_part[((long)mt * 3 + 2) * a.Cout + nn] = 0.f;
       } else {
