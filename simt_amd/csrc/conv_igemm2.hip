@@ -104,7 +104,10 @@ __device__ __forceinline__ void conv_igemm2_body(const Conv2KArgs& a, const int 
       const int iy = oy * a.stride, ix = ox * a.stride;
       a_off[i] = (unsigned)(((b * a.H + iy) * a.W + ix)) * (unsigned)a.pix_bytes + (unsigned)(a_cg * 16);
       unsigned long long msk = 0ull;
-      if (ntaps <= 9) {
+      if (ntaps == 1 && tdy[0] == 0 && tdx[0] == 0) {
+        msk = 1ull;          // 1x1 convs (two thirds of the launches): the one tap is the pixel itself, always inside -- the nine predicated tap tests
+                             // below were ~190 of this prologue's ~250 vector instructions per thread (uniform branch)
+      } else if (ntaps <= 9) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
           const int yy = iy + tdy[t], xx = ix + tdx[t];
