@@ -327,7 +327,10 @@ def main():
                     "whole_step_frac": round((g_fl + t_fl) / ((g_ms + aux + evs[0].elapsed_time(evs[2])) * 1e-3) / 1e12 / peak, 4),
                     "what": "tap-expanded ASPP classifier GEMMs (3 forward: two trainable heads + the frozen main head; 2 dgrad; wgrads are in "
                             "conv_wgrad) as launched in the step, plus the fused head kernels (upsample, softmax, logits x T, the nine losses and "
-                            "their gradients: VALU per lane, 22 x 19 mat-vec, SURVEY allows) timed alone; target north_star: >= 0.5 of MFMA peak"}
+                            "their gradients: VALU per lane, 22 x 19 mat-vec, SURVEY allows) timed alone; target north_star: >= 0.5 of MFMA peak.  "
+                            "Bound for THIS decomposition (DESIGN.md 5b): the GEMMs run as N = 432 columns in two 256-column tiles (19 % padding) with an fp32 "
+                            "result or as K = 448 dgrads (output-bound: 154 MB bf16 result + bit mask for 66 GFLOP), at most ~0.4 ms at this kernel's best "
+                            "shape rate -> gemm_frac_of_peak <= 0.3; with the 0.7-ms fused loss block (VALU, no MFMA shape) whole_step_frac <= 0.15"}
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc or twhy, "mfma_busy": mfma_busy, "mfma_busy_source": msrc or mwhy,
                 "alg_bytes_per_launch": int(by / n), "launches_per_step": n,
