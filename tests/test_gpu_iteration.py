@@ -300,7 +300,9 @@ def test_early_sgd_and_schedule_switches_same_trajectory(dev, monkeypatch):
     for env in ({"SIMT_EARLY_SGD": "0", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "main"}, {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "side"},
                 {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "1", "SIMT_FWD_ORDER": "main"}, {"SIMT_EARLY_SGD": "0", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "interleave"},
                 {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "pair"},       # round 5 default: one launch per layer for both networks
-                {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "bnside2"}):
+                {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "bnside2"},
+                {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "main", "SIMT_LIGHT_EVENTS": "0"}):      # torch.cuda.Event instead of the device-scope events
+        monkeypatch.delenv("SIMT_LIGHT_EVENTS", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         hp = Hyper(open_classes=K, lambda_convex=0.1, lambda_volume=1.0, lambda_anchor=1.0, lr=6e-4, lr_T=6e-3)
