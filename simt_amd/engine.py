@@ -940,9 +940,18 @@ class TrunkPlan:
         nblk_group = max(1, min(npar - 3, int(os.environ.get("SIMT_WGRAD_BLOCKS", "3")))) if pair_ok else 1
         pend = {"jobs": [], "pars": [], "M": None, "tco": None, "blocks": 0}
 
+        per_block_events = os.environ.get("SIMT_WGRAD_EVENT_PER_BLOCK") == "1"      # A/B switch: round 4's one event per Bottleneck
+        waited_main = set()
+
         def flush_wgrads():
             if not pend["jobs"]:
                 return
+            # ONE main -> side edge per weight-gradient GROUP (round 5), recorded here: everything the group reads (the dY / dy buffers of up
+            # to three Bottlenecks) is already enqueued on the main stream.  Until round 4 every block recorded its own event although its jobs
+            # only left with the group's launch: a record idles the recording queue for ~6.5 us (profiles/r05_conv_attribution.txt section 6),
+            # 22 of them per step on the critical dgrad / BatchNorm chain.
+            if not per_block_events:
+                b.wait(b.record(0), 1)
             self._wgrad_group(b, pend["jobs"])
             ev = b.record(1)
             for q in pend["pars"]:
@@ -969,8 +978,10 @@ class TrunkPlan:
             assert dz is not None, "no gradient reaches the last block (a head must sit on the last layer)"
             blk_start = len(b)
             par = bi % npar
-            if last_side[par] is not None:
+            if last_side[par] is not None and (per_block_events or id(last_side[par]) not in waited_main):
+                # (one wait per side-stream event: the three Bottlenecks of a weight-gradient group share the event behind their group's launch)
                 b.wait(last_side[par], 0)
+                waited_main.add(id(last_side[par]))
             # ---- z = relu(bn3(y3) + shortcut)
             dy3 = self.buf("g.dy3.%d" % par, Mo, c4)
             dyd = self.buf("g.dyd.%d" % par, Mo, c4) if down else None
@@ -1021,7 +1032,8 @@ class TrunkPlan:
                 self._bn_bwd(b, dz=da1, y=rec["y1"], bname=f"{name}.bn1", dy=dy1, M=Mo, Cn=p, mask_mode=2,
                              reduce_done_nblk=self._fused_nblk(dsc, bnr))
             # conv1 (+ downsample) wgrads
-            b.wait(b.record(0), 1)
+            if not grouped or per_block_events:
+                b.wait(b.record(0), 1)
             wjobs.append(dict(dy=dy1, x=rec["x"], Bn=B, Hi=Hi, Wi=Wi, Cin=inpl, Ho=Ho, Wo=Wo, Cd=p, ldd=p, taps=[(0, 0)], stride=stride,
                               parts=[(f"{name}.conv1.weight", 0, 0, p, 1, inpl)]))
             if down:

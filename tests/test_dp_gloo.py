@@ -184,7 +184,7 @@ def test_dp_step_equals_oracle_on_mean_gradients_world2():
 # World size 8 (BASELINE configs[2]: 8 x MI355X, global batch 32) on the REAL exchange table of the production plan
 # (tests/golden/g16_dp_bucket_table.json, written on a GPU box by profiles/tools/dump_bucket_table.py; tests/test_gpu_dp.py checks
 # that the live plan still produces it): 96 gradient tensors, 42.2 M fp32 = 168.7 MB, five buckets of 33 / 32 / 33 / 34 / 28 MB that
-# become ready at backward launches 41 / 77 / 125 / 197 / 238 of 322.  Eight gloo ranks release the buckets at the replay's real hook
+# become ready at backward launches 37 / 69 / 105 / 159 / 191 of 263.  Eight gloo ranks release the buckets at the replay's real hook
 # points, exactly like TrunkPlan.backward(hook=...) with the early optimiser step does, and must end with the mean.
 # ----------------------------------------------------------------------------------------------------------------------
 def _real_table():
