@@ -139,6 +139,69 @@ def cpu_baseline(K, iters):
             "c1_512x512": {"value": round(1.0 / pts[512], 5), "s_per_iter": round(pts[512], 2)}}
 
 
+class PowerWatch:
+    """Socket power and shader clock of THIS process's GPU during the timed steps, sampled from sysfs (hwmon power1_average, the starred level of
+    pp_dpm_sclk) by a thread every 0.1 s.  Context for the roofline fraction, not a metric: the peaks of MI355X_MICROARCH.md are quoted at the
+    nominal 2.4 GHz, and the step of this bench runs power-managed below it (profiles/r05_power_clock.txt: 1 218 W, 2 166 MHz sustained; the dominant
+    conv alone 1 941 MHz)."""
+
+    def __init__(self, device_index):
+        import glob
+        import threading
+        self.dir, self.samples, self._stop, self._thr = None, [], threading.Event(), None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for c in glob.glob("/sys/class/drm/card[0-9]*"):
+                if os.path.basename(os.path.realpath(os.path.join(c, "device"))) == addr:
+                    self.dir = os.path.join(c, "device")
+            if self.dir:
+                hw = glob.glob(os.path.join(self.dir, "hwmon", "hwmon*"))
+                self.pfile = next((os.path.join(h, f) for h in hw for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, f))), None)
+                self._thr = threading.Thread(target=self._run, daemon=True)
+        except Exception:
+            self.dir = None
+
+    def _read(self):
+        w = mhz = top = None
+        try:
+            if self.pfile:
+                w = float(open(self.pfile).read()) / 1e6
+            lv = open(os.path.join(self.dir, "pp_dpm_sclk")).read().split("\n")
+            vals = [float(l.split()[1].lower().replace("mhz", "")) for l in lv if l.strip()]
+            cur = [float(l.split()[1].lower().replace("mhz", "")) for l in lv if "*" in l]
+            mhz, top = (cur[0] if cur else None), (max(vals) if vals else None)
+        except Exception:
+            pass
+        return w, mhz, top
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append(self._read())
+            self._stop.wait(0.1)
+
+    def __enter__(self):
+        if self._thr:
+            self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thr:
+            self._thr.join()
+
+    def report(self):
+        w = [x[0] for x in self.samples if x[0] is not None]
+        m = [x[1] for x in self.samples if x[1] is not None]
+        t = [x[2] for x in self.samples if x[2] is not None]
+        if not w and not m:
+            return None
+        return {"avg_w": round(sum(w) / len(w), 1) if w else None, "sclk_mhz_avg": round(sum(m) / len(m), 1) if m else None,
+                "sclk_mhz_top_level": max(t) if t else None, "samples": len(self.samples),
+                "what": "socket power and shader clock of this GPU during the timed steps (sysfs, every 0.1 s): the step runs power-managed below "
+                        "the nominal clock the MFMA peak is quoted at"}
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -253,7 +316,8 @@ def main():
     red = getattr(tr, "reducer", None)
     if red is not None:
         red.measure = True
-    dt, med = timed(tr, resident(1234 + rank), a.steps, a.warmup)
+    with PowerWatch(local) as pw:
+        dt, med = timed(tr, resident(1234 + rank), a.steps, a.warmup)
     comm = None
     if red is not None:
         comm = red.report()              # the exchange of the timed steps (plus warm-up): bytes, buckets, exposed wait
@@ -431,6 +495,8 @@ def main():
             line["aspp_t_step"] = aspp
         if comm is not None:
             line["comm"] = comm
+        if pw.report() is not None:
+            line["power_clock"] = pw.report()
         line.update(extra)
         print(json.dumps(line))
     if world > 1:

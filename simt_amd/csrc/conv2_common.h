@@ -45,7 +45,10 @@ struct Conv2KArgs {
 // In-kernel stamps (diagnostic builds only): s_memtime of wave 0 / lane 0 of every workgroup at fixed points, read back with
 // simt_debug_stamps().  Slots: 0 start, 1 addressing done, 2 first stage landed, 3 main loop done, 4 tile in LDS, 5 stores issued, 6 end.
 static __device__ unsigned long long g_stamps[8192 * 8];     // one copy per translation unit (no relocatable device code)
-#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// Slot 7: s_memrealtime ticks (constant 100 MHz) between stamps 0 and 6 -- with slots 0 and 6 the shader clock the launch actually ran at.
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) { g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if ((i) == 0) g_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime(); \
+    if ((i) == 6) g_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime() - g_stamps[blockIdx.x * 8 + 7]; } } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif

@@ -252,7 +252,7 @@ bool simt_conv2_abl_launch(const Conv2KArgs& k, int bn, int tm, int nst, hipStre
 int simt_conv2_abl_wants_frag(const simt_conv_desc* d);
 #endif
 #ifdef SIMT_ABLATION
-bool simt_conv2_roles_launch(const Conv2KArgs& k, int tm, int epi, size_t lds, hipStream_t st, int* rc);      // round-5 experiment, ablation builds only
+bool simt_conv2_roles_launch(const Conv2KArgs& k, int tm, int epi, size_t lds, hipStream_t st, int* rc); bool simt_conv2_half_launch(const Conv2KArgs& k, int tm, int epi, size_t lds, hipStream_t st, int* rc);      // round-5 experiments, ablation builds only
 #endif
 template <int BN, int TM, int NST = 3, int FBN = 0, int EPI = 0>
 static int launch_conv2e(const Conv2KArgs& k, hipStream_t st) {
@@ -264,7 +264,7 @@ static int launch_conv2e(const Conv2KArgs& k, hipStream_t st) {
 #ifdef SIMT_ABLATION
   if constexpr (NST == 3 && BN == 256 && FBN == 0 && (EPI == 1 || EPI == 2 || EPI == 3 || EPI == 5)) {
     int rc;
-    if (simt_conv2_roles_launch(k, TM, EPI, lds, st, &rc)) return rc;      // csrc/experiments/conv_igemm2_roles.hip (SIMT_CONV2_ROLES=1 | 2, SIMT_CONV2_INTER=1)
+    if (simt_conv2_half_launch(k, TM, EPI, lds, st, &rc) || simt_conv2_roles_launch(k, TM, EPI, lds, st, &rc)) return rc;      // csrc/experiments/conv_igemm2_roles.hip (SIMT_CONV2_ROLES=1 | 2, SIMT_CONV2_INTER=1)
   }
 #endif
   static SimtLdsAttrCache attr_cache;
