@@ -400,6 +400,8 @@ def main():
                 "alg_bytes_per_launch": int(by / n), "launches_per_step": n,
                 "avg_launch_us": round(ms_k / n * 1e3, 2), "alg_gflop_per_launch": round(fl / n / 1e9, 3),
                 "share_of_step_kernel_time": round(ms_k / tot_ms, 3),
+                "clock_note": ("peak is the guide's dense bf16 figure at the nominal 2.4 GHz; this kernel runs power-managed at ~1.94 GHz (in-kernel s_memtime "
+                               "against s_memrealtime, profiles/r05_power_clock.txt), where the matrix pipes offer ~2.02 PFLOP/s") if a.dtype == "bf16" else None,
                 "flavours": flav,      # <..., fused BatchNorm (0 | 1), epilogue (0 generic, 1 statistics, 2 BN-backward reduce, 3 bias + ReLU, 4-7 dgrads)>
                 "classes": {k: {"ms": round(v[0], 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[1] else None,
                                 "n": v[3]} for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])[:16]}}
