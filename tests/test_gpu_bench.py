@@ -53,3 +53,7 @@ def test_bench_single_gpu_line_has_every_contract_field(dev):
         assert k in line, k
     assert line["n_gpus"] == 1 and line["roofline"]["bound"] == "mfma" and line["cpu_baseline"]["kind"] == "port"
     assert 0 <= line["trained_like_pass"]["pixels_with_confidence_label"] <= line["trained_like_pass"]["pixels"]
+    # power / shader clock of the timed steps, where the box lets the process read its card's sysfs (context for the roofline fraction)
+    pc = line.get("power_clock")
+    if pc is not None:
+        assert pc["samples"] >= 1 and (pc["sclk_mhz_avg"] is None or 50 <= pc["sclk_mhz_avg"] <= 3000)

@@ -240,3 +240,22 @@ def test_no_scratch_in_production_kernels():
                "head_pass1_kernel<24, 0, 0>", "head_pass1_kernel<40, 0, 0>", "head_pass2_kernel<40, 0, 0>")
     bad = {k: v for k, v in res.items() if v and not any(a in k for a in allowed)}
     assert not bad, f"kernels with scratch_* instructions: {bad}"
+
+
+def test_bench_power_watch_is_silent_without_a_gpu():
+    """bench.py's power / clock sampler (sysfs of the process's GPU) must never break a run: no GPU (here) or unreadable sysfs -> no object in
+    the JSON line; with readable files it reports their means (a fake card directory)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    with bench.PowerWatch(0) as pw:
+        pass
+    assert pw.report() is None or isinstance(pw.report(), dict)
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "hwmon", "hwmon3"))
+        open(os.path.join(td, "hwmon", "hwmon3", "power1_average"), "w").write("1218000000\n")
+        open(os.path.join(td, "pp_dpm_sclk"), "w").write("0: 132Mhz\n1: 2166Mhz *\n2: 2400Mhz\n")
+        pw = bench.PowerWatch.__new__(bench.PowerWatch)
+        pw.dir, pw.pfile, pw.samples = td, os.path.join(td, "hwmon", "hwmon3", "power1_average"), []
+        pw.samples.append(pw._read())
+        r = pw.report()
+        assert r["avg_w"] == 1218.0 and r["sclk_mhz_avg"] == 2166.0 and r["sclk_mhz_top_level"] == 2400.0 and r["samples"] == 1
