@@ -27,6 +27,7 @@ rd=v["TCC_BUBBLE_sum"]*128+(v["TCC_EA0_RDREQ_sum"]-v["TCC_BUBBLE_sum"]-v["TCC_EA
 print(f"{tag}: M={M} {Cin}->{Cout} {k}x{k} d{dil}: algorithmic {alg/1e6:.1f} MB (x {M*Cin*2/1e6:.1f} + y {M*Cout*2/1e6:.1f} + w {Cout*k*k*Cin*2/1e6:.1f}); "
       f"reads {rd/1e6:.1f} MB ({v['TCC_BUBBLE_sum']:.0f} x 128 B + {v['TCC_EA0_RDREQ_sum']-v['TCC_BUBBLE_sum']-v['TCC_EA0_RDREQ_32B_sum']:.0f} x 64 B), "
       f"FETCH_SIZE {v['FETCH_SIZE']*1024/1e6:.1f} MB, writes {v['WRITE_SIZE']*1024/1e6:.1f} MB; L2 requests {v['TCC_REQ_sum']:.0f} hits {v['TCC_HIT_sum']:.0f} "
-      f"misses {v['TCC_MISS_sum']:.0f} ({v['TCC_HIT_sum']/v['TCC_REQ_sum']:.3f} hit)")
+      f"misses {v['TCC_MISS_sum']:.0f} ({v['TCC_HIT_sum']/v['TCC_REQ_sum']:.3f} hit); sector misses x 64 B = {v['TCC_MISS_sum']*64/1e6:.1f} MB, "
+      f"misses per fabric read request {v['TCC_MISS_sum']/max(v['TCC_EA0_RDREQ_sum'],1):.2f} (2 = every request fetches a whole 128-B line: reads = {v['TCC_EA0_RDREQ_sum']*128/1e6:.1f} MB)")
 PY
 rm -rf $OUT/a $OUT/a2 $OUT/a3 $OUT/a4 $OUT/b
