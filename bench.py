@@ -223,7 +223,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
-    if world > 1:
+    # SIMT_DP_FORCE=1 under a one-rank torchrun: the data-parallel job over a REAL one-rank RCCL group (functional test of the N > 1 path -- process
+    # group, barrier, bucketed all-reduce, comm report -- on a 1-GPU box; never a measurement: the exchange is the identity)
+    dp_job = world > 1 or (os.environ.get("SIMT_DP_FORCE") == "1" and "RANK" in os.environ)
+    if dp_job:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -278,7 +281,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp_job:
             import torch.distributed as dist
             if dist.get_backend() == "nccl":
                 dist.barrier(device_ids=[local])
@@ -299,7 +302,7 @@ def main():
             evs[i + 1].record()
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dp_job:
             import torch.distributed as dist
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -486,7 +489,7 @@ def main():
                 "ms_per_step_median": round(med, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                 "config": {"workload": f"{names[1]} + SimT(C=19,K={K}) full training iteration, batch={a.batch}/GPU, "
-                                       f"{H}x{W}, {a.dtype}, {world}xMI355X" + (" DP RCCL all-reduce" if world > 1 else "")
+                                       f"{H}x{W}, {a.dtype}, {world}xMI355X" + (" DP RCCL all-reduce" if dp_job else "")
                                        + (" [backward stops at layer3: unapplied gradients skipped]" if a.skip_unapplied_grads else ""),
                            "global_batch": a.batch * world, "baseline_config": cfg,
                            "numerics": mode, "inputs": "resident in HBM (see h2d_inclusive for the PCIe-inclusive rate)",
@@ -501,7 +504,7 @@ def main():
             line["power_clock"] = pw.report()
         line.update(extra)
         print(json.dumps(line))
-    if world > 1:
+    if dp_job:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -9,6 +9,7 @@ as soon as the launch that completes its last tensor has been enqueued -- the ex
 backward of layer3.  Buckets are sized for xGMI rings (7 links x ~153 GB/s per GPU, per-link bound): few, large
 messages (default 32 MB) rather than NVSwitch-style small ones.
 """
+import os
 import time
 
 import torch
@@ -40,6 +41,9 @@ class BucketReducer:
         """flat: 1-D fp32 tensor; buckets from make_buckets; extra: small tensors reduced at finish() (NTM grads)."""
         self.flat, self.buckets, self.group, self.extra = flat, buckets, group, list(extra)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # a one-rank group exchanges nothing -- unless SIMT_DP_FORCE=1 (tests: the only way to run the collectives of a REAL RCCL group on a
+        # 1-GPU box; a mean over one rank is the identity, bit for bit)
+        self.single = self.world == 1 and not (os.environ.get("SIMT_DP_FORCE") == "1" and dist.is_initialized())
         self.cuda = flat.is_cuda
         self.comm = torch.cuda.Stream(device=flat.device) if self.cuda else None
         backend = dist.get_backend(group) if dist.is_initialized() else ""
@@ -80,7 +84,7 @@ class BucketReducer:
         self.released = [None] * len(self.buckets)
 
     def _reduce(self, t):
-        if self.world == 1:
+        if self.single:
             return
         if self.avg:
             self.handles.append(dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
@@ -94,7 +98,7 @@ class BucketReducer:
             s, e, _ = self.buckets[self.next]
             self.released[self.next] = launch_index
             self.next += 1
-            if self.world == 1:
+            if self.single:
                 continue
             if self.cuda:
                 ev = torch.cuda.Event()
@@ -110,7 +114,7 @@ class BucketReducer:
     def finish(self):
         """Flush remaining buckets + the extra tensors, then make the compute stream wait for the exchange."""
         self.ready_upto(1 << 60)
-        if self.world == 1:
+        if self.single:
             return
         if self.cuda:
             ev = torch.cuda.Event()

@@ -57,3 +57,28 @@ def test_bench_single_gpu_line_has_every_contract_field(dev):
     pc = line.get("power_clock")
     if pc is not None:
         assert pc["samples"] >= 1 and (pc["sclk_mhz_avg"] is None or 50 <= pc["sclk_mhz_avg"] <= 3000)
+
+
+def test_bench_dp_job_over_a_real_one_rank_rccl_group(dev):
+    """The driver's N > 1 launch line with ONE rank and SIMT_DP_FORCE=1: bench.py's data-parallel job -- RCCL process group bound to the device,
+    barrier, bucketed ReduceOp.AVG all-reduce on the comm stream under the backward, max-over-ranks timing, comm report -- runs end to end over
+    the production backend (a 1-GPU box cannot hold two RCCL ranks; the two-rank functional test above uses gloo)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["SIMT_DP_FORCE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "1", "--size", "129", "129", "--no-cpu-baseline",
+           "--no-extra-passes"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-3000:]
+    line = json.loads(lines[0])
+    c = line["comm"]
+    assert line["n_gpus"] == 1 and "RCCL" in line["config"]["workload"] and c["op"] == "AVG" and c["world"] == 1
+    assert c["steps_measured"] >= 3 and c["exposed_wait_ms_median"] >= 0.0 and all(r >= 0 for r in c["bucket_released_launch"])
+    assert line["value"] > 0
