@@ -155,6 +155,8 @@ class PowerWatch:
             for c in glob.glob("/sys/class/drm/card[0-9]*"):
                 if os.path.basename(os.path.realpath(os.path.join(c, "device"))) == addr:
                     self.dir = os.path.join(c, "device")
+            if os.environ.get("SIMT_BENCH_NO_POWER") == "1":      # A/B of the sampler itself
+                self.dir = None
             if self.dir:
                 hw = glob.glob(os.path.join(self.dir, "hwmon", "hwmon*"))
                 self.pfile = next((os.path.join(h, f) for h in hw for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, f))), None)
