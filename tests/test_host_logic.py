@@ -259,3 +259,15 @@ def test_bench_power_watch_is_silent_without_a_gpu():
         pw.samples.append(pw._read())
         r = pw.report()
         assert r["avg_w"] == 1218.0 and r["sclk_mhz_avg"] == 2166.0 and r["sclk_mhz_top_level"] == 2400.0 and r["samples"] == 1
+
+
+def test_measurement_tools_compile():
+    """profiles/tools/*.py, profiles/*.py and bench.py are run only on the GPU box: at least their syntax is checked here."""
+    import glob
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "tools", "*.py")) + glob.glob(os.path.join(root, "profiles", "*.py"))) + [os.path.join(root, "bench.py")]
+    assert len(files) > 20
+    with tempfile.TemporaryDirectory() as td:
+        for f in files:
+            py_compile.compile(f, cfile=os.path.join(td, "x.pyc"), doraise=True)
