@@ -39,11 +39,28 @@ for (Cin, Cout, k, dil) in ((256, 256, 3, 2), (1024, 256, 1, 1)):
     e1.record()
     torch.cuda.synchronize()
     nb = 255
-    out = (C.c_uint64 * (nb * 8))()
-    assert getattr(lib, which)(out, nb) == 0
-    v = np.array(out, dtype=np.int64).reshape(nb, 8)
-    clocks = v[:, 6] - v[:, 0]
-    mhz = clocks / (v[:, 7] * 10e-9) / 1e6
-    loop = v[:, 3] - v[:, 2]
+
+    def stamps():
+        out = (C.c_uint64 * (nb * 8))()
+        assert getattr(lib, which)(out, nb) == 0
+        v = np.array(out, dtype=np.int64).reshape(nb, 8)
+        clocks = v[:, 6] - v[:, 0]
+        return clocks, clocks / (v[:, 7] * 10e-9) / 1e6, v[:, 3] - v[:, 2]
+    clocks, mhz, loop = stamps()
+    # the same launch after 20 ms of idle GPU (nothing to throttle for): what the kernel takes when the chip grants the nominal clock
+    import time
+    ts = []
+    for _ in range(9):
+        torch.cuda.synchronize()
+        time.sleep(0.02)
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        assert fn(C.byref(d), st) == 0
+        s1.record()
+        torch.cuda.synchronize()
+        ts.append(s0.elapsed_time(s1) * 1e3)
+    clocks1, mhz1, _ = stamps()
+    print(f"{tag}: {k}x{k} {Cin}->{Cout}: ONE launch after 20 ms of idle: {np.median(ts):.1f} us (event pair; min {min(ts):.1f}); in-kernel {np.median(clocks1):.0f} clocks at "
+          f"{np.median(mhz1):.0f} MHz")
     print(f"{tag}: {k}x{k} {Cin}->{Cout}: {e0.elapsed_time(e1) * 1e3 / N:.1f} us per launch back to back; in-kernel {np.median(clocks):.0f} clocks, K loop "
           f"{np.median(loop):.0f}; shader clock {np.median(mhz):.0f} MHz (5 % .. 95 % of the workgroups: {np.percentile(mhz, 5):.0f} .. {np.percentile(mhz, 95):.0f})")
