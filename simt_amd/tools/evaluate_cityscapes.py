@@ -36,8 +36,11 @@ def label_mapping(inp, mapping):
 
 class Evaluator:
     def __init__(self, state, *, num_classes=19, open_classes=0, openset=None, batch=1, label_hw=(1024, 2048),
-                 scales=((512, 1024), (640, 1280)), dtype=torch.bfloat16, device="cuda:0", layers=None):
+                 scales=((512, 1024), (640, 1280)), dtype=torch.float32, device="cuda:0", layers=None):
+        # dtype: fp32 by default -- the reference evaluates in fp32 (evaluate_cityscapes.py:96-162) and the metric is defined "argmax bit-exact";
+        # bf16 plans are an explicit, labelled opt-in (tools: --eval-dtype bf16; < 0.2 % of the arg-max positions differ)
         self.dev = torch.device(device)
+        self.dtype = dtype
         self.C = num_classes
         openset = (open_classes > 0) if openset is None else openset
         params = {k: v.detach().to(self.dev, torch.float32 if v.dtype != torch.long else torch.long).clone() for k, v in state.items()}
@@ -84,10 +87,11 @@ class Evaluator:
 
 
 def evaluate_simt(state, data_dir, data_list, gt_dir, devkit_dir="../dataset/cityscapes_list", *, num_classes=19, open_classes=0, set_name="val",
-                  device="cuda:0", dtype=torch.bfloat16, evaluator=None, rank=0, world=1, process_group=None, verbose=True, workers=4):
+                  device="cuda:0", dtype=torch.float32, evaluator=None, rank=0, world=1, process_group=None, verbose=True, workers=4):
     """File-based evaluation loop of the reference (evaluate_cityscapes.py:96-162): every validation frame at crop sizes (1024, 512) and
     (1280, 640) -> logits[:, :num_classes] of the main head, upsampled to 1024 x 2048, summed, arg-maxed -> fast_hist against the
     ground-truth label ids mapped with info.json's label2train -> mIoU (round(nanmean * 100, 2)).
+    dtype: fp32 like the reference; torch.bfloat16 is an opt-in whose mIoU is printed with a "(bf16 plans)" label.
     Host: file lists, PNG decoding (threads), the label LUT.  Device: both resizes (Pillow-exact), BGR - mean, both forwards, the fused
     upsample + sum + arg-max, the histogram.  Data parallel: ranks take strided shards of the list and the histogram is all-reduced."""
     import json
@@ -135,7 +139,7 @@ def evaluate_simt(state, data_dir, data_list, gt_dir, devkit_dir="../dataset/cit
     if verbose and rank == 0:
         for ind_class in range(num_classes):
             print("===>" + str(name_classes[ind_class]) + ":\t" + str(round(ius[ind_class] * 100, 2)))
-        print("===> mIoU: " + str(miou))
+        print("===> mIoU: " + str(miou) + ("" if ev.dtype == torch.float32 else "   (bf16 plans: not the reference's fp32 arithmetic)"))
     return miou
 
 

@@ -59,6 +59,8 @@ def get_arguments(argv=None):
     p.add_argument("--log-dir", type=str, default="./log/")
     # additions (all optional)
     p.add_argument("--compute-dtype", choices=["bf16", "f32"], default="bf16")
+    p.add_argument("--eval-dtype", choices=["f32", "bf16"], default="f32",
+                   help="arithmetic of the periodic evaluation: fp32 like the reference (evaluate_cityscapes.py:96-162); bf16 is a labelled opt-in")
     p.add_argument("--print-every", type=int, default=100)
     p.add_argument("--synthetic", action="store_true", help="synthetic Cityscapes-shaped batches")
     p.add_argument("--from-scratch", action="store_true", help="allow training from the constructor init (no --restore-from)")
@@ -93,6 +95,7 @@ def main(argv=None):
     hp = Hyper(num_classes=C, open_classes=0, lambda_seg=args.lambda_seg, lr=args.learning_rate, iter_size=args.iter_size,
                momentum=args.momentum, weight_decay=args.weight_decay, power=args.power, num_steps=args.num_steps)
     dtype = torch.bfloat16 if args.compute_dtype == "bf16" else torch.float32
+    eval_dtype = torch.bfloat16 if args.eval_dtype == "bf16" else torch.float32
     tr = WarmupTrainer(state, hp, args.batch_size, h, w, dtype=dtype, device=dev, process_group=pg)
     cd = ms.load_class_dist("bapa")
     if rank == 0:
@@ -120,11 +123,11 @@ def main(argv=None):
             # :241-256: evaluate_warmup on the validation set, keep only the best-mIoU snapshot `GTA5_BAPA_warmup_iter<i>_mIoU<m>.pth`
             from simt_amd.tools.evaluate_cityscapes import Evaluator, evaluate_warmup
             if evaluator is None:
-                evaluator = Evaluator(tr.params, num_classes=C, open_classes=0, dtype=dtype, device=dev)
+                evaluator = Evaluator(tr.params, num_classes=C, open_classes=0, dtype=eval_dtype, device=dev)
             if rank == 0:
                 print(time.strftime("%Y-%m-%d %H:%M:%S"), "  Begin evaluation on iter {0:8d}/{1:8d}  ".format(i_iter, args.num_steps))
             mIoU = evaluate_warmup(tr.params, args.data_dir_val, args.data_list_val, args.gt_dir_val, args.devkit_dir, num_classes=C,
-                                   device=dev, dtype=dtype, evaluator=evaluator, rank=rank, world=world, process_group=pg)
+                                   device=dev, dtype=eval_dtype, evaluator=evaluator, rank=rank, world=world, process_group=pg)
             if rank == 0:
                 print("Finish Evaluation: " + time.asctime(time.localtime(time.time())))
                 keeper.best(tr.state_dict(), i_iter, mIoU)

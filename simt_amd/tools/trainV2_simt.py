@@ -12,7 +12,8 @@ BGR-mean on the GPU, pinned double-buffered uploads; simt_amd/data/pipeline.py),
 it; `--synthetic` feeds Cityscapes-shaped synthetic batches instead.  Pointing --data-dir-target at a missing directory
 without --synthetic is an error (a run that silently trains on noise would still write checkpoints that look like results).
 Every --save-pred-every iterations: evaluate_simt on the validation set (--data-dir-val ...) and the best-mIoU snapshot rotation of
-trainV2_simt.py:452-464.  Additions over the reference (all optional): --synthetic, --compute-dtype, --print-every, --data-dir-val,
+trainV2_simt.py:452-464.  Additions over the reference (all optional): --synthetic, --compute-dtype, --eval-dtype (fp32 like the
+reference unless bf16 is asked for), --print-every, --data-dir-val,
 --data-list-val, --gt-dir-val, --devkit-dir.
 """
 import argparse
@@ -70,6 +71,8 @@ def get_arguments(argv=None):
     # additions
     p.add_argument("--synthetic", action="store_true", help="synthetic Cityscapes-shaped batches")
     p.add_argument("--compute-dtype", choices=["bf16", "f32"], default="bf16")
+    p.add_argument("--eval-dtype", choices=["f32", "bf16"], default="f32",
+                   help="arithmetic of the periodic evaluation: fp32 like the reference (evaluate_cityscapes.py:96-162); bf16 is a labelled opt-in")
     p.add_argument("--print-every", type=int, default=100)
     p.add_argument("--data-dir-val", type=str, default="", help="Cityscapes root for the in-loop evaluation (evaluate_cityscapes.py:26)")
     p.add_argument("--data-list-val", type=str, default="../dataset/cityscapes_list/val.txt")
@@ -183,6 +186,7 @@ def main(argv=None):
                lr=args.learning_rate, lr_T=args.learning_rate_T, momentum=args.momentum,
                weight_decay=args.weight_decay, power=args.power, num_steps=args.num_steps)
     dtype = torch.bfloat16 if args.compute_dtype == "bf16" else torch.float32
+    eval_dtype = torch.bfloat16 if args.eval_dtype == "bf16" else torch.float32
     tr = SimTTrainer(state, fixed, ms.ntm_init(C, K, args.random_seed + 1), ms.ntm_init(C, K, args.random_seed + 2), hp, cd,
                      args.batch_size, h, w, dtype=dtype, device=dev, process_group=pg)
     if rank == 0:
@@ -213,11 +217,11 @@ def main(argv=None):
             # :452-464: evaluate, keep only the best-mIoU snapshot
             from simt_amd.tools.evaluate_cityscapes import Evaluator, evaluate_simt
             if evaluator is None:
-                evaluator = Evaluator(tr.params, num_classes=C, open_classes=K, dtype=dtype, device=dev)
+                evaluator = Evaluator(tr.params, num_classes=C, open_classes=K, dtype=eval_dtype, device=dev)
             if rank == 0:
                 print(time.strftime("%Y-%m-%d %H:%M:%S"), "  Begin evaluation on iter {0:8d}/{1:8d}  ".format(i_iter, args.num_steps))
             mIoU = evaluate_simt(tr.params, args.data_dir_val, args.data_list_val, args.gt_dir_val, args.devkit_dir, num_classes=C,
-                                 open_classes=K, device=dev, dtype=dtype, evaluator=evaluator, rank=rank, world=world, process_group=pg)
+                                 open_classes=K, device=dev, dtype=eval_dtype, evaluator=evaluator, rank=rank, world=world, process_group=pg)
             if rank == 0:
                 print("Finish Evaluation: " + time.asctime(time.localtime(time.time())))
                 keeper.best(tr.state_dict(), i_iter, mIoU)

@@ -160,3 +160,71 @@ def test_upsample_sum_argmax_at_cityscapes_resolution(dev):
     hist = torch.zeros(C * C, device=dev, dtype=torch.int64)
     L.call("simt_confusion_hist", ops._p(gt.to(dev)), ops._p(pred), gt.numel(), C, ops._p(hist), ops.stream_ptr())
     assert np.array_equal(hist.cpu().numpy().reshape(C, C), fast_hist(gt.numpy().flatten(), got.flatten().astype(np.int64), C))
+
+
+def test_evaluator_full_depth_r101_fp32_at_reference_geometry(dev):
+    """the metric north_star names ("mIoU/argmax bit-exact"), end to end, at FULL depth and at the reference's geometry
+    (evaluate_cityscapes.py:96-162): ResNet-101 two-head model with open-set heads, one frame at 1024 x 512 and 1280 x 640 -> logits[:, :19]
+    upsampled to 1024 x 2048, summed, arg-maxed -> fast_hist -> mIoU; the DEFAULT Evaluator (fp32 plans) against the oracle's forward x 2 +
+    numpy arg-max on the CPU.  Weights: the checkpoint-like recipe (ms.trained_like_init, head_scale 8) with BatchNorm running statistics
+    calibrated by train-mode forwards of the HIP trunk and handed to BOTH sides (with uncalibrated statistics 101 eval-mode layers collapse the
+    features and every pixel gets the same label: a vacuous comparison).  Bar: labels equal wherever the oracle's own top-2 gap of the summed
+    logits exceeds 1e-4 of max|summed logit| (the fp32 conv parity error through 101 layers is ~3e-5 of it); < 0.5 % of the pixels exempt;
+    the device histogram equals fast_hist of the device labels; mIoU (2 decimals) equals the oracle's within one unit of the last decimal."""
+    from simt_amd import model_spec as ms
+    from simt_amd.engine import TrunkPlan, multi_heads
+    K = 3
+    cd = ms.load_class_dist("bapa")
+    st = ms.trained_like_init(ms.state_shapes(19, K, True), seed=1234)
+    p = {k: v.clone().to(dev) for k, v in st.items()}
+    cal = TrunkPlan(p, 1, 384, 768, multi_heads(19, K, True), dtype=torch.float32, train=True)
+    img_c, _ = ms.synthetic_batch(1, 384, 768, cd, seed=99, device=dev)
+    cal.x_in.copy_(img_c)
+    for _ in range(40):
+        cal.fwd_list.run()
+    torch.cuda.synchronize()
+    for k in st:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            st[k] = p[k].detach().cpu().clone()
+    del cal, p
+    torch.cuda.empty_cache()
+    H, W = 1024, 2048
+    s1, s2 = (512, 1024), (640, 1280)
+    # a frame with structure at every scale (piecewise-constant blocks + noise, BGR - mean range), resized like the loader does (bilinear
+    # stands in for the bicubic resize: both sides get the identical tensors)
+    g = torch.Generator().manual_seed(77)
+    base = torch.randn(1, 3, 32, 64, generator=g) * 60
+    full = F.interpolate(base, size=(H, W), mode="nearest") + torch.randn(1, 3, H, W, generator=g) * 12
+    img1 = F.interpolate(full, size=s1, mode="bilinear", align_corners=False).contiguous()
+    img2 = F.interpolate(full, size=s2, mode="bilinear", align_corners=False).contiguous()
+    gt = torch.randint(0, 19, (1, H, W), generator=g)
+    gt[torch.rand(1, H, W, generator=g) < 0.1] = 255
+    ev = Evaluator(st, num_classes=19, open_classes=K, device=dev)             # every default: fp32 plans, the reference's geometry
+    assert ev.dtype == torch.float32 and (ev.H, ev.W) == (H, W)
+    ev.add(img1, img2, gt)
+    miou, ius = ev.result()
+    got = ev.pred.cpu().numpy()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 8)))
+    with torch.no_grad():
+        _, o1 = so.deeplab_multi_forward(st, img1, False, True)
+        _, o2 = so.deeplab_multi_forward(st, img2, False, True)
+        out = (F.interpolate(o1[:, :19], size=(H, W), mode="bilinear", align_corners=True) +
+               F.interpolate(o2[:, :19], size=(H, W), mode="bilinear", align_corners=True))
+        top2 = out.topk(2, dim=1)
+    pred = top2.indices[:, 0].numpy()
+    gap = (top2.values[:, 0] - top2.values[:, 1]).numpy()
+    margin = 1e-4 * float(out.abs().max())
+    diff = got != pred
+    nlab = len(np.unique(pred))
+    print(f"full-depth fp32 evaluator: {int(diff.sum())} of {diff.size} labels differ; {int((gap < margin).sum())} pixels with a top-2 gap below "
+          f"{margin:.2e}; {nlab} distinct labels in the oracle's map")
+    assert nlab >= 4, "degenerate label map: the comparison would be vacuous"
+    assert not np.any(diff & (gap >= margin)), f"{int((diff & (gap >= margin)).sum())} labels differ outside the rounding margin"
+    assert (gap < margin).mean() < 5e-3
+    h = fast_hist(gt.numpy().flatten(), got.flatten().astype(np.int64), 19)
+    assert np.array_equal(ev.hist.cpu().numpy().reshape(19, 19), h)
+    assert miou == round(float(np.nanmean(per_class_iu(h))) * 100, 2)
+    h_ref = fast_hist(gt.numpy().flatten(), pred.flatten().astype(np.int64), 19)
+    miou_ref = round(float(np.nanmean(per_class_iu(h_ref))) * 100, 2)
+    print(f"mIoU: device {miou}, oracle {miou_ref}")
+    assert abs(miou - miou_ref) <= 0.011
