@@ -228,8 +228,14 @@ def main():
     # SIMT_DP_FORCE=1 under a one-rank torchrun: the data-parallel job over a REAL one-rank RCCL group (functional test of the N > 1 path -- process
     # group, barrier, bucketed all-reduce, comm report -- on a 1-GPU box; never a measurement: the exchange is the identity)
     dp_job = world > 1 or (os.environ.get("SIMT_DP_FORCE") == "1" and "RANK" in os.environ)
+    # the plan's two streams take their hardware queues before anything else makes streams (RCCL / ProcessGroupNCCL do): engine.reserve_streams
+    from simt_amd.engine import reserve_streams
+    reserve_streams(dev)
     if dp_job:
         import torch.distributed as dist
+        # The conv tile lists of a data-parallel plan leave 20 of the 256 CUs free (236 one-per-CU workgroups: engine.TrunkPlan.cu_budget); RCCL is
+        # told to stay inside that margin unless the user says otherwise (must be set before the communicator exists)
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:

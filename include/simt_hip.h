@@ -28,11 +28,19 @@ enum { SIMT_F32 = 0, SIMT_BF16 = 1 };
 const char* simt_last_error(void);
 /* Device-scope events for ordering two HIP streams of ONE device (the launch lists of simt_amd/engine.py): like hipEventCreateWithFlags /
  * hipEventRecord / hipStreamWaitEvent (which torch.cuda.Event wraps), but recorded with a device-scope release instead of the default
- * system-scope fence (system_scope = 0) -- the host never inspects them.  Replaces torch.cuda.Event().record() / stream.wait_event(). */
-int simt_event_create(void** ev, int system_scope);
+ * system-scope fence -- the host never inspects them.  Replaces torch.cuda.Event().record() / stream.wait_event().  `scope`:
+ *   0  hipEventDisableTiming | hipEventReleaseToDevice      the DOCUMENTED device-scope release (default of the launch lists since ABI 2)
+ *   1  hipEventDisableTiming                                system-scope release (what torch.cuda.Event does)
+ *   2  hipEventDisableTiming | hipEventDisableSystemFence   no release at the marker at all: ordering rests on the producing kernels' own
+ *      end-of-kernel agent-scope release (round 5's form; explicit opt-in, SIMT_EVENT_SCOPE=2) */
+int simt_event_create(void** ev, int scope);
 int simt_event_destroy(void* ev);
 int simt_event_record(void* ev, simt_stream_t stream);
 int simt_stream_wait_event(simt_stream_t stream, void* ev);
+/* 2 since round 6: simt_sgd_desc.skip_if, simt_fbn_desc.err, simt_ntm_inner_desc.skip_if (trailing pointers the library dereferences),
+ * simt_adam_step_guarded, simt_event_create's scope values, simt_conv_desc.cu_budget / in_scale / in_shift / in_out.  A caller built against an older header passes
+ * shorter structs: check the version before the first call (simt_amd/_lib.py does). */
+#define SIMT_ABI_VERSION 2
 int simt_abi_version(void);
 
 /* ---- convolution: fprop / dgrad (implicit GEMM, MFMA) --------------------------------------------------
@@ -77,6 +85,20 @@ typedef struct {
                         * bf16 kernel loads its weight operand straight into registers (1 KB contiguous per wave-instruction)
                         * instead of staging it through LDS; results are bit-identical either way */
   const struct simt_fbn_desc* fbn;   /* optional (may be NULL): the train-mode BatchNorm behind this conv fused into the launch, below */
+  int32_t cu_budget;   /* ABI 2.  Compute units this launch may plan for; 0 = all of the device (256).  Data-parallel plans pass 256 minus the
+                        * CUs the collective's persistent kernels hold (NCCL_MAX_NCHANNELS): the one-workgroup-per-CU tile lists of the wide convs
+                        * are planned for that many CUs (M = 37 636: 236 tiles of 160 rows for any budget >= 236 -- the default plan already leaves
+                        * 20 CUs free; a smaller budget re-plans).  Changes only the pixel rows per tile: every output element is bit-identical across budgets; the per-tile
+                        * BatchNorm partial sums (stats / bnr_part: one slot per tile) regroup, i.e. their fp32 rounding may differ in the last bit. */
+  int32_t reserved_;
+  /* ABI 2.  BatchNorm + ReLU of the INPUT applied in the operand path (round 6; model/deeplab_multi.py:88-92: out = relu(bn2(conv2)), conv3(out)).
+   * When in_scale != NULL the launch reads x as the RAW pre-BatchNorm activation y2, uses a = relu(x * in_scale[c] + in_shift[c]) (rounded to
+   * bf16, bitwise what simt_bn_apply writes) as its operand and ALSO writes a to in_out [B*H*W][Cin] (the weight gradient of this conv and
+   * the BatchNorm backward read it later) -- the separate simt_bn_apply launch and its re-read of y2 disappear.  Only launches for which
+   * simt_conv_inbn_ok(d) != 0 (the row-streaming 1x1 kernel on Cin in {64, 128, 256} with BatchNorm statistics: a Bottleneck's conv3 in the
+   * training forward) accept it; everywhere else the fields must be NULL. */
+  const float *in_scale, *in_shift;
+  void* in_out;
 } simt_conv_desc;
 /* Train-mode BatchNorm2d (frozen affine; model/deeplab_multi.py:63-70,81-91) fused into the PRODUCING conv launch -- round 4.  For a
  * launch whose workgroups are all co-resident (one round of the chip: simt_conv_fbn_ok), the pixel tile stays in LDS after the epilogue;
@@ -88,10 +110,13 @@ typedef struct {
  * (d->stats / d->bnr_part themselves are not written in fused launches.)  Only a launch on the stream that owns the plan may wait like
  * this: kernels of the other streams (frozen forward, weight gradients) never wait on anything, so the co-residency the polling needs
  * always resolves.  A workgroup that has polled for ~2 s (another process's waiting launch on the same GPU, persistent collective kernels holding
- * CUs) does NOT trap: it sets the sticky error word (`err`, or work[SIMT_FBN_ERR_WORD]), every other poller of the launch sees it and the launch ends
- * without writing `out`; later fused launches that share the word bail out at their first failed poll.  The caller reads the word (simt_amd:
- * TrunkPlan.fbn_error(), raised by losses()) and rebuilds the plan with the two-pass BatchNorm; an optimiser step given the same word
- * (simt_sgd_desc.skip_if) leaves the weights untouched.  `work` belongs to ONE BatchNorm and direction: its ticket counters only ever grow and
+ * CUs) does NOT trap: it sets the sticky error word (`err`, or work[SIMT_FBN_ERR_WORD]), every other poller of the launch sees it and the launch ends;
+ * later fused launches that share the word bail out at their first failed poll.  What such a launch guarantees: a poller that gave up writes
+ * nothing derived from its incomplete reads -- no constants, no mean / rstd / scale / shift / coef / d gamma / d beta, NO running-statistics
+ * update, not its rows of `out` (workgroups whose polls had completed wrote theirs from complete sums: `out` is PARTIALLY written and must be
+ * treated as undefined).  The caller reads the word (simt_amd: TrunkPlan.fbn_error(), raised by losses()) and rebuilds the plan with the
+ * two-pass BatchNorm; the optimiser launches given the same word (simt_sgd_desc.skip_if, simt_adam_step_guarded) leave weights, momentum
+ * buffers and Adam moments untouched while it is set.  `work` belongs to ONE BatchNorm and direction: its ticket counters only ever grow and
  * give every launch its generation = the granules' tag. */
 #define SIMT_FBN_BAR_WORDS 144            /* uint64 words at the head of `work`: 8 ticket counters, one 128-byte line each (+ spare) */
 #define SIMT_FBN_ERR_WORD 136             /* spare word of the head used as the error word when simt_fbn_desc.err is NULL */
@@ -139,6 +164,7 @@ int simt_conv_variant(const simt_conv_desc* d, int* bn, int* tm, int* nst);
 int simt_conv_epilogue_flavour(const simt_conv_desc* d);
 /* number of pixel tiles (= statistics / bnr_part slots) the launch for d uses; 0 if d does not run on the bf16 v2 kernel */
 int simt_conv_mtiles(const simt_conv_desc* d);
+int simt_conv_inbn_ok(const simt_conv_desc* d);        /* ABI 2: may d carry in_scale / in_shift / in_out (see simt_conv_desc)? */
 
 /* ---- convolution: wgrad (split-K over pixels, transposed MFMA operands) -------------------------------
  * slab[split][co][tap*Cin+ci] = sum_{m in split} dy[m][co] * x[pixel(m)*stride + (dy,dx)[tap]][ci]
@@ -313,6 +339,7 @@ typedef struct {
   int32_t Q, C, steps, step0; /* step0 = Adam steps already taken on w */
   float lr, beta1, beta2, eps;
   int32_t single;       /* 1: only NTM / W number 1 (index [1]) exist -- one-output models; index [0] pointers may be NULL */
+  const uint64_t* skip_if;   /* ABI 2.  Optional device word (simt_fbn_desc.err): the launch changes nothing while it is non-zero; NULL: always run */
 } simt_ntm_inner_desc;
 int simt_ntm_inner_loop(const simt_ntm_inner_desc* d, simt_stream_t stream);
 typedef struct {
@@ -333,6 +360,9 @@ int simt_sig_ntm(const float* ntm, const float* class_dist, const float* dT, flo
 int simt_sig_w(float* weight, const float* dW, float* W_out, float* dweight_out, int Q, simt_stream_t stream);
 int simt_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                    int step, simt_stream_t stream);
+/* ABI 2: the same step, skipped (parameter AND moments untouched) while *skip_if != 0 -- the guard simt_sgd_desc.skip_if gives the SGD launch */
+int simt_adam_step_guarded(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                           int step, const uint64_t* skip_if, simt_stream_t stream);
 
 /* ---- fused SGD with duplicate-listing semantics (tools/trainV2_simt.py:296-297,434; model/deeplab_multi.py:194-237) --- */
 typedef struct {

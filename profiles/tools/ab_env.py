@@ -31,12 +31,24 @@ def main():
     fst = ms.reference_init(ms.state_shapes(19, 0, False), seed=1234)
     H, W = a.size
 
+    pg = [None]
+
     def make(env):
+        env = dict(env)
+        dp = env.pop("DP", "0") == "1"          # pseudo-variable (round 6): the data-parallel trainer over a REAL one-rank RCCL group (SIMT_DP_FORCE=1)
+        if dp and pg[0] is None:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29573")
+            os.environ["SIMT_DP_FORCE"] = "1"
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            pg[0] = dist.group.WORLD
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
             return SimTTrainer(st, fst, ms.ntm_init(19, K, 1), ms.ntm_init(19, K, 2), Hyper(open_classes=K, lr=2.5e-4, lr_T=6e-3), cd,
-                               a.batch, H, W, dtype=torch.bfloat16, device=dev)
+                               a.batch, H, W, dtype=torch.bfloat16, device=dev, process_group=pg[0] if dp else None)
         finally:
             for k, v in old.items():
                 if v is None:

@@ -45,7 +45,9 @@ for (Cin, Cout, k, dil) in ((256, 256, 3, 2), (1024, 256, 1, 1)):
         assert getattr(lib, which)(out, nb) == 0
         v = np.array(out, dtype=np.int64).reshape(nb, 8)
         clocks = v[:, 6] - v[:, 0]
-        return clocks, clocks / (v[:, 7] * 10e-9) / 1e6, v[:, 3] - v[:, 2]
+        rt = (C.c_uint64 * nb)()                       # s_memrealtime ticks between stamps 0 and 6 (their own array since round 6)
+        assert getattr(lib, which + "_rt")(rt, nb) == 0
+        return clocks, clocks / (np.array(rt, dtype=np.int64) * 10e-9) / 1e6, v[:, 3] - v[:, 2]
     clocks, mhz, loop = stamps()
     # the same launch after 20 ms of idle GPU (nothing to throttle for): what the kernel takes when the chip grants the nominal clock
     import time

@@ -23,10 +23,13 @@ def make(Cin, Cout, epi):
                      "scale": torch.rand(Cout, device=dev) + 0.5, "shift": torch.randn(Cout, device=dev) * 0.3,
                      "bits": torch.randint(0, 256, (M, Cout // 8), dtype=torch.uint8, device=dev), "mode": 3, "part": torch.zeros(M // 128 + 2, 3, Cout, device=dev)}
     d = ops.make_conv_desc(x.view(B, H, W, Cin), wp, y, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=Cout, taps=[(0, 0)], Npad=npad, tile_n=256, **kw)
+    if "inbn" in epi:            # round 6: BatchNorm + ReLU of the input in the operand path (simt_conv_desc.in_*)
+        kw["in"] = (torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.3, torch.empty(M, Cin, device=dev, dtype=BF))
+        d.in_scale, d.in_shift, d.in_out = (t.data_ptr() for t in kw["in"])
     return d, (x, wp, y, kw)
 st = torch.cuda.current_stream().cuda_stream
 flush = torch.empty(1 << 28, device=dev, dtype=torch.uint8)
-for (Cin, Cout, epi) in ((256, 1024, "stats"), (256, 1024, "bias res"), (256, 1024, "res rbits bnr3")):
+for (Cin, Cout, epi) in ((256, 1024, "stats"), (256, 1024, "stats inbn"), (256, 1024, "bias res"), (256, 1024, "res rbits bnr3")):
     d, keep = make(Cin, Cout, epi)
     for _ in range(2):
         flush.zero_(); torch.cuda.synchronize()

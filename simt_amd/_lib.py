@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("SIMT_LIB_PATH") or os.path.join(_HERE, "libsimt_hip.s
 
 SIMT_F32, SIMT_BF16 = 0, 1
 MAX_TAPS = 36
+ABI_VERSION = 2          # include/simt_hip.h SIMT_ABI_VERSION
 QMAX = 40
 
 c_p = C.c_void_p
@@ -25,7 +26,8 @@ class ConvDesc(C.Structure):
                 ("relu", i32), ("dtype_in", i32), ("dtype_out", i32), ("tile_n", i32),
                 ("dy", C.c_int16 * MAX_TAPS), ("dx", C.c_int16 * MAX_TAPS), ("mask", c_p), ("ldm", i32),
                 ("res_bits", c_p), ("bnr_y", c_p), ("bnr_mean", c_p), ("bnr_rstd", c_p), ("bnr_scale", c_p), ("bnr_shift", c_p),
-                ("bnr_bits", c_p), ("bnr_part", c_p), ("bnr_mode", i32), ("bnr_ld", i32), ("w_frag", c_p), ("fbn", c_p)]
+                ("bnr_bits", c_p), ("bnr_part", c_p), ("bnr_mode", i32), ("bnr_ld", i32), ("w_frag", c_p), ("fbn", c_p),
+                ("cu_budget", i32), ("reserved_", i32), ("in_scale", c_p), ("in_shift", c_p), ("in_out", c_p)]
 
 
 FBN_BAR_WORDS = 144
@@ -74,7 +76,7 @@ class NtmInnerDesc(C.Structure):
     _fields_ = [("ntm", c_p * 2), ("w", c_p * 2), ("ntm_grad", c_p * 2), ("w_m", c_p * 2), ("w_v", c_p * 2),
                 ("T_out", c_p * 2), ("class_dist", c_p),
                 ("Q", i32), ("C", i32), ("steps", i32), ("step0", i32),
-                ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("single", i32)]
+                ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("single", i32), ("skip_if", c_p)]
 
 
 class NtmPostDesc(C.Structure):
@@ -103,6 +105,7 @@ SIGNATURES = {
     "simt_abi_version": (_I, []),
     "simt_conv_fprop": (_I, [C.POINTER(ConvDesc), c_p]),
     "simt_conv_mtiles": (_I, [C.POINTER(ConvDesc)]),
+    "simt_conv_inbn_ok": (_I, [C.POINTER(ConvDesc)]),
     "simt_conv_fprop_pair": (_I, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), c_p]),
     "simt_conv_pair_fused": (_I, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     "simt_conv_fbn_ok": (_I, [C.POINTER(ConvDesc)]),
@@ -147,6 +150,7 @@ SIGNATURES = {
     "simt_sig_ntm": (_I, [c_p, c_p, c_p, c_p, c_p, _I, _I, c_p]),
     "simt_sig_w": (_I, [c_p, c_p, c_p, c_p, _I, c_p]),
     "simt_adam_step": (_I, [c_p, c_p, c_p, c_p, _L, f32, f32, f32, f32, _I, c_p]),
+    "simt_adam_step_guarded": (_I, [c_p, c_p, c_p, c_p, _L, f32, f32, f32, f32, _I, c_p, c_p]),
     "simt_sgd_multi": (_I, [C.POINTER(SgdDesc), c_p]),
     "simt_event_create": (_I, [C.POINTER(c_p), _I]),
     "simt_event_destroy": (_I, [c_p]),
@@ -195,6 +199,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.simt_abi_version() != ABI_VERSION:      # a stale libsimt_hip.so reads past the end of the shorter descriptors it was built for
+        raise SimtHipError(f"{LIB_PATH} has ABI version {lib.simt_abi_version()}, these bindings need {ABI_VERSION}: rebuild it "
+                           "(python -c 'import __graft_entry__ as g; g.build()')")
     _lib = lib
     return lib
 

@@ -11,19 +11,21 @@ void simt_set_error(const char* file, int line, const char* msg) {
 }
 
 extern "C" const char* simt_last_error(void) { return g_err; }
-extern "C" int simt_abi_version(void) { return 1; }
+extern "C" int simt_abi_version(void) { return SIMT_ABI_VERSION; }
 
 // ---- device-scope events (round 5).  The launch lists order their two HIP streams with events (weight gradients behind the dgrad chain,
 // BatchNorm passes beside the frozen model's convs).  A default hipEvent performs a SYSTEM-scope release when it is recorded -- write-back
 // and invalidation of the caches so that the host could read the data -- and the stream's next kernel waits for it: ~6.5 us of idle queue
 // behind every record, ~12 us for a cross-stream wait (rocprofv3 kernel trace, profiles/r05_conv_attribution.txt section 6).  Both streams of a plan live on
-// one device: hipEventDisableTiming | hipEventReleaseToDevice | hipEventDisableSystemFence is all the ordering they need.
-extern "C" int simt_event_create(void** ev, int system_scope) {
-  SIMT_CHECK(ev);
+// one device: a device-scope release is all the ordering they need.  scope 0 (default): hipEventReleaseToDevice, the documented device-scope
+// release; scope 2: hipEventDisableSystemFence, which drops the release from the marker altogether (the edge then rests on the producing kernel's
+// own end-of-kernel agent-scope release -- undocumented runtime behaviour, explicit opt-in); scope 1: the default system-scope event.  (The
+// runtime accepts ONE of the two flags: both together are rejected.)
+extern "C" int simt_event_create(void** ev, int scope) {
+  SIMT_CHECK(ev && scope >= 0 && scope <= 2);
   hipEvent_t e;
-  // (the runtime accepts ONE of the release flags: hipEventReleaseToDevice together with hipEventDisableSystemFence is rejected)
-  hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming | (system_scope ? 0u : hipEventDisableSystemFence));
-  if (err != hipSuccess && !system_scope) { (void)hipGetLastError(); err = hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice); }
+  const unsigned fl = hipEventDisableTiming | (scope == 0 ? hipEventReleaseToDevice : scope == 2 ? hipEventDisableSystemFence : 0u);
+  hipError_t err = hipEventCreateWithFlags(&e, fl);
   if (err != hipSuccess) { (void)hipGetLastError(); simt_set_error(__FILE__, __LINE__, "hipEventCreateWithFlags"); return SIMT_ERR_LAUNCH; }
   *ev = (void*)e;
   return SIMT_OK;

@@ -82,7 +82,11 @@ __device__ __forceinline__ void unpack8(const uint4& q, float* v) {
 }
 
 struct Aux { uint4 res, by; unsigned rbits, ybits; };
-enum { FL_GEN = 0, FL_GEN_AUX = 1, FL_STATS = 2, FL_BRR = 3, FL_BNR = 4 };
+// FL_STATS_INBN (round 6): FL_STATS whose INPUT is the raw pre-BatchNorm activation of the previous conv (simt_conv_desc.in_scale / in_shift /
+// in_out): the store waves normalise + ReLU every landed stage IN PLACE in its ring slot one stage period before the compute waves multiply it,
+// and write the activation out on the way (each of the ntiles_n workgroups that share a pixel row writes 1 / ntiles_n of it) -- the separate
+// simt_bn_apply launch between conv2 and conv3 of a Bottleneck (model/deeplab_multi.py:88-92) and its 19-MB re-read disappear.
+enum { FL_GEN = 0, FL_GEN_AUX = 1, FL_STATS = 2, FL_BRR = 3, FL_BNR = 4, FL_STATS_INBN = 5 };
 
 template <int KS, int TM, int D, int FL, int NSW, int NCW, int TN>
 __device__ __forceinline__ void conv1x1_rows_body(const Conv2KArgs& a, const int G, const int bid) {
@@ -111,11 +115,14 @@ __device__ __forceinline__ void conv1x1_rows_body(const Conv2KArgs& a, const int
   // reads per 16 channels and 32 pixels instead of 3 VALU per element (measured 39.0 us on 256 -> 1024).  1 (default): the compute waves (VALU behind their MFMAs, DPP
   // reduce; 39.7 us).  0: the store waves' VALU (register sums, row groups through sR; 39.7-41 us).  The stage time is set by the barrier-
   // coupled pair of chains (HBM write back-pressure on the store waves, MFMA + epilogue on the compute waves), not by where these sums run.
-  constexpr bool CSTAT = FL == FL_STATS && SIMT_ROWS_CSTAT == 1;
-  constexpr bool MSTAT = FL == FL_STATS && SIMT_ROWS_CSTAT == 2;
+  constexpr bool INBN = FL == FL_STATS_INBN;
+  constexpr bool STATS = FL == FL_STATS || INBN;
+  static_assert(!INBN || (D >= 4 && SIMT_ROWS_CSTAT == 1), "the in-place input BatchNorm needs a stage landed one period early and the compute-wave statistics");
+  constexpr bool CSTAT = STATS && SIMT_ROWS_CSTAT == 1;
+  constexpr bool MSTAT = STATS && SIMT_ROWS_CSTAT == 2;
   const bool has_bias = GEN ? a.bias != nullptr : FL == FL_BRR;
   const bool has_relu = GEN ? a.relu != 0 : FL == FL_BRR;
-  const bool has_stats = GEN ? a.stats != nullptr : (FL == FL_STATS && SIMT_ROWS_CSTAT == 0);      // statistics taken by the store waves (FL_STATS: by the compute waves)
+  const bool has_stats = GEN ? a.stats != nullptr : (STATS && SIMT_ROWS_CSTAT == 0);      // statistics taken by the store waves (FL_STATS: by the compute waves)
   const bool has_res = GEN ? (AUX && a.res != nullptr) : AUX;
   const bool has_rbits = GEN ? (AUX && a.res_bits != nullptr) : FL == FL_BNR;
   const bool has_bnr = GEN ? (AUX && a.bnr_mode != 0) : FL == FL_BNR;
@@ -298,11 +305,19 @@ __device__ __forceinline__ void conv1x1_rows_body(const Conv2KArgs& a, const int
 #pragma unroll
         for (int i = 0; i < TM; ++i) prev[j][i] = acc[j][i];
     };
+    if (INBN) {
+      // stage 0 must be normalised by the store waves BEFORE period 0 multiplies it: one extra hand-over (landed -> barrier -> their period)
+      if (D - 2 < S_total) wait_vmcnt<g::PT * (D - 2)>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
     for (int gi = 0; gi <= S_total; ++gi) {
 #ifdef SIMT_ABLATION
       const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
 #endif
-      if (gi + D - 2 < S_total) wait_vmcnt<g::PT * (D - 2)>(); else wait_vmcnt<0>();     // stage gi landed (this wave's pieces)
+      // stage gi landed (this wave's pieces); INBN: stage gi + 1 -- the store waves normalise it during period gi
+      if (INBN) { if (gi + D - 2 < S_total) wait_vmcnt<g::PT * (D - 3)>(); else wait_vmcnt<0>(); }
+      else if (gi + D - 2 < S_total) wait_vmcnt<g::PT * (D - 2)>(); else wait_vmcnt<0>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  // this wave's slab writes (stage gi - 2)
 #ifdef SIMT_ABLATION
       const unsigned long long tw1 = __builtin_amdgcn_s_memtime();
@@ -451,8 +466,69 @@ __device__ __forceinline__ void conv1x1_rows_body(const Conv2KArgs& a, const int
   const unsigned tr_lane = (unsigned)(((lane >> 4) * 8 + ((lane & 15) >> 2)) * CP + (lane & 3) * 8);
   uint4 ov[g::PASSES];                                         // PIPE: the rows of the slab to be stored, read during the previous stage
   const int LAST = PIPE ? S_total + 1 : S_total;
+  // ---- INBN: BatchNorm + ReLU of the landed input stage, in place in its ring slot (store thread st owns the linear 16-byte pieces
+  // q * NS + st of a stage: row (p >> 3) % RS, 64-channel sub-tile p / (RS * 8), chunk (p & 7) ^ ((row >> 1) & 7) -- the compute waves' LDS-DMA layout)
+  constexpr int PTS = INBN ? g::SB / 16 / NS : 1;               // pieces per store thread and stage
+  float isc[PTS][8], ish[PTS][8];
+  unsigned t_loff[PTS], t_goff[PTS];                           // piece's byte offset in the slot / in the activation (row pitch CIN * 2)
+  int t_row[PTS];
+  bool t_mine[PTS];                                            // the 1 / ntiles_n share of the activation this workgroup writes out
+  if (INBN) {
+#pragma unroll
+    for (int q = 0; q < PTS; ++q) {
+      const int p = q * NS + st;
+      const int row = (p >> 3) % g::RS, kc = p / (g::RS * 8), cg = (p & 7) ^ ((row >> 1) & 7);
+      const int ch = kc * 64 + cg * 8;
+      t_loff[q] = (unsigned)p * 16u;
+      t_row[q] = row;
+      t_goff[q] = (unsigned)row * (unsigned)(g::CIN * 2) + (unsigned)ch * 2u;
+      t_mine[q] = (q * a.ntiles_n) / PTS == nt;                 // (host: PTS % ntiles_n == 0)
+      load8(a.in_scale + ch, isc[q]);
+      load8(a.in_shift + ch, ish[q]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { asm volatile("" : "+v"(isc[q][e])); asm volatile("" : "+v"(ish[q][e])); }      // (waits pinned here, like bias8)
+    }
+  }
+  int t_is = 0, t_ci = 0;                                      // cursor of the next stage to normalise: stage inside its tile, tile of this workgroup
+  auto in_bn = [&](int s) {                                    // stage s (landed: the compute waves waited for it before the barrier just passed)
+    if (!INBN || s >= S_total) return;
+    const int srow0 = (mt0 + t_ci * mt_step) * 128 + t_is * g::RS;
+    if (++t_is == g::SPT) { t_is = 0; ++t_ci; }
+    const unsigned slot = (unsigned)(size_t)LPTR(smem + (s % D) * g::SB);
+    const bool full = srow0 + g::RS <= a.M;                    // uniform; rows past the end stay the zero page's zeros (they add nothing to the statistics)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // (a native vector: HIP's uint4 is a struct, which an asm "v" operand cannot be)
+    u32x4 xin[PTS];
+#pragma unroll
+    for (int q = 0; q < PTS; ++q) asm volatile("ds_read_b128 %0, %1" : "=v"(xin[q]) : "v"(slot + t_loff[q]));
+#pragma unroll
+    for (int q = 0; q < PTS; ++q) {
+      // (asm loads, asm wait tied to the registers: the compiler's waitcnt insertion does not see asm operands -- DESIGN.md 5b "a measured trap")
+      if (q == 0) {
+        if constexpr (PTS == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xin[0]));
+        else if constexpr (PTS == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xin[0]), "+v"(xin[PTS - 1]));
+        else if constexpr (PTS == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xin[0]), "+v"(xin[1]), "+v"(xin[PTS - 2]), "+v"(xin[PTS - 1]));
+      }
+      if (!full && srow0 + t_row[q] >= a.M) continue;
+      float v[8];
+      unpack8(make_uint4(xin[q][0], xin[q][1], xin[q][2], xin[q][3]), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * isc[q][e] + ish[q][e];           // simt_bn_apply's expression (same contraction: bitwise its output)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      asm volatile("ds_write_b128 %0, %1" :: "v"(slot + t_loff[q]), "v"(o) : "memory");
+      if (t_mine[q]) st_out16((char*)a.in_out + (size_t)srow0 * (size_t)(g::CIN * 2) + t_goff[q], make_uint4(o[0], o[1], o[2], o[3]));
+    }
+  };
+  static_assert(!INBN || PTS == 1 || PTS == 2 || PTS == 4, "in_bn's wait names one, two or four pieces");
+  if (INBN) {
+    __builtin_amdgcn_s_barrier();                              // the compute waves' preamble barrier: stage 0 landed
+    in_bn(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();                                // the compute waves' barrier 0: they write the slab of stage g - 1 during stage g,
                                                                // so "barrier gi" below is their barrier gi + 1
+  in_bn(1);                                                    // period 0 (stage 1 landed before barrier 0)
   for (int gi = 0; gi <= LAST; ++gi) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // slab reads / sR writes of the previous iteration
 #ifdef SIMT_ABLATION
@@ -468,7 +544,7 @@ __device__ __forceinline__ void conv1x1_rows_body(const Conv2KArgs& a, const int
 #ifdef SIMT_ABLATION
     ts_prev = tb1;
 #endif
-    if (gi == 0 || (SIMT_ROWS_ABL & 8)) continue;
+    if (gi == 0 || (SIMT_ROWS_ABL & 8)) { in_bn(gi + 2); continue; }
     const char* sl = slab + ((gi - 1) & 1) * g::SLAB;
     if (PIPE) {
       const bool guard_cur = !(all_cols && row0 + g::RS <= a.M);
@@ -497,6 +573,7 @@ __device__ __forceinline__ void conv1x1_rows_body(const Conv2KArgs& a, const int
       if (gi <= S_total) {                                     // slab gi - 1: LDS -> registers (in flight during the statistics below)
 #pragma unroll
         for (int p = 0; p < g::PASSES; ++p) nv[p] = *(const uint4*)(sl + (rg + p * RGS) * CP + vcol * 2);
+        in_bn(gi + 2);                                         // INBN: the stage the compute waves multiply NEXT period (behind the output stores: they block on HBM)
         if (MSTAT) {
           const unsigned sl_a = (unsigned)(size_t)LPTR(sl) + tr_lane;
 #pragma unroll
@@ -727,10 +804,21 @@ bool simt_conv_rows_eligible(const simt_conv_desc* d) {
   return ntn == 2 || ntn == 4 || ntn == 8 || ntn == 16 || ntn == 32;           // ntiles_n | grid / 8
 }
 
+// simt_conv_desc.in_scale / in_shift / in_out (BatchNorm + ReLU of the input in the operand path): the statistics flavour on Cin 64 / 128 / 256,
+// where the pieces a store thread normalises per stage (2 / 4 / 4) are a multiple of the column tiles that share a pixel row (Cout / 256)
+bool simt_conv_rows_inbn_ok(const simt_conv_desc* d) {
+  if (!simt_conv_rows_eligible(d)) return false;
+  if (!d->stats || d->bias || d->relu || d->res || d->bnr_mode || d->Cout % 4 != 0) return false;
+  if (d->Cin != 64 && d->Cin != 128 && d->Cin != 256) return false;
+  const int pts = d->Cin == 64 ? 2 : 4, ntn = d->Npad / 256;
+  return ntn >= 1 && pts % ntn == 0 && (long)d->B * d->Ho * d->Wo * d->Cin * 2 < (1l << 32);
+}
+
 int simt_conv_rows_launch(Conv2KArgs k, int npad, hipStream_t st) {
   const bool aux = k.res || k.bnr_mode;
   const int cin = k.pix_bytes / 2;
   const bool f_stats = k.stats && !k.bias && !k.relu && !aux && k.Cout % 4 == 0;
+  const bool f_inbn = f_stats && k.in_scale;                    // (simt_conv_inbn_ok: checked by conv2_fill_args)
   const bool f_brr = k.bias && k.relu && k.res && !k.res_bits && !k.bnr_mode && !k.stats;
   const bool f_bnr = k.res && k.res_bits && k.bnr_mode == 3 && !k.bias && !k.relu && !k.stats;
 #ifndef SIMT_ROWS_NCW
@@ -738,6 +826,7 @@ int simt_conv_rows_launch(Conv2KArgs k, int npad, hipStream_t st) {
 #endif
   constexpr int CW = SIMT_ROWS_NCW, SW = CW / 2, D256 = CW == 8 ? 6 : 3;
   if (cin == 256) {
+    if (f_inbn) return launch_rows<8, 2, 6, FL_STATS_INBN, 4, 8>(k, npad, st);
     if (f_stats) return launch_rows<8, 2, D256, FL_STATS, SW, CW>(k, npad, st);
     if (f_brr) return launch_rows<8, 2, D256, FL_BRR, SW, CW>(k, npad, st);
     if (f_bnr) return launch_rows<8, 2, D256, FL_BNR, SW, CW>(k, npad, st);
@@ -755,11 +844,13 @@ int simt_conv_rows_launch(Conv2KArgs k, int npad, hipStream_t st) {
   // Cin 128 / 64: 64-row stages without global epilogue operands; with them 32-row stages (the operands of a 64-row slab do not fit
   // the store waves' registers), for Cin = 64 as two 384-thread workgroups per CU (a 32-row stage is only 4 KB)
   if (cin == 128) {
+    if (f_inbn) return launch_rows<4, 4, 4, FL_STATS_INBN, 4, 8>(k, npad, st);
     if (f_stats) return launch_rows<4, 4, 4, FL_STATS, 4, 8>(k, npad, st);
     if (f_brr) return launch_rows<4, 2, 6, FL_BRR, 4, 8>(k, npad, st);
     if (f_bnr) return launch_rows<4, 2, 6, FL_BNR, 4, 8>(k, npad, st);
     return aux ? launch_rows<4, 2, 6, FL_GEN_AUX, 4, 8>(k, npad, st) : launch_rows<4, 4, 4, FL_GEN, 4, 8>(k, npad, st);
   }
+  if (f_inbn) return launch_rows<2, 4, 6, FL_STATS_INBN, 4, 8>(k, npad, st);
   if (f_stats) return launch_rows<2, 4, 6, FL_STATS, 4, 8>(k, npad, st);
   if (f_brr) return launch_rows<2, 2, 6, FL_BRR, 2, 4>(k, npad, st);
   if (f_bnr) return launch_rows<2, 2, 6, FL_BNR, 2, 4>(k, npad, st);

@@ -39,16 +39,21 @@ struct Conv2KArgs {
   float *fbn_rmean, *fbn_rvar;
   float fbn_momentum, fbn_eps;
   float *fbn_mean, *fbn_rstd, *fbn_scale, *fbn_shift, *fbn_coef, *fbn_dgamma, *fbn_dbeta;
+  // BatchNorm + ReLU of the input in the operand path (simt_conv_desc.in_*; conv1x1_rows_kernel FL_STATS_INBN only)
+  const float *in_scale, *in_shift;
+  bf16_t* in_out;
 };
 
 #ifdef SIMT_ABLATION
 // In-kernel stamps (diagnostic builds only): s_memtime of wave 0 / lane 0 of every workgroup at fixed points, read back with
 // simt_debug_stamps().  Slots: 0 start, 1 addressing done, 2 first stage landed, 3 main loop done, 4 tile in LDS, 5 stores issued, 6 end.
 static __device__ unsigned long long g_stamps[8192 * 8];     // one copy per translation unit (no relocatable device code)
-// Slot 7: s_memrealtime ticks (constant 100 MHz) between stamps 0 and 6 -- with slots 0 and 6 the shader clock the launch actually ran at.
+// s_memrealtime ticks (constant 100 MHz) between stamps 0 and 6 -- with slots 0 and 6 the shader clock the launch actually ran at -- live in their
+// OWN array (slot 7 of g_stamps is a regular stamp of the fused-BatchNorm tail and of the rows kernel: the delta used to be overwritten there)
+static __device__ unsigned long long g_stamps_rt[8192];
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) { g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
-    if ((i) == 0) g_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime(); \
-    if ((i) == 6) g_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime() - g_stamps[blockIdx.x * 8 + 7]; } } while (0)
+    if ((i) == 0) g_stamps_rt[blockIdx.x] = __builtin_amdgcn_s_memrealtime(); \
+    if ((i) == 6) g_stamps_rt[blockIdx.x] = __builtin_amdgcn_s_memrealtime() - g_stamps_rt[blockIdx.x]; } } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif

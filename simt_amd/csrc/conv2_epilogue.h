@@ -25,9 +25,11 @@ __device__ __forceinline__ unsigned long long ld_gran(const unsigned long long* 
 }
 // Polling loops below: the other workgroups of the launch must become resident for a poll to end.  If something keeps them off the chip
 // for ~2 s (two waiting launches of different processes starving each other, a collective's persistent kernels holding CUs: engine.py
-// SIMT_BN_GRID), the poller does NOT trap (round 5): it sets the sticky error word of the plan and leaves its loop with whatever it read; every
-// other poller checks the word every 256 polls and leaves too, so the launch -- and every later fused launch that shares the word -- ends within
-// a poll period, its BatchNorm output undefined.  The host reads the word (TrunkPlan.fbn_error(); the trainers' losses() raise) and the optimiser
+// SIMT_BN_GRID), the poller does NOT trap (round 5): it sets the sticky error word of the plan and leaves its loop; every other poller checks the
+// word every 256 polls and leaves too, so the launch -- and every later fused launch that shares the word -- ends within a poll period.  Round 6:
+// a poller that gave up writes NOTHING derived from what it read -- an owner publishes no constants and leaves mean / rstd / scale / shift / the
+// running statistics / coef / d gamma / d beta untouched, a workgroup whose constants poll gave up returns without its part of `out` (workgroups
+// whose polls completed before the word was set have written theirs from complete sums): `out` is partially written, never garbage-normalised.  The host reads the word (TrunkPlan.fbn_error(); the trainers' losses() raise) and the optimiser
 // kernels skip their update while it is set (simt_sgd_desc.skip_if).  s_memrealtime = constant 100 MHz (s_memtime counts core clocks).
 __device__ __forceinline__ bool fbn_poll_gives_up(unsigned long long* err, unsigned long long t0) {
   if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return true;
@@ -240,6 +242,8 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
       if (a.fbn_mode && tid == 0) {          // tag of this launch's granules: generation + 1 (never 0: the buffers start zeroed)
         const unsigned cnt_s = (unsigned)(a.ntiles_m * a.ntiles_n - (int)(blockIdx.x & 7) + 7) >> 3;
         sTag[0] = (unsigned)(fbn_ticket / cnt_s) + 1u;
+        sTag[1] = 0u;                        // set by an owner thread whose granule poll gave up: the owner finalizes NOTHING
+        sTag[2] = 0u;                        // set by the constants poller when it gave up: the workgroup applies NOTHING
       }
     }
     lds_barrier();
@@ -339,6 +343,7 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
                     if ((++spins & 255u) == 0u && fbn_poll_gives_up(a.fbn_err, t0)) break;      // ~2 s, or another poller's bail-out
                   }
                 } while (!ok);
+                if (!ok) sTag[1] = 1u;       // (benign race: every writer stores 1; read behind the barrier below)
 #pragma unroll
                 for (int u = 0; u < MAXS; ++u)
 #pragma unroll
@@ -351,7 +356,10 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
             for (int j = 0; j < 3; ++j) sRed[(r * 8 + cl) * 3 + j] = sj[j];       // (constant trip counts: a run-time index puts the array in scratch)
           }
           lds_barrier();
-          if (tid < 8 && c < a.Cout) {
+          // a poll of this owner gave up (time-out, or another poller's sticky error word): partial sums -- publish no constants, touch no
+          // statistics (mean / rstd / scale / shift / running statistics / coef / d gamma / d beta keep their previous values); the constants
+          // pollers of every workgroup then leave through the error word
+          if (tid < 8 && c < a.Cout && sTag[1] == 0u) {
             double t[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int j = 0; j < 3; ++j)
@@ -416,11 +424,13 @@ __device__ __forceinline__ void conv2_epilogue(const Conv2KArgs& a_, char* smem,
               if ((++spins & 255u) == 0u && __any(fbn_poll_gives_up(a.fbn_err, t0))) break;
             }
           } while (!ok);
+          if (!ok && lane == 0) sTag[2] = 1u;
 #pragma unroll
           for (int u = 0; u < PER; ++u)
             if (lane + 64 * u < 2 * BN) sCst[lane + 64 * u] = cv[u];
         }
         lds_barrier();
+        if (sTag[2] != 0u) return;                                 // gave up (workgroup-uniform): `out` is NOT written by this workgroup
         STAMP(7);                                                  // (constants published and seen)
         // ---- apply: the tile is still in LDS (bf16, as stored)
         if (n < a.Nstore) {

@@ -292,6 +292,7 @@ extern "C" int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream) {
   SIMT_CHECK(!(d->dtype_in == SIMT_F32 && d->dtype_out == SIMT_BF16));
   if (v2) return simt_conv_fprop_bf16_v2(d, stream);
   SIMT_CHECK(!d->bnr_mode);   // the fused BN-backward reduce exists in the bf16 v2 kernel only
+  SIMT_CHECK(!d->in_scale && !d->in_shift && !d->in_out);      // ... and so does the operand-path BatchNorm (simt_conv_inbn_ok)
   ConvKArgs k;
   k.x = (const char*)d->x; k.w = (const char*)d->w; k.y = d->y; k.bias = d->bias; k.res = d->res;
   k.stats = d->stats; k.zero = (const char*)simt_zero_page();

@@ -14,7 +14,7 @@
 //   * BatchNorm batch statistics (sum, sum of squares of the values as stored) accumulated by the same row-streaming pass,
 //     row groups combined in fixed order through LDS: one deterministic slot per (pixel tile, channel).
 //   * flexible pixel tile: a workgroup owns `rows` <= BM consecutive pixels (BM = 128 or 160 allocated), rows chosen on
-//     the host so that the grid is a whole number of 256-CU rounds (M = 37636: 255 tiles of 148 rows instead of 295
+//     the host so that the grid is a whole number of 256-CU rounds (M = 37636: 236 tiles of 160 rows instead of 295
 //     of 128 -> one round instead of two);
 //   * the two waves of a SIMD run the K-stage in opposite order: waves 0-3 load-then-multiply, waves 4-7 multiply the
 //     fragments they fetched in the previous stage first and load afterwards, so one wave's MFMA burst covers the other
@@ -32,6 +32,9 @@
 #ifdef SIMT_ABLATION       // in-kernel s_memtime stamps of THIS kernel (diagnostic builds only; conv2_common.h STAMP)
 extern "C" int simt_debug_stamps(unsigned long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+extern "C" int simt_debug_stamps_rt(unsigned long long* out, int n) {      // s_memrealtime ticks (100 MHz) between stamps 0 and 6, one per workgroup
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_rt), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
 #endif
 
@@ -240,9 +243,11 @@ __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_kernel(C
 // round of workgroups starts as the first drains, one launch ramp / drain / boundary instead of two.
 template <int BN, int TMP, int NSTP, int EPI0, int EPI1>
 __global__ __launch_bounds__(512, (NSTP == 2 ? 4 : 2)) void conv_igemm2_pair_kernel(Conv2KArgs a0, Conv2KArgs a1) {
-  const int nwg0 = a0.ntiles_m * a0.ntiles_n;
+  // problem 1 starts at the next multiple of 8 (the <= 7 workgroups in between exit at once): xcd_remap reads the XCD off the low three bits of
+  // the id it is given, and blockIdx.x - nwg0 has the hardware's only when nwg0 % 8 == 0 (255 tiles: it was shifted by one XCD)
+  const int nwg0 = a0.ntiles_m * a0.ntiles_n, base1 = (nwg0 + 7) & ~7;
   if ((int)blockIdx.x < nwg0) conv_igemm2_body<BN, TMP, NSTP, 0, EPI0>(a0, (int)blockIdx.x);
-  else conv_igemm2_body<BN, TMP, NSTP, 0, EPI1>(a1, (int)blockIdx.x - nwg0);
+  else if ((int)blockIdx.x >= base1) conv_igemm2_body<BN, TMP, NSTP, 0, EPI1>(a1, (int)blockIdx.x - base1);
 }
 
 #ifdef SIMT_ABLATION
@@ -319,16 +324,21 @@ static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
 }
 
 // Pixel rows per tile: 128 (TM = 4) or, for the 2x4 wave layouts, up to 160 (TM = 5) when that saves a whole round of
-// the 256 CUs.  Cost model: rounds * allocated rows.
-static void pick_rows(int M, int ntn, bool allow160, int* rows, int* tm) {
-  const int CUS = 256;
+// the 256 CUs.  Cost model: rounds * allocated rows; among equal costs the LARGEST tile (round 6).  A TM = 5 workgroup multiplies 160 rows
+// whatever it is given: at M = 37 636 rounds 1-5 took the first one-round size, 148 rows -> 255 tiles, i.e. 7.5 % of the matrix work of every
+// wide conv spent on rows that do not exist -- on a chip whose clock is set by the energy of exactly those launches (profiles/r05_power_clock.txt)
+// -- and left ONE CU to the other stream.  160 rows -> 236 tiles: no padding work, 20 CUs for the weight gradients / the frozen net beside it:
+// the step 24.13 -> 23.68 ms (same box, alternating; profiles/r06_tile_rows.txt).  SIMT_PICK_ROWS_FIRST=1 restores the old choice (A/B).
+static void pick_rows(int M, int ntn, bool allow160, int* rows, int* tm, int cu_budget) {
+  const int CUS = (cu_budget > 0 && cu_budget < 256) ? cu_budget : 256;      // simt_conv_desc.cu_budget: CUs left beside a collective's kernels
+  static const int first = getenv("SIMT_PICK_ROWS_FIRST") ? atoi(getenv("SIMT_PICK_ROWS_FIRST")) : 0;
   long best = -1;
   *rows = 128; *tm = 4;
   for (int r = 128; r <= (allow160 ? 160 : 128); r += 4) {
     const int tiles = (M + r - 1) / r;
     const long rounds = ((long)tiles * ntn + CUS - 1) / CUS;
     const long cost = rounds * (r <= 128 ? 128 : 160);
-    if (best < 0 || cost < best) { best = cost; *rows = r; *tm = r <= 128 ? 4 : 5; }
+    if (best < 0 || cost < best || (cost == best && !first)) { best = cost; *rows = r; *tm = r <= 128 ? 4 : 5; }
   }
 }
 
@@ -336,6 +346,7 @@ extern "C" int simt_conv_fprop(const simt_conv_desc* d, simt_stream_t stream);  
 bool simt_conv_stream_eligible(const simt_conv_desc* d);                  // conv1x1_stream.hip
 int simt_conv_stream_launch(Conv2KArgs k, int npad, hipStream_t st);
 bool simt_conv_rows_eligible(const simt_conv_desc* d);                    // conv1x1_rows.hip
+bool simt_conv_rows_inbn_ok(const simt_conv_desc* d);
 int simt_conv_rows_launch(Conv2KArgs k, int npad, hipStream_t st);
 static bool rows_enabled() {
   static const int off = getenv("SIMT_NO_ROWS") ? atoi(getenv("SIMT_NO_ROWS")) : 0;     // A/B switch
@@ -359,7 +370,7 @@ static Conv2Variant pick_variant(const simt_conv_desc* d) {
   const long Kt = (long)d->ntaps * d->Cin;
   const bool short_k = d->tile_n == 256 && d->dtype_out == SIMT_BF16 && ((Kt <= 512 && d->Cout >= 512) || (Kt <= 128 && d->Cout >= 256));
 #ifdef SIMT_ABLATION
-  { static const int no_short = getenv("SIMT_NO_SHORTK") ? atoi(getenv("SIMT_NO_SHORTK")) : 0; if (no_short) { Conv2Variant w; w.stream = false; w.rowsk = false; w.tile_n = d->tile_n; w.nst = 3; w.ntiles_n = d->Npad / w.tile_n; w.tm = 4; pick_rows(M, w.ntiles_n, w.tile_n != 64, &w.rows, &w.tm); if (w.tile_n == 64) w.tm = 2; return w; } }
+  { static const int no_short = getenv("SIMT_NO_SHORTK") ? atoi(getenv("SIMT_NO_SHORTK")) : 0; if (no_short) { Conv2Variant w; w.stream = false; w.rowsk = false; w.tile_n = d->tile_n; w.nst = 3; w.ntiles_n = d->Npad / w.tile_n; w.tm = 4; pick_rows(M, w.ntiles_n, w.tile_n != 64, &w.rows, &w.tm, d->cu_budget); if (w.tile_n == 64) w.tm = 2; return w; } }
 #endif
   // Round 4 experiment (SIMT_ROWS_1024=1; default OFF): the long-reduction 1x1 convs on dense rows (conv1 of layer 3 / 4: 1024 -> 256 / 512)
   // as whole 2-KB pixel rows streamed past register-resident weights (conv1x1_rows_kernel<32, 1, 4, ..., 1, 4, 1>: 128 weight registers per
@@ -375,7 +386,7 @@ static Conv2Variant pick_variant(const simt_conv_desc* d) {
   v.nst = short_k ? 2 : 3;
   v.ntiles_n = d->Npad / v.tile_n;
   v.tm = 4;
-  pick_rows(M, short_k ? (v.ntiles_n + 1) / 2 : v.ntiles_n, v.tile_n != 64, &v.rows, &v.tm);
+  pick_rows(M, short_k ? (v.ntiles_n + 1) / 2 : v.ntiles_n, v.tile_n != 64, &v.rows, &v.tm, d->cu_budget);
   if (v.tile_n == 64) v.tm = 2;
   return v;
 }
@@ -446,6 +457,13 @@ extern "C" long simt_conv_fbn_words(const simt_conv_desc* d) {
   return SIMT_FBN_BAR_WORDS + 2l * d->Cout + tiles * 3 * d->Cout;
 }
 
+// Does the launch for d accept simt_conv_desc.in_scale / in_shift / in_out (BatchNorm + ReLU of the input applied in the operand path)?
+extern "C" int simt_conv_inbn_ok(const simt_conv_desc* d) {
+  if (!d || d->dtype_in != SIMT_BF16 || d->dtype_out != SIMT_BF16 || d->tile_n != 256 || d->fbn) return 0;
+  const Conv2Variant v = pick_variant(d);
+  return v.rowsk && simt_conv_rows_inbn_ok(d) ? 1 : 0;
+}
+
 extern "C" int simt_conv_mtiles(const simt_conv_desc* d) {
   int bn, tm, nst;
   const int gen = simt_conv_variant(d, &bn, &tm, &nst);
@@ -482,6 +500,9 @@ static int conv2_fill_args(const simt_conv_desc* d, Conv2KArgs& k, Conv2Variant*
     k.fbn_mean = f->mean; k.fbn_rstd = f->rstd; k.fbn_scale = f->scale; k.fbn_shift = f->shift; k.fbn_coef = f->coef;
     k.fbn_dgamma = f->dgamma; k.fbn_dbeta = f->dbeta;
   }
+  k.in_scale = d->in_scale; k.in_shift = d->in_shift; k.in_out = (bf16_t*)d->in_out;
+  if (d->in_scale || d->in_shift || d->in_out)       // the operand-path BatchNorm exists in the row-streaming kernel's statistics flavour only
+    SIMT_CHECK(d->in_scale && d->in_shift && d->in_out && simt_conv_inbn_ok(d));
   k.out_f32 = d->dtype_out == SIMT_F32;
   if (k.out_f32) SIMT_CHECK(!d->bias && !d->res && !d->relu && !d->stats && d->Nstore % 4 == 0 && d->ldy % 4 == 0);
   k.H = d->H; k.W = d->W; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout; k.Nstore = d->Nstore; k.ldy = d->ldy; k.ldr = d->ldr;
@@ -539,7 +560,7 @@ static int launch_pair(const Conv2KArgs& k0, const Conv2KArgs& k1, hipStream_t s
   static SimtLdsAttrCache attr_cache;
   if (simt_lds_attr_needed(&attr_cache, lds))
     (void)hipFuncSetAttribute((const void*)conv_igemm2_pair_kernel<BN, TM, 3, E0, E1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((conv_igemm2_pair_kernel<BN, TM, 3, E0, E1>), dim3(2 * k0.ntiles_m * k0.ntiles_n), dim3(512), lds, st, k0, k1);
+  hipLaunchKernelGGL((conv_igemm2_pair_kernel<BN, TM, 3, E0, E1>), dim3(((k0.ntiles_m * k0.ntiles_n + 7) & ~7) + k1.ntiles_m * k1.ntiles_n), dim3(512), lds, st, k0, k1);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }
@@ -569,6 +590,7 @@ extern "C" int simt_conv_pair_fused(const simt_conv_desc* d0, const simt_conv_de
   if (d0->B != d1->B || d0->H != d1->H || d0->W != d1->W || d0->Cin != d1->Cin || d0->Ho != d1->Ho || d0->Wo != d1->Wo || d0->stride != d1->stride ||
       d0->ntaps != d1->ntaps || d0->Npad != d1->Npad || d0->Cout != d1->Cout || d0->Nstore != d1->Nstore || d0->dtype_out != d1->dtype_out) return 0;
   for (int i = 0; i < d0->ntaps; ++i) if (d0->dy[i] != d1->dy[i] || d0->dx[i] != d1->dx[i]) return 0;
+  if (d0->in_scale || d1->in_scale) return 0;       // (the operand-path BatchNorm flavour has no pair instantiation)
   Conv2KArgs k0, k1;
   k0.out_f32 = d0->dtype_out == SIMT_F32; k0.res = (const bf16_t*)d0->res; k0.mask = (const bf16_t*)d0->mask; k0.Nstore = d0->Nstore; k0.Cout = d0->Cout;
   k0.stats = d0->stats; k0.bias = d0->bias; k0.relu = d0->relu; k0.bnr_mode = d0->bnr_mode; k0.res_bits = d0->res_bits;

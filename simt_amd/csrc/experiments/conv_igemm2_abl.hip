@@ -82,6 +82,9 @@ extern "C" int simt_debug_kstamps(unsigned long long* out, int nblocks) {
 extern "C" int simt_debug_stamps_abl(unsigned long long* out, int n) {      // g_stamps of THIS translation unit (STAMP in conv2_common.h)
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
+extern "C" int simt_debug_stamps_abl_rt(unsigned long long* out, int n) {      // s_memrealtime ticks (100 MHz) between stamps 0 and 6, one per workgroup
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_rt), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
 #define KST(i) do { if constexpr (KS != 0) { if (kt == kmid) { asm volatile("" ::: "memory"); kst[i] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } } } while (0)
 #define KST_NEXT() do { if constexpr (KS != 0) { if (kt == kmid + 1) { asm volatile("" ::: "memory"); kst[4] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } } } while (0)
 #define KST_LANDED(i) do { if constexpr (KS != 0) { if (kt == kmid) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); kst[i] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } } } while (0)

@@ -27,6 +27,9 @@ extern "C" int simt_debug_hstamps(unsigned long long* out, int nblocks) {
 extern "C" int simt_debug_stamps_half(unsigned long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
+extern "C" int simt_debug_stamps_half_rt(unsigned long long* out, int n) {      // s_memrealtime ticks (100 MHz) between stamps 0 and 6, one per workgroup
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_rt), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
 
 template <int BN, int TMP, int EPI, int PLAIN, int KS = 0>
 __global__ __launch_bounds__(512, 2) void conv_igemm2h_kernel(Conv2KArgs a) {

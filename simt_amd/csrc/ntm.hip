@@ -23,6 +23,7 @@ struct NtmInnerArgs {
   int Q, C, steps, step0;
   float lr, beta1, beta2, eps;
   int k0;      // first NTM index this launch handles (1 for one-output models)
+  const unsigned long long* skip_if;   // simt_ntm_inner_desc.skip_if
 };
 
 // T = rowL1normalize( sigmoid(N) * cd + [I;0] ), also returns sigmoid and the row sums (for the backward)
@@ -84,6 +85,8 @@ __global__ __launch_bounds__(256) void ntm_inner_kernel(NtmInnerArgs a) {
   __shared__ float wraw[NQ * NQ], sm[NQ * NQ], Wm[NQ * NQ], dW[NQ * NQ], am[NQ * NQ], av[NQ * NQ];
   __shared__ float rs[NQ], dot[NQ], cd[NC];
   const int k = blockIdx.x + a.k0, tid = threadIdx.x, Q = a.Q, C = a.C;
+  // a fused BatchNorm launch of an earlier iteration gave up (sticky word): W, its Adam moments, the leaked NTM gradient and T_out stay as they are
+  if (a.skip_if && __hip_atomic_load(a.skip_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return;
   for (int i = tid; i < Q * C; i += 256) { N[i] = a.ntm[k][i]; gN[i] = 0.f; }
   for (int i = tid; i < Q * Q; i += 256) { wraw[i] = a.w[k][i]; am[i] = a.w_m[k][i]; av[i] = a.w_v[k][i]; }
   if (tid < C) cd[tid] = a.class_dist[tid];
@@ -158,6 +161,7 @@ extern "C" int simt_ntm_inner_loop(const simt_ntm_inner_desc* d, simt_stream_t s
   }
   a.class_dist = d->class_dist; a.Q = d->Q; a.C = d->C; a.steps = d->steps; a.step0 = d->step0;
   a.lr = d->lr; a.beta1 = d->beta1; a.beta2 = d->beta2; a.eps = d->eps;
+  a.skip_if = (const unsigned long long*)d->skip_if;
   hipLaunchKernelGGL(ntm_inner_kernel, dim3(2 - a.k0), dim3(256), 0, (hipStream_t)stream, a);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
@@ -414,9 +418,10 @@ extern "C" int simt_sig_w(float* weight, const float* dW, float* W_out, float* d
 }
 
 __global__ void adam_step_kernel(float* p, const float* g, float* m, float* v, long n, float step_size, float bc2s,
-                                 float beta1, float beta2, float eps) {
+                                 float beta1, float beta2, float eps, const unsigned long long* skip_if) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (skip_if && __hip_atomic_load(skip_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return;     // like simt_sgd_desc.skip_if
   float gi = g[i];
   float mi = m[i] + (gi - m[i]) * (1.f - beta1);
   float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
@@ -424,13 +429,18 @@ __global__ void adam_step_kernel(float* p, const float* g, float* m, float* v, l
   v[i] = vi;
   p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2s + eps));
 }
-extern "C" int simt_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                              float eps, int step, simt_stream_t stream) {
+// skip_if: optional device word (simt_fbn_desc.err); while it is non-zero the launch changes neither p nor the moments
+extern "C" int simt_adam_step_guarded(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                                      float eps, int step, const uint64_t* skip_if, simt_stream_t stream) {
   SIMT_CHECK(p && g && m && v && step >= 1);
   double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   float step_size = (float)((double)lr / bc1), bc2s = (float)sqrt(bc2);
   hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     n, step_size, bc2s, beta1, beta2, eps);
+                     n, step_size, bc2s, beta1, beta2, eps, (const unsigned long long*)skip_if);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
+}
+extern "C" int simt_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                              float eps, int step, simt_stream_t stream) {
+  return simt_adam_step_guarded(p, g, m, v, n, lr, beta1, beta2, eps, step, nullptr, stream);
 }

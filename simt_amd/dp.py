@@ -45,7 +45,14 @@ class BucketReducer:
         # 1-GPU box; a mean over one rank is the identity, bit for bit)
         self.single = self.world == 1 and not (os.environ.get("SIMT_DP_FORCE") == "1" and dist.is_initialized())
         self.cuda = flat.is_cuda
-        self.comm = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        # The collectives are issued with the plan's SIDE stream current (round 6; rounds 1-5 made a stream of their own): the side stream is
+        # where the weight gradients are produced, it trails the main stream through the backward (so its wait for the main stream's position
+        # at a release point is free), and every extra stream is one more contender for HIP's 4 hardware queues -- a "comm" stream that lands on
+        # the main stream's queue stalls the main stream at each of its cross-stream waits (engine.reserve_streams).
+        self.comm = None
+        if self.cuda:
+            from .engine import side_stream
+            self.comm = side_stream(flat.device)
         backend = dist.get_backend(group) if dist.is_initialized() else ""
         self.avg = backend == "nccl"
         self.handles = []
@@ -93,7 +100,12 @@ class BucketReducer:
 
     def ready_upto(self, launch_index, producer_event=None):
         """Called by the backward replay after `launch_index` launch-list entries have been enqueued.  producer_event:
-        event on the stream that writes the gradients (the plan's side stream) covering those entries."""
+        event on the stream that writes the gradients (the plan's side stream) covering those entries -- or a callable that
+        records and returns one (TrunkPlan.backward: only called when a bucket really leaves at this point)."""
+        if callable(producer_event) and not self.single and self.next < len(self.buckets) and self.buckets[self.next][2] <= launch_index:
+            producer_event = producer_event()
+        elif callable(producer_event):
+            producer_event = None
         while self.next < len(self.buckets) and self.buckets[self.next][2] <= launch_index:
             s, e, _ = self.buckets[self.next]
             self.released[self.next] = launch_index
@@ -101,12 +113,16 @@ class BucketReducer:
             if self.single:
                 continue
             if self.cuda:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
+                # compute stream -> comm stream: device scope is enough (the consumer is the collective's kernel on this device; a system-scope
+                # torch event idles the recording queue ~6.5 us: engine.DeviceEvent).  The event BEHIND the exchange (finish) stays system scope.
+                from .engine import _new_event, wait_event
+                ev_stream = torch.cuda.current_stream()
+                ev = _new_event()
+                ev.record(ev_stream)
                 with torch.cuda.stream(self.comm):
-                    self.comm.wait_event(ev)
-                    if producer_event is not None:
-                        self.comm.wait_event(producer_event)
+                    if torch.cuda.current_stream() != ev_stream:
+                        wait_event(self.comm, ev)
+                    # (producer_event was recorded on the side stream itself: in-order, nothing to wait for)
                     self._reduce(self.flat[s:e])
             else:
                 self._reduce(self.flat[s:e])
@@ -117,10 +133,13 @@ class BucketReducer:
         if self.single:
             return
         if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
+            from .engine import _new_event, wait_event
+            ev_stream = torch.cuda.current_stream()
+            ev = _new_event()
+            ev.record(ev_stream)
             with torch.cuda.stream(self.comm):
-                self.comm.wait_event(ev)
+                if torch.cuda.current_stream() != ev_stream:
+                    wait_event(self.comm, ev)
                 for t in self.extra:
                     self._reduce(t)
         else:
@@ -140,7 +159,7 @@ class BucketReducer:
         # exposed wait: on CUDA tensors the e0 -> e1 event pair already contains whatever the host blocked for between the two records
         # (gloo on device tensors), so the host timer counts only for CPU tensors -- never both (double counting)
         host = time.perf_counter() - t0 if not self.cuda else 0.0
-        if self.cuda:
+        if self.cuda and torch.cuda.current_stream() != self.comm:      # (the early optimiser step calls finish() ON the side stream: nothing to join)
             done = torch.cuda.Event()
             done.record(self.comm)
             torch.cuda.current_stream().wait_event(done)

@@ -92,6 +92,34 @@ def side_stream(device=None):
     return _SIDE_STREAMS[dev]
 
 
+_RESERVED = set()
+
+
+def reserve_streams(device=None):
+    """Give the plan's two streams their hardware queues NOW.  HIP multiplexes every stream of a process onto 4 hardware queues, handed out in
+    order of FIRST USE; two streams that share a queue run their kernels strictly one after the other.  Measured (round 6, profiles/
+    r06_dp_emulation.txt): a data-parallel job that created its process group first -- RCCL and ProcessGroupNCCL make streams of their own --
+    found the plan's side stream (weight gradients, frozen forward) on the MAIN stream's queue: 26.18 ms per step instead of 24.06, the whole
+    two-stream overlap gone.  Call this before torch.distributed.init_process_group / before creating other streams (bench.py and the tools do);
+    TrunkPlan calls it too, which is early enough in a single-GPU process.  Idempotent."""
+    if not torch.cuda.is_available():
+        return
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev in _RESERVED:
+        return
+    _RESERVED.add(dev)
+    with torch.cuda.device(dev):
+        main, side = torch.cuda.current_stream(dev), side_stream(dev)
+        t = torch.zeros(64, device=torch.device("cuda", dev))
+        t.add_(1)                                  # a kernel on the main stream ...
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            t.add_(1)                              # ... and one on the side stream: both queues exist from here on
+        torch.cuda.synchronize(dev)
+
+
 class DeviceEvent:
     """An event that orders the two HIP streams of a plan on ONE device: recorded with a device-scope release (simt_event_create: no
     system-scope cache write-back behind every record, which costs the recording queue ~6.5 us and a cross-stream wait ~12 us).  Same
@@ -100,7 +128,9 @@ class DeviceEvent:
 
     def __init__(self):
         h = C.c_void_p()
-        L.call("simt_event_create", C.byref(h), 0)
+        # SIMT_EVENT_SCOPE: 0 (default) hipEventReleaseToDevice, the documented device-scope release; 2 = no release at the marker
+        # (hipEventDisableSystemFence: round 5's form, opt-in); 1 = system scope
+        L.call("simt_event_create", C.byref(h), int(os.environ.get("SIMT_EVENT_SCOPE", "0")))
         self.h = h
 
     def record(self, stream):
@@ -122,6 +152,11 @@ def _new_event():
     if os.environ.get("SIMT_LIGHT_EVENTS", "1") != "0" and torch.cuda.is_available():
         return DeviceEvent()
     return torch.cuda.Event()
+
+
+def wait_event(stream, ev):
+    """stream waits for ev (a torch.cuda.Event or a DeviceEvent); for callers outside this module (dp.BucketReducer)."""
+    _wait_event(stream, ev)
 
 
 def _wait_event(stream, ev):
@@ -303,6 +338,8 @@ class TrunkPlan:
         # im2col matrix is reused instead of being rebuilt; the caller orders the streams (step.py)
         self.stem_from = stem_from
         self.dev = device or next(iter(params.values())).device
+        if torch.device(self.dev).type == "cuda":
+            reserve_streams(self.dev)
         self.esz = 2 if dtype == torch.bfloat16 else 4
         self.kq = 128 // self.esz            # channel quantum of the K dimension (one 128-B stage)
         (self.H0, self.W0), (self.Hp, self.Wp), (self.H2, self.W2) = trunk_geometry(H, W)
@@ -317,16 +354,32 @@ class TrunkPlan:
         # sums through polled granules, so all of them must be resident at once.  Measured on the production step (profiles/
         # r04_bn_fusion.txt): the BACKWARD form (dgrad + BatchNorm backward in one launch) is worth -0.2 ms; the FORWARD form is +0.75 ms
         # slower in the step although it is 5 us faster per launch alone -- its waiting workgroups hold CUs the frozen forward on the side
-        # stream wants.  Default 3 = backward only -- for a plan that has the GPU to itself.  A waiting launch needs ALL its workgroups resident
-        # (255 of 256 CUs, 156 KB of LDS each): under data parallelism the bucketed all-reduce's persistent RCCL kernels hold CUs and spin on
-        # remote peers during exactly these launches, and a second process on the same GPU can starve it outright.  So: `data_parallel` plans
-        # (the trainers pass process_group is not None) default to 0 = two-pass BatchNorm; SIMT_BN_GRID set explicitly always wins (opt in after a
-        # multi-GPU soak).  A launch whose polling times out (~2 s) no longer traps: it sets the plan's sticky error word `fbn_err` and ends;
+        # stream wants.  Default 3 = backward only.  A waiting launch needs ALL its workgroups resident (236 of 256 CUs, 156 KB of LDS each); a
+        # second PROCESS on the same GPU can starve it outright (bench.py forces SIMT_BN_GRID=0 there).  Rounds 4-5 also switched it off under
+        # data parallelism (255-workgroup launches beside a collective's persistent kernels); see below.  A launch whose polling times out (~2 s) no longer traps: it sets the plan's sticky error word `fbn_err` and ends;
         # fbn_error() reports it, the trainers' losses() raise, and the optimiser kernels skip their update while it is set (skip_if).
+        # Round 6: data-parallel plans default to 3 as well.  The fused launches are 236 workgroups (160-row tiles): with <= 20 CUs held by the
+        # collective they ARE all resident, with more they wait for the collective's kernels to end (finite: those never wait for a compute kernel
+        # of this process) -- no circular wait, and the time-out path no longer traps.  Measured over a one-rank RCCL group (profiles/
+        # r06_dp_emulation.txt): 24.83 ms two-pass -> 24.31 ms fused.  SIMT_BN_GRID=0 remains the switch; bench.py forces it when several ranks
+        # share one GPU (two waiting launches of different processes can starve each other).
         g = os.environ.get("SIMT_BN_GRID")           # 0 off, 1 forward + backward, 2 forward only, 3 backward only
         if g is None:
-            g = "0" if data_parallel else "3"
+            g = "3"
         self.data_parallel = bool(data_parallel)
+        # CU budget of the conv tile lists (simt_conv_desc.cu_budget; round 6).  The wide convs are ONE workgroup per CU (156 KB of LDS); their
+        # default plan at M = 37 636 is 236 tiles of 160 rows (pick_rows: the largest one-round tile), which leaves 20 CUs to whatever runs beside
+        # them -- the side stream's weight gradients, or a collective's persistent kernels.  A data-parallel plan states the CUs it may use as
+        # 256 - NCCL_MAX_NCHANNELS (16 channels assumed when the variable is unset -- bench.py and the training tools set that default before the
+        # process group exists; at most 20 are given up): any budget >= 236 leaves the plan as it is, so the budget costs nothing; a smaller one
+        # re-plans the tile lists (profiles/r06_dp_emulation.txt).  SIMT_CU_BUDGET=n sets it explicitly (0: the whole device).
+        cb = os.environ.get("SIMT_CU_BUDGET")
+        if cb is not None:
+            self.cu_budget = int(cb)
+        elif data_parallel:
+            self.cu_budget = 256 - max(0, min(20, int(os.environ.get("NCCL_MAX_NCHANNELS", "16"))))
+        else:
+            self.cu_budget = 0
         self._fbn_on = train and dtype == torch.bfloat16 and g != "0"
         self._fbn_dirs = {"1": (1, 2), "2": (1,), "3": (2,)}.get(g, ())
         self.fbn_err = None                          # one int64 device word shared by every fused launch of this plan (allocated on first use)
@@ -361,9 +414,12 @@ class TrunkPlan:
 
     def raise_on_fbn_error(self):
         if self.fbn_error():
-            raise RuntimeError("a fused BatchNorm launch (SIMT_BN_GRID) timed out waiting for its workgroups to become co-resident: its outputs "
-                               "are undefined and the optimiser skipped the update; rebuild the trainer with SIMT_BN_GRID=0 (two-pass BatchNorm) -- "
-                               "required when several processes share a GPU, the default under data parallelism")
+            raise RuntimeError("a fused BatchNorm launch (SIMT_BN_GRID) timed out waiting for its workgroups to become co-resident: its output and every "
+                               "later activation / gradient of that step are undefined.  No optimiser launch (SGD, Adam on NTM1 / NTM2, the W inner loop) "
+                               "has changed anything since the word was set, and the launch that gave up updated no BatchNorm statistics: the state_dict "
+                               "holds the last good state (W one inner loop ahead if the time-out hit in the iteration's own forward / backward).  Rebuild the "
+                               "trainer with SIMT_BN_GRID=0 (two-pass BatchNorm) -- required when several processes share a GPU, the default under data "
+                               "parallelism")
 
     # ------------------------------------------------------------------ buffers
     def buf(self, role, *shape, dtype=None, zero=False):
@@ -440,7 +496,8 @@ class TrunkPlan:
 
     # ------------------------------------------------------------------ forward construction
     def _conv(self, lst, x, wp_info, y, *, Bn, Hi, Wi, Cin, Ho, Wo, Cout, taps, stride=1, bias=None, res=None, stats=None,
-              relu=False, ldy=None, Nstore=None, alg_k=None, alg_flops=None, mask=None, res_bits=None, bnr=None, note="", fbn=None):
+              relu=False, ldy=None, Nstore=None, alg_k=None, alg_flops=None, mask=None, res_bits=None, bnr=None, note="", fbn=None,
+              inbn=None):
         """alg_k: algorithmic reduction length per output element (defaults to ntaps*Cin; the K-padded head dgrad and
         the stem pass their true value) -> algorithmic FLOPs = 2 * M * Cout * alg_k.
         fbn: ask for the train-mode BatchNorm behind this conv to be fused into the launch (simt_fbn_desc; dict(mode, out, bname[,
@@ -456,6 +513,13 @@ class TrunkPlan:
         d = ops.make_conv_desc(x, wp, y, B=Bn, H=Hi, W=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, taps=taps, stride=stride,
                                bias=bias, res=res, stats=stats, relu=relu, Npad=npad, tile_n=tile, ldy=ldy,
                                Nstore=Nstore, mask=mask, res_bits=res_bits, bnr=bnr)
+        d.cu_budget = self.cu_budget
+        if inbn is not None:
+            # x is the RAW pre-BatchNorm activation; the launch normalises + ReLUs it in its operand path and writes the activation to inbn[2]
+            # (simt_conv_desc.in_*; the caller asked simt_conv_inbn_ok first: _conv3_takes_bn2)
+            assert L.load().simt_conv_inbn_ok(C.byref(d))
+            d.in_scale, d.in_shift, d.in_out = inbn[0].data_ptr(), inbn[1].data_ptr(), inbn[2].data_ptr()
+            note = note + " (input BatchNorm in the operand path)"
         M = Bn * Ho * Wo
         k = alg_k if alg_k is not None else len(taps) * Cin
         tn = {torch.bfloat16: "bf16", torch.float32: "f32"}
@@ -587,7 +651,7 @@ class TrunkPlan:
                 w1 = self._plan_pack(f"{name}.conv1", planes, inpl, 1)
                 w2 = self._plan_pack(f"{name}.conv2", planes, planes, 3)
                 w3 = self._plan_pack(f"{name}.conv3", c4, planes, 1)
-                # bn1 / bn2: fused into the producing conv where its grid is one co-resident round (layer 3 at 4 x 768 x 768: 255 tiles):
+                # bn1 / bn2: fused into the producing conv where its grid is one co-resident round (layer 3 at 4 x 768 x 768: 236 tiles):
                 # the launch writes y AND a = relu(bn(y)); otherwise statistics slots -> finalize -> apply as separate launches
                 dsc = self._conv(f, x, w1, y1, Bn=B, Hi=Hc, Wi=Wc, Cin=inpl, Ho=Ho, Wo=Wo, Cout=planes, taps=[(0, 0)],
                                  stride=stride, stats=s1["part"], fbn=dict(mode=1, out=a1, bname=f"{name}.bn1"))
@@ -597,12 +661,20 @@ class TrunkPlan:
                           None, a1.data_ptr(), Mo, planes, 1, ops.dt_code(dt))
                 dsc = self._conv(f, a1, w2, y2, Bn=B, Hi=Ho, Wi=Wo, Cin=planes, Ho=Ho, Wo=Wo, Cout=planes, taps=t3,
                                  stats=s2["part"], fbn=dict(mode=1, out=a2, bname=f"{name}.bn2"))
+                # bn2 -> conv3 (round 6): where the row-streaming 1x1 kernel takes conv3 (layers 1-3), bn2's normalise + ReLU runs in ITS operand
+                # path (the store waves rewrite every landed stage in LDS and write a2 out on the way): no simt_bn_apply launch, no re-read of y2
+                kw3 = dict(Bn=B, Hi=Ho, Wi=Wo, Cin=planes, Ho=Ho, Wo=Wo, Cout=c4, taps=[(0, 0)], stats=s3["part"])
+                inbn = (not dsc.fbn) and os.environ.get("SIMT_NO_INBN", "0") == "0" and L.load().simt_conv_inbn_ok(C.byref(self._conv(LaunchList(), y2, w3, y3, **kw3))) != 0
                 if not dsc.fbn:
                     self._bn_train(f, f"{name}.bn2", y2, Mo, planes)
-                    f.add("simt_bn_apply", y2.data_ptr(), s2["scale"].data_ptr(), s2["shift"].data_ptr(), None, None, None,
-                          None, a2.data_ptr(), Mo, planes, 1, ops.dt_code(dt))
-                self._conv(f, a2, w3, y3, Bn=B, Hi=Ho, Wi=Wo, Cin=planes, Ho=Ho, Wo=Wo, Cout=c4, taps=[(0, 0)],
-                           stats=s3["part"])
+                    if not inbn:
+                        f.add("simt_bn_apply", y2.data_ptr(), s2["scale"].data_ptr(), s2["shift"].data_ptr(), None, None, None,
+                              None, a2.data_ptr(), Mo, planes, 1, ops.dt_code(dt))
+                if inbn:
+                    self._conv(f, y2, w3, y3, inbn=(s2["scale"], s2["shift"], a2), **kw3)
+                else:
+                    self._conv(f, a2, w3, y3, **kw3)
+                rec["inbn"] = bool(inbn)
                 self._bn_train(f, f"{name}.bn3", y3, Mo, c4)
                 # ReLU mask of the block output as one bit per element: what bn3's backward reads instead of z
                 zbits = self.new(Mo, c4 // 8, dtype=torch.uint8)
@@ -1235,9 +1307,18 @@ class TrunkPlan:
         for c in cuts:
             seg.items = items[i0:c]
             seg.run()
-            ev = torch.cuda.Event()
-            ev.record(side)
-            hook(c, ev)
+            # the event is made only if the hook asks for it (the reducer does when a bucket leaves at this cut: 5 of 29 cuts in the production
+            # plan -- round 5 recorded a system-scope torch event at every cut: ~6.5 us of idle side queue each), device scope like the
+            # launch lists' own events: the consumer is the collective's kernel on THIS device
+            made = []
+
+            def make_ev():
+                if not made:
+                    e = _new_event()
+                    e.record(side)
+                    made.append(e)
+                return made[0]
+            hook(c, make_ev)
             i0 = c
         seg.items = items[i0:]
         seg.run()

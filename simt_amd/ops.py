@@ -306,8 +306,9 @@ def softmax_rows(src, ldi, out, ldo, M, Cn):
     L.call("simt_softmax_rows", _p(src), ldi, _p(out), ldo, M, Cn, stream_ptr())
 
 
-def adam_step(p, g, m, v, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, step):
-    L.call("simt_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, stream_ptr())
+def adam_step(p, g, m, v, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, step, skip_if=None):
+    """skip_if: device word (TrunkPlan.fbn_err); while it is non-zero the launch leaves p and the moments untouched."""
+    L.call("simt_adam_step_guarded", _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, _p(skip_if), stream_ptr())
 
 
 def sig_ntm(ntm, class_dist, T_out=None, dT=None, dN_out=None):

@@ -80,7 +80,7 @@ class SimTTrainer:
                               data_parallel=process_group is not None, **kw)
         # the frozen model sees the same image: it reuses the trainable plan's stem im2col matrix (one im2col per micro-batch)
         self.fixed = TrunkPlan(self.fixed_params, B, H, W, multi_heads(Cn, 0, False), dtype=dtype, train=False,
-                               stem_from=self.plan, **kw)
+                               stem_from=self.plan, data_parallel=process_group is not None, **kw)      # (same CU budget = same tile lists as the trainable plan)
         assert self.plan.fwd_list.items[0].tag == "simt_im2col_stem"
         import os
         # hipGraphs of the three launch lists (frozen forward, trainable forward, backward with its two streams): the host spends
@@ -108,7 +108,10 @@ class SimTTrainer:
         Q = self.Q
         # ---- NTM / W state (model/deeplab_multi.py:244-286)
         self.ntm = [ntm1.detach().to(dev, f32).clone(), ntm2.detach().to(dev, f32).clone()]
-        self._ntm_grad_flat = torch.zeros(2, Q, Cn, device=dev)
+        # ONE allocation [16 scalars (lout) | dNTM1 | dNTM2]: under data parallelism its tail from lout[12] on (the bad-label count, three unused
+        # slots, both NTM gradients) is ONE contiguous collective at the end of the exchange (it used to be two)
+        self._xchg = torch.zeros(16 + 2 * Q * Cn, device=dev)
+        self._ntm_grad_flat = self._xchg[16:].view(2, Q, Cn)
         self.ntm_grad = [self._ntm_grad_flat[0], self._ntm_grad_flat[1]]
         self.ntm_m = [torch.zeros(Q, Cn, device=dev) for _ in range(2)]
         self.ntm_v = [torch.zeros(Q, Cn, device=dev) for _ in range(2)]
@@ -125,7 +128,8 @@ class SimTTrainer:
         self.part = torch.zeros(self.nblk, lib.simt_head_part_floats(Q, Cn), device=dev)
         self.keys = torch.zeros(lib.simt_head_keys_count(), device=dev, dtype=torch.int64)
         self.hout = torch.zeros(lib.simt_head_hout_floats(Q, Cn), device=dev)
-        self.lout = torch.zeros(16, device=dev)
+        self.lout = self._xchg[:16]
+        self._bad_reported = 0                     # out-of-range labels already raised for (host side; the device counter is never reset)
         self.QP = ops.round_up(Q, 8)
         self.g1 = torch.zeros(2, B, H, w, self.QP, device=dev)
         self.ldf = self.fixed.ldp["x2"]
@@ -157,6 +161,11 @@ class SimTTrainer:
             ni.w_m[k], ni.w_v[k], ni.T_out[k] = self.w_m[k].data_ptr(), self.w_v[k].data_ptr(), self.T[k].data_ptr()
         ni.class_dist, ni.Q, ni.C, ni.steps = self.cd.data_ptr(), Q, Cn, self.inner_steps
         ni.beta1, ni.beta2, ni.eps = 0.9, 0.999, 1e-8
+        # every optimiser launch is guarded by the plan's sticky fused-BatchNorm error word (engine.TrunkPlan.fbn_error): once a fused launch has
+        # given up polling, SGD, both Adams and the W inner loop change nothing -- a state_dict saved after losses() raised holds the last good state
+        self._skip_word = getattr(self.plan, "fbn_err", None)
+        if self._skip_word is not None:
+            ni.skip_if = self._skip_word.data_ptr()
         self.inner_desc = ni
         npd = L.NtmPostDesc()
         for k in range(2):
@@ -196,7 +205,7 @@ class SimTTrainer:
             buckets = make_buckets(order, sizes, self.plan.grad_ready, bucket_elems=self.BUCKET_ELEMS)
             # the bad-label count (lout[12], accumulated by simt_ntm_post) rides in the same exchange: after the mean every rank holds
             # total / world, so losses() needs no collective of its own and every rank raises in the same call
-            self.reducer = BucketReducer(self.plan.flat_grad[:end], buckets, group=self.pg, extra=[self._ntm_grad_flat, self.lout[12:13]])
+            self.reducer = BucketReducer(self.plan.flat_grad[:end], buckets, group=self.pg, extra=[self._xchg[12:]])
             self.reducer.total_launches = len(self.plan.bwd_list.items)
 
     BUCKET_ELEMS = 8 << 20      # 32 MB of fp32 per all-reduce: few large messages for xGMI rings (dp.py)
@@ -367,8 +376,8 @@ class SimTTrainer:
         return both
 
     def _paired_forwards(self):
-        """Both forwards as ONE launch list on the main stream with ONE launch per layer for both networks (round 5; the
-        default, SIMT_FWD_ORDER=pair): the trainable and the frozen ResNetMulti run the same conv shapes on the same image
+        """Both forwards as ONE launch list on the main stream with ONE launch per layer for both networks (round 5; OPT-IN,
+        SIMT_FWD_ORDER=pair: measured +1.3 ms per step, the default stays "main"): the trainable and the frozen ResNetMulti run the same conv shapes on the same image
         (tools/trainV2_simt.py:351-353 and :370 -> model/deeplab_multi.py:172-192), so conv k of one and conv k of the other go into one
         simt_conv_fprop_pair launch (510 workgroups: the second 255 start as the first drain), each half with its own compile-time epilogue
         (BatchNorm statistics | folded bias + ReLU [+ residual]).  The two lists are aligned by a longest-common-subsequence match on the
@@ -596,7 +605,7 @@ class SimTTrainer:
                 self._sgd(lr, st)
         torch.cuda.current_stream().wait_event(self._ev_post)      # regularisers (side stream): NTM gradients and the losses are final
         for k in range(2):
-            ops.adam_step(self.ntm[k], self.ntm_grad[k], self.ntm_m[k], self.ntm_v[k], lr=lr_T, step=self.it_done + 1)
+            ops.adam_step(self.ntm[k], self.ntm_grad[k], self.ntm_m[k], self.ntm_v[k], lr=lr_T, step=self.it_done + 1, skip_if=self._skip_word)
         if not self._early_sgd:
             self.plan.repack()
         self.it_done += 1
@@ -668,10 +677,10 @@ class SimTTrainer:
         v = self.lout.cpu().tolist()                  # ONE device-to-host copy: the scalars and the bad-label count (lout[12])
         self.plan.raise_on_fbn_error()
         # accumulated by simt_ntm_post over every micro-batch since the last call; data parallel: the exchange leaves total / world on every rank
-        bad = int(round(v[12] * (self.reducer.world if self.reducer is not None else 1)))
-        if bad:
-            self.lout[12] = 0.0
-        if bad:          # utils/loss.py:36 / nn.CrossEntropyLoss raise on such a target; the kernels skip the pixel and count it
+        # (the counter is cumulative and never reset on the device: a local reset by one rank would turn the next mean into a fraction on all)
+        bad = int(round(v[12] * (self.reducer.world if self.reducer is not None else 1))) - self._bad_reported
+        self._bad_reported += max(bad, 0)
+        if bad > 0:      # utils/loss.py:36 / nn.CrossEntropyLoss raise on such a target; the kernels skip the pixel and count it
             raise ValueError(f"{bad} label value(s) outside [0, {self.hp.num_classes}) that are not the ignore value 255")
         keys = ["total", "loss_p1", "loss_p2", "loss_y1", "loss_y2", "place", "convex", "volume", "anchor", "vol_ok"]
         return dict(zip(keys, v))
@@ -701,6 +710,7 @@ class WarmupTrainer:
         # labels outside [0, C) other than 255, ACCUMULATED over every micro-batch of every step until losses() reads and clears it (hout[15]
         # itself is overwritten by each head launch; nn.CrossEntropyLoss(ignore_index=255) raises on the first one, trainV1_warmup.py:217-224)
         self.bad_labels = torch.zeros(1, device=dev)
+        self._bad_reported = 0
         self.QP = ops.round_up(Cn, 8)
         self.g1 = torch.zeros(2, B, H, w, self.QP, device=dev)
         self.label = torch.zeros(B, H, W, device=dev, dtype=torch.int64)
@@ -784,10 +794,9 @@ class WarmupTrainer:
         step since the last call (a device-side accumulator; under data parallelism it rides in the gradient exchange)."""
         v = torch.cat([self.hout[:16], self.bad_labels]).cpu().tolist()
         self.plan.raise_on_fbn_error()
-        bad = int(round(v[16] * (self.reducer.world if self.reducer is not None else 1)))
-        if bad:
-            self.bad_labels.zero_()
-        if bad:          # nn.CrossEntropyLoss(ignore_index=255) raises on such a target (trainV1_warmup.py:217-224)
+        bad = int(round(v[16] * (self.reducer.world if self.reducer is not None else 1))) - self._bad_reported      # cumulative, never reset on the device
+        self._bad_reported += max(bad, 0)
+        if bad > 0:      # nn.CrossEntropyLoss(ignore_index=255) raises on such a target (trainV1_warmup.py:217-224)
             raise ValueError(f"{bad} label value(s) outside [0, {self.hp.num_classes}) that are not the ignore value 255")
         # `loss = loss / args.iter_size` (trainV1_warmup.py:227): the reported total is the scaled one, like SimTTrainer's
         return {"total": v[14] / self.hp.iter_size, "loss_seg1": v[0], "loss_seg2": v[1]}

@@ -76,7 +76,8 @@ class SimTSingleTrainer:
         self.grad_ready = self.plan.grad_ready
         # ---- NTM / W (index [1] of the two-slot descriptors; slot [0] = the auxiliary head, absent here)
         self.ntm = ntm.detach().to(dev, f32).clone()
-        self.ntm_grad = torch.zeros(Q, Cn, device=dev)
+        self._xchg = torch.zeros(16 + Q * Cn, device=dev)      # [lout | dNTM]: lout[12:] + dNTM is ONE collective under data parallelism (step.py)
+        self.ntm_grad = self._xchg[16:].view(Q, Cn)
         self.ntm_m, self.ntm_v = torch.zeros(Q, Cn, device=dev), torch.zeros(Q, Cn, device=dev)
         self.wraw = torch.full((Q, Q), 1.0 / (Q - 1.0), device=dev)
         self.w_m, self.w_v = torch.zeros(Q, Q, device=dev), torch.zeros(Q, Q, device=dev)
@@ -87,7 +88,8 @@ class SimTSingleTrainer:
         self.part = torch.zeros(lib.simt_head_nblk(B, H, W), lib.simt_head_part_floats(Q, Cn), device=dev)
         self.keys = torch.zeros(lib.simt_head_keys_count(), device=dev, dtype=torch.int64)
         self.hout = torch.zeros(lib.simt_head_hout_floats(Q, Cn), device=dev)
-        self.lout = torch.zeros(16, device=dev)
+        self.lout = self._xchg[:16]
+        self._bad_reported = 0
         self.QP = ops.round_up(Q, 8)
         self.g1 = torch.zeros(2, B, H, w, self.QP, device=dev)
         self.fixp = self.fix_logits_t if fix_logits else torch.zeros(B * h * w, self.ldf, device=dev)
@@ -112,6 +114,11 @@ class SimTSingleTrainer:
         ni.w_m[1], ni.w_v[1], ni.T_out[1] = self.w_m.data_ptr(), self.w_v.data_ptr(), self.T.data_ptr()
         ni.class_dist, ni.Q, ni.C, ni.steps, ni.single = self.cd.data_ptr(), Q, Cn, self.inner_steps, 1
         ni.beta1, ni.beta2, ni.eps = 0.9, 0.999, 1e-8
+        # every optimiser launch is guarded by the plan's sticky fused-BatchNorm error word (engine.TrunkPlan.fbn_error): once a fused launch has
+        # given up polling, SGD, both Adams and the W inner loop change nothing -- a state_dict saved after losses() raised holds the last good state
+        self._skip_word = getattr(self.plan, "fbn_err", None)
+        if self._skip_word is not None:
+            ni.skip_if = self._skip_word.data_ptr()
         self.inner_desc = ni
         npd = L.NtmPostDesc()
         npd.ntm[1], npd.w[1], npd.ntm_grad[1] = self.ntm.data_ptr(), self.wraw.data_ptr(), self.ntm_grad.data_ptr()
@@ -126,7 +133,7 @@ class SimTSingleTrainer:
             from .dp import BucketReducer, make_buckets
             sizes = {n: k for n, (_o, k) in self.plan.grad_offsets.items()}
             buckets = make_buckets(self.plan.grad_order, sizes, self.plan.grad_ready, bucket_elems=8 << 20)
-            self.reducer = BucketReducer(self.plan.flat_grad, buckets, group=self.pg, extra=[self.ntm_grad, self.lout[12:13]])
+            self.reducer = BucketReducer(self.plan.flat_grad, buckets, group=self.pg, extra=[self._xchg[12:]])
 
     # ------------------------------------------------------------------ optimiser
     def optim_groups(self):
@@ -213,7 +220,7 @@ class SimTSingleTrainer:
         d.first_step = 1 if self.it_done == 0 else 0
         L.call("simt_sgd_multi", C.byref(d), st)
         main.wait_event(ev_post)
-        ops.adam_step(self.ntm, self.ntm_grad, self.ntm_m, self.ntm_v, lr=lr_T, step=self.it_done + 1)
+        ops.adam_step(self.ntm, self.ntm_grad, self.ntm_m, self.ntm_v, lr=lr_T, step=self.it_done + 1, skip_if=self._skip_word)
         self.plan.repack()
         self.it_done += 1
         return self.lout
@@ -226,10 +233,9 @@ class SimTSingleTrainer:
         v = self.lout.cpu().tolist()                  # ONE device-to-host copy: the scalars and the bad-label count (lout[12])
         self.plan.raise_on_fbn_error()
         # accumulated by simt_ntm_post since the last call; data parallel: the gradient exchange leaves total / world on every rank
-        bad = int(round(v[12] * (self.reducer.world if self.reducer is not None else 1)))
-        if bad:
-            self.lout[12] = 0.0
-        if bad:          # the reference's nll_loss raises on such a target; the kernels skip the pixel and count it
+        bad = int(round(v[12] * (self.reducer.world if self.reducer is not None else 1))) - self._bad_reported      # cumulative, never reset on the device
+        self._bad_reported += max(bad, 0)
+        if bad > 0:      # the reference's nll_loss raises on such a target; the kernels skip the pixel and count it
             raise ValueError(f"{bad} label value(s) outside [0, {self.hp.num_classes}) that are not the ignore value 255")
         return {"total": v[0], "loss_p": v[2], "loss_y": v[4], "place": v[5], "convex": v[6], "volume": v[7], "anchor": v[8],
                 "vol_ok": v[9]}

@@ -83,6 +83,9 @@ def main(argv=None):
     pg = None
     if world > 1:
         import torch.distributed as dist
+        from simt_amd.engine import reserve_streams
+        reserve_streams(dev)                                    # the plan's streams take their hardware queues before RCCL makes its own
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")      # the conv tile lists leave 20 CUs to the collective's kernels (engine.TrunkPlan.cu_budget)
         dist.init_process_group("nccl", device_id=dev)
         pg = dist.group.WORLD
     if rank == 0:

@@ -221,10 +221,13 @@ def _world8_worker(rank, world, port, q):
         # rank r holds (r + 1) * g(i) + r: the mean over 8 ranks is 4.5 * g(i) + 3.5 in closed form (no 1.3 GB all-gather to check it)
         g = ((torch.arange(n, dtype=torch.float32) % 1021.0) - 510.0) / 64.0
         flat = g * float(rank + 1) + float(rank)
-        ntm = torch.full((2, 22, 19), float(rank + 1))
-        bad = torch.tensor([3.0 if rank == 5 else 0.0])      # rank 5 saw three bad labels this step (lout[12]; step.SimTTrainer)
+        # the product's layout (step.SimTTrainer._xchg[12:]): [bad-label count, 3 unused slots | dNTM1 | dNTM2] -- ONE extra collective
+        xchg = torch.zeros(4 + 2 * 22 * 19)
+        bad, ntm = xchg[0:1], xchg[4:].view(2, 22, 19)
+        ntm.fill_(float(rank + 1))
+        bad.fill_(3.0 if rank == 5 else 0.0)                 # rank 5 saw three bad labels this step (lout[12])
         red = BucketReducer(flat, make_buckets(t["order"], sizes, ready, bucket_elems=t["bucket_elems"]), group=dist.group.WORLD,
-                            extra=[ntm, bad])
+                            extra=[xchg])
         red.total_launches = t["backward_launches"]
         red.measure = True
         red.start()
@@ -242,7 +245,7 @@ def _world8_worker(rank, world, port, q):
               and abs(float(bad) * world - 3.0) < 1e-5                       # losses(): total = mean * world on EVERY rank, no collective
               and rep["bucket_released_launch"] == released_at == rep["bucket_ready_launch"]      # released at the very hook that made them final
               and rep["backward_launches"] == t["backward_launches"] and rep["buckets"] == 5 and rep["world"] == 8
-              and rep["bytes_per_step"] == (n + ntm.numel() + 1) * 4)
+              and rep["bytes_per_step"] == (n + ntm.numel() + 4) * 4 and rep["extra_tensors"] == 1)
         q.put((rank, bool(ok), released_at))
     finally:
         dist.destroy_process_group()

@@ -148,7 +148,9 @@ def test_fused_bn_whole_plan_bitwise_b4_768(dev):
         del tr
         torch.cuda.empty_cache()
     a, b = res
-    assert a["napply"] == b["napply"] - 46
+    # 46 applies ride in the fused launches; in the unfused plan layer 3's 23 bn2 applies run in conv3's operand path instead (round 6), and in
+    # BOTH plans so do bn2 of layers 1-2 (their conv2 launches are more than one round: never fused)
+    assert a["napply"] == b["napply"] - 23
     for k in ("x1", "x2", "a1", "a2", "y2", "flat", "rm"):
         assert torch.isfinite(a[k].float()).all(), k
         assert torch.equal(a[k], b[k]), f"{k}: plan with fused BatchNorm launches differs from the plan without"
@@ -281,12 +283,24 @@ def test_fused_bn_polling_timeout_sets_error_word_and_launch_ends(dev):
     # Break the protocol the way a starved launch looks from inside: the workgroups of ONE ticket shard (blockIdx % 8 == 0) draw tickets of a
     # different generation, so their granules never carry the tag the owners wait for -- exactly "some workgroups never arrived".
     bar[0] += 1000
+    # round 6: a launch that gave up writes NOTHING derived from its incomplete reads: the statistics the healthy launch left
+    # (mean / rstd / scale / shift and the running statistics it updates in place) and the rows of `out` of every workgroup whose poll gave up
+    rm, rv = torch.full((Cout,), 0.25, device=dev), torch.full((Cout,), 1.5, device=dev)
+    fd_r = _fbn(1, a, bar, momentum=BN_MOMENTUM, eps=BN_EPS, running_mean=rm, running_var=rv, **cst)
+    d.fbn = C.addressof(fd_r)
+    good = {n: v.clone() for n, v in cst.items()}
+    a.fill_(-7.0)
     t0 = time.perf_counter()
     ops.conv_fprop_desc(d)
     torch.cuda.synchronize()                        # returns: the launch ended by itself (the old kernel executed s_trap here)
     dt = time.perf_counter() - t0
     assert int(bar[L.FBN_ERR_WORD].item()) == 1, "the poller that timed out must set the error word"
     assert 1.0 < dt < 20.0, f"the launch should end within a poll period of the ~2 s timeout, took {dt:.1f} s"
+    for n in cst:
+        assert torch.equal(cst[n], good[n]), f"{n} was rewritten by a launch whose owners' polls gave up"
+    assert bool((rm == 0.25).all()) and bool((rv == 1.5).all()), "running statistics updated from partial sums"
+    assert bool((a.float() == -7.0).all()), "`out` written although no workgroup saw this launch's constants"
+    d.fbn = C.addressof(fd)
     # the word is sticky and shared: a later launch that polls in vain leaves at its first check instead of waiting 2 s again
     t0 = time.perf_counter()
     ops.conv_fprop_desc(d)
@@ -322,10 +336,17 @@ def test_fbn_error_word_makes_losses_raise_and_sgd_skip(dev):
     assert not tr.plan.fbn_error()
     n = "layer4.0.conv2.weight"
     w0 = tr.params[n].clone()
+    assert tr.inner_desc.skip_if == tr.plan.fbn_err.data_ptr()
+    snap = lambda: [t.clone() for k in range(2) for t in (tr.ntm[k], tr.ntm_m[k], tr.ntm_v[k], tr.wraw[k], tr.w_m[k], tr.w_v[k])]
+    s0 = snap()
     tr.plan.fbn_err.fill_(1)                        # what a timed-out fused launch leaves behind
     tr.step(img, lab, 1)
     torch.cuda.synchronize()
     assert torch.equal(tr.params[n], w0), "the optimiser must not apply gradients of a step whose fused BatchNorm bailed out"
+    # round 6: neither do the two Adam steps on NTM1 / NTM2 nor the W inner loop (parameters AND moments): a state_dict
+    # saved after losses() raised holds the last good state
+    for t0_, t1_ in zip(s0, snap()):
+        assert torch.equal(t0_, t1_), "NTM / W / an Adam moment moved while the fused-BatchNorm error word was set"
     with pytest.raises(RuntimeError, match="SIMT_BN_GRID=0"):
         tr.losses()
     tr.plan.fbn_err.zero_()
@@ -334,7 +355,10 @@ def test_fbn_error_word_makes_losses_raise_and_sgd_skip(dev):
     assert not torch.equal(tr.params[n], w0)
 
 
-def test_data_parallel_plans_default_to_two_pass_batchnorm(dev):
+def test_data_parallel_plans_keep_the_fused_batchnorm_and_can_switch_it_off(dev):
+    """Round 6: with 236-workgroup launches (160-row tiles) a data-parallel plan keeps the fused BatchNorm backward (engine.TrunkPlan: the
+    collective's kernels get the 20 CUs the tile plan leaves free; no circular wait is possible); SIMT_BN_GRID=0 is the documented switch
+    (bench.py forces it when several ranks share one GPU)."""
     st = so.recipe_state(so.state_shapes(19, 3, True, layers=(1, 1, 2, 1)), seed=1, head_scale=8.0)
     p = lambda: {k: v.clone().to(dev) for k, v in st.items()}
     kw = dict(dtype=BF, train=True, layers=(1, 1, 2, 1))
@@ -342,10 +366,99 @@ def test_data_parallel_plans_default_to_two_pass_batchnorm(dev):
     solo = TrunkPlan(p(), B4, 768, 768, multi_heads(19, 3, True), **kw)
     dp = TrunkPlan(p(), B4, 768, 768, multi_heads(19, 3, True), data_parallel=True, **kw)
     assert solo._fbn_on and solo._fbn_dirs == (2,) and solo.fbn_launches > 0
-    assert not dp._fbn_on and dp.fbn_launches == 0 and dp.fbn_err is None          # no waiting launch beside the collective's kernels
-    os.environ["SIMT_BN_GRID"] = "3"                # an explicit setting wins (opt in after a multi-GPU soak)
+    assert dp._fbn_on and dp._fbn_dirs == (2,) and dp.fbn_launches == solo.fbn_launches and dp.fbn_err is not None and dp.cu_budget == 240
+    os.environ["SIMT_BN_GRID"] = "0"
     try:
-        dp_on = TrunkPlan(p(), B4, 768, 768, multi_heads(19, 3, True), data_parallel=True, **kw)
+        dp_off = TrunkPlan(p(), B4, 768, 768, multi_heads(19, 3, True), data_parallel=True, **kw)
     finally:
         os.environ.pop("SIMT_BN_GRID")
-    assert dp_on._fbn_on and dp_on.fbn_launches > 0
+    assert not dp_off._fbn_on and dp_off.fbn_launches == 0 and dp_off.fbn_err is None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Round 6 (VERDICT r5 #1a): bn2's normalise + ReLU applied in conv3's OPERAND path (conv1x1_rows_kernel FL_STATS_INBN; simt_conv_desc.in_*):
+# the store waves rewrite every landed stage in LDS one period before the compute waves multiply it and write the activation out on the way.
+# Bitwise the two-pass result: simt_bn_apply -> conv with statistics (model/deeplab_multi.py:88-92).
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(256, 1024, B4, HW, HW), (128, 512, B4, HW, HW), (64, 256, B4, 193, 193), (256, 1024, 1, 9, 13)],
+                         ids=["layer3_256_1024", "layer2_128_512", "layer1_64_256", "tiny_ragged"])
+def test_operand_path_batchnorm_is_bitwise_the_two_pass(dev, shape):
+    Cin, Cout, B, H, W = shape
+    M = B * H * W
+    g = torch.Generator().manual_seed(Cin + M)
+    y2 = (torch.randn(B, H, W, Cin, generator=g) * 1.5).to(dev, BF)
+    wp = (torch.randn(Cout, Cin, generator=g) * (1.0 / Cin) ** 0.5).to(dev, BF)
+    scale = (torch.rand(Cin, generator=g) + 0.5).to(dev)
+    shift = (torch.randn(Cin, generator=g) * 0.4).to(dev)
+    nblk = (M + 127) // 128
+
+    def conv(x, inbn):
+        y = torch.full((M, Cout), float("nan"), device=dev, dtype=BF)
+        part = torch.full((nblk, 2, Cout), float("nan"), device=dev)
+        d = ops.make_conv_desc(x, wp, y, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=Cout, taps=[(0, 0)], Npad=Cout, tile_n=256, stats=part)
+        bn, tm, nst = C.c_int(), C.c_int(), C.c_int()
+        assert L.load().simt_conv_variant(C.byref(d), C.byref(bn), C.byref(tm), C.byref(nst)) == 5, "not the row-streaming kernel"
+        a = None
+        if inbn:
+            assert L.load().simt_conv_inbn_ok(C.byref(d)) == 1
+            a = torch.full((M, Cin), float("nan"), device=dev, dtype=BF)
+            d.in_scale, d.in_shift, d.in_out = scale.data_ptr(), shift.data_ptr(), a.data_ptr()
+        for _ in range(2):                          # twice: a persistent kernel must leave nothing behind
+            ops.conv_fprop_desc(d)
+        torch.cuda.synchronize()
+        return y, part, a
+    a_ref = torch.empty(M, Cin, device=dev, dtype=BF)
+    ops.bn_apply(y2.view(M, Cin), scale, shift, a_ref, M=M, Cn=Cin, relu=True)
+    y_ref, p_ref, _ = conv(a_ref.view(B, H, W, Cin), False)
+    y, p, a = conv(y2, True)
+    assert torch.equal(a, a_ref), f"activation written by the operand path differs from simt_bn_apply: {(a.float() - a_ref.float()).abs().max().item()}"
+    assert torch.equal(y, y_ref), f"conv output differs: {(y.float() - y_ref.float()).abs().max().item()}"
+    assert torch.equal(p, p_ref), "BatchNorm statistics differ"
+    assert float(a.float().min()) == 0.0 and float((a == 0).float().mean()) > 0.2          # the ReLU is live
+
+
+def test_operand_path_batchnorm_rejected_where_no_kernel_takes_it(dev):
+    """in_scale on a launch that is not the row-streaming statistics flavour: refused (SIMT_ERR_INVALID), never silently ignored."""
+    B, H, W, Cin, Cout = 1, 9, 13, 256, 256
+    x = torch.zeros(B, H, W, Cin, device=dev, dtype=BF)
+    taps = ops.conv_taps(3, 3, 2, 2)
+    wp = torch.zeros(Cout, len(taps) * Cin, device=dev, dtype=BF)
+    y = torch.zeros(B * H * W, Cout, device=dev, dtype=BF)
+    part = torch.zeros(1, 2, Cout, device=dev)
+    sc = torch.ones(Cin, device=dev)
+    d = ops.make_conv_desc(x, wp, y, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=Cout, taps=taps, Npad=Cout, tile_n=256, stats=part)
+    assert L.load().simt_conv_inbn_ok(C.byref(d)) == 0
+    d.in_scale, d.in_shift, d.in_out = sc.data_ptr(), sc.data_ptr(), x.data_ptr()
+    assert L.load().simt_conv_fprop(C.byref(d), ops.stream_ptr()) != 0
+
+
+def test_operand_path_batchnorm_plan_bitwise_b4_768(dev, monkeypatch):
+    """The production training plan (B=4, 768 x 768, bf16, full depth) with bn2 in conv3's operand path (default) against the plan with the
+    separate simt_bn_apply launches (SIMT_NO_INBN=1): 30 of 33 Bottlenecks take it (layer 4's Cin = 512 tile has a 3-slot ring), 30 launches
+    fewer in the forward list; logits of both heads and EVERY gradient bit-identical."""
+    st = so.recipe_state(so.state_shapes(19, 3, True), seed=1234, head_scale=8.0)
+    img, _ = so.synthetic_batch(B4, 768, 768, CD.numpy(), seed=77)
+    res = []
+    for off in ("0", "1"):
+        monkeypatch.setenv("SIMT_NO_INBN", off)
+        plan = TrunkPlan({k: v.clone().to(dev) for k, v in st.items()}, B4, 768, 768, multi_heads(19, 3, True), dtype=BF, train=True)
+        n_in = sum(1 for r in plan.block_io if r.get("inbn"))
+        n_apply = sum(1 for it in plan.fwd_list.items if it.tag == "simt_bn_apply")
+        out = plan.forward(img.to(dev))
+        gsd = torch.Generator().manual_seed(3)
+        for nm in sorted(plan.dlogits):                # a seeded upstream gradient of the heads' logits (live columns only)
+            t = plan.dlogits[nm]
+            t.zero_()
+            t[:, :22].copy_((torch.randn(t.shape[0], 22, generator=gsd) * 1e-3).to(dev))
+        plan.backward()
+        torch.cuda.synchronize()
+        rec = plan.block_io[10]
+        res.append(dict(x1=out["x1"].clone(), x2=out["x2"].clone(), flat=plan.flat_grad.clone(), n_in=n_in, n_apply=n_apply,
+                        a2=rec["a2"].clone(), rm=plan.p["layer3.5.bn3.running_mean"].clone()))
+        del plan
+        torch.cuda.empty_cache()
+    a, b = res
+    assert a["n_in"] == 30 and b["n_in"] == 0 and b["n_apply"] - a["n_apply"] == 30, (a["n_in"], a["n_apply"], b["n_apply"])
+    assert torch.isfinite(a["flat"]).all() and a["flat"].abs().max().item() > 0
+    assert torch.equal(a["a2"], b["a2"]) and torch.equal(a["x1"], b["x1"]) and torch.equal(a["x2"], b["x2"]) and torch.equal(a["rm"], b["rm"])
+    assert torch.equal(a["flat"], b["flat"]), "gradients differ between the operand-path BatchNorm plan and the two-pass plan"

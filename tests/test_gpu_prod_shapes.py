@@ -711,3 +711,69 @@ def test_full_depth_bf16_backward_is_bitwise_reproducible_b4(dev, monkeypatch):
     diff = [k for k in res[0] if not torch.equal(res[0][k], res[1][k])]
     assert not diff, f"{len(diff)} gradient tensors differ between two runs of the same backward: {diff[:5]}"
     assert all(torch.isfinite(v).all() for v in res[0].values())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 6: the CU budget of a tile list (simt_conv_desc.cu_budget; data-parallel plans leave CUs to the collective's kernels)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(256, 256, 3, 2), (1024, 256, 1, 1), (512, 512, 3, 4)], ids=["3x3_d2_256", "1x1_1024_256", "3x3_d4_512"])
+def test_cu_budget_changes_the_tile_list_not_the_results(dev, shape):
+    """The wide convs at M = 37 636 under CU budgets 256 (0), 248, 236, 200, 120: the plan is what pick_rows' cost model gives for that many
+    CUs -- 236 tiles of 160 rows for every budget >= 236 (ONE round of full 160-row MFMA tiles: the default), 295 tiles of 128 rows in two
+    rounds at 200, 236 tiles in two rounds at 120.  Every output element is bit-identical across budgets (an element's K reduction does not
+    depend on the tile it sits in); the BatchNorm partial sums are one slot per TILE, so their grouping -- hence the last bit of their fp32
+    rounding -- changes with the rows per tile: the per-channel totals agree to 1e-6."""
+    Cin, Cout, k, dil = shape
+    B, H, W = B4, HW, HW
+    M = B * H * W
+    g = torch.Generator().manual_seed(Cin + k)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev, BF)
+    taps = ops.conv_taps(k, k, dil, dil * (k // 2))
+    wp = (torch.randn(Cout, len(taps) * Cin, generator=g) * 0.02).to(dev, BF)
+    outs = {}
+    for budget, tiles in ((0, 236), (248, 236), (236, 236), (200, 295), (120, 236)):
+        y = torch.full((M, Cout), float("nan"), device=dev, dtype=BF)
+        part = torch.zeros((M + 127) // 128, 2, Cout, device=dev)
+        d = ops.make_conv_desc(x, wp, y, B=B, H=H, W=W, Cin=Cin, Ho=H, Wo=W, Cout=Cout, taps=taps, Npad=Cout, tile_n=256, stats=part)
+        d.cu_budget = budget
+        bn, tm, nst = C.c_int(), C.c_int(), C.c_int()
+        assert L.load().simt_conv_variant(C.byref(d), C.byref(bn), C.byref(tm), C.byref(nst)) == 2 and (bn.value, nst.value) == (256, 3)
+        assert tm.value == (4 if tiles == 295 else 5)
+        assert L.load().simt_conv_mtiles(C.byref(d)) == tiles, f"budget {budget}: {L.load().simt_conv_mtiles(C.byref(d))} pixel tiles"
+        ops.conv_fprop_desc(d)
+        torch.cuda.synchronize()
+        outs[budget] = (y, part.double().sum(0))
+    y0, s0 = outs[0]
+    assert torch.isfinite(y0.float()).all()
+    for budget in (248, 236, 200, 120):
+        y, s = outs[budget]
+        assert torch.equal(y, y0), f"budget {budget}: output differs from the full-chip plan"
+        rss = s0[1].sqrt().clamp_min(1e-30)
+        assert ((s[0] - s0[0]).abs() / (rss * M ** 0.5)).max().item() < 1e-6 and ((s[1] - s0[1]).abs() / s0[1]).max().item() < 1e-6
+
+
+def test_data_parallel_plan_carries_the_cu_budget(dev, monkeypatch):
+    """A plan built for a trainer with a process group plans its conv tile lists for 256 - NCCL_MAX_NCHANNELS CUs (16 assumed when unset);
+    SIMT_CU_BUDGET wins; a single-GPU plan keeps the whole device.  At M = 37 636 every budget down to 236 gives the default plan (236 tiles of
+    160 rows: it already leaves 20 CUs free); a budget of 200 changes the tile list -- same forward output bit for bit (frozen / eval plan)."""
+    st = so.recipe_state(so.state_shapes(19, 3, True, layers=(1, 1, 2, 1)), seed=1, head_scale=8.0)
+    p = lambda: {k: v.clone().to(dev) for k, v in st.items()}
+    kw = dict(dtype=BF, train=False, layers=(1, 1, 2, 1))
+    monkeypatch.delenv("SIMT_CU_BUDGET", raising=False)
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    solo = TrunkPlan(p(), B4, 768, 768, multi_heads(19, 3, True), **kw)
+    dp = TrunkPlan(p(), B4, 768, 768, multi_heads(19, 3, True), data_parallel=True, **kw)
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "8")
+    dp8 = TrunkPlan(p(), B4, 768, 768, multi_heads(19, 3, True), data_parallel=True, **kw)
+    monkeypatch.setenv("SIMT_CU_BUDGET", "200")
+    dpx = TrunkPlan(p(), B4, 768, 768, multi_heads(19, 3, True), data_parallel=True, **kw)
+    assert (solo.cu_budget, dp.cu_budget, dp8.cu_budget, dpx.cu_budget) == (0, 240, 248, 200)
+
+    def wide_tiles(plan):
+        return {L.load().simt_conv_mtiles(C.byref(it.keep)) for it in plan.fwd_list.items
+                if it.tag and it.tag.startswith("conv_igemm2_kernel<256, ") and "N256" in (it.shape or "")}
+    assert wide_tiles(solo) == {236} and wide_tiles(dp) == {236} and wide_tiles(dp8) == {236} and wide_tiles(dpx) == {295}
+    img, _ = so.synthetic_batch(B4, 768, 768, CD.numpy(), seed=3)
+    o = [pl.forward(img.to(dev))["x2"].clone() for pl in (solo, dp, dp8, dpx)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(o[0], t) for t in o[1:])
