@@ -342,8 +342,12 @@ def main():
     comm = None
     if red is not None:
         comm = red.report()              # the exchange of the timed steps (plus warm-up): bytes, buckets, exposed wait
+        comm["batchnorm_form"] = ("fused BatchNorm backward launches: %d -- the SAME form as the single-GPU plan (round 6; rounds 4-5 ran the two-pass "
+                                  "form under a process group, a built-in N = 1 -> N > 1 loss of ~0.3-0.6 ms per step)" % tr.plan.fbn_launches)
+        comm["cu_budget"] = tr.plan.cu_budget
+        comm["nccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
         comm["what"] = ("mean all-reduce of the applied prefix of the flat gradient buffer + the NTM gradients over "
-                        + ("RCCL/xGMI" if backend == "nccl" else backend) + ", bucketed, on a side HIP stream under the backward; "
+                        + ("RCCL/xGMI" if backend == "nccl" else backend) + ", bucketed, issued from the plan's side stream under the backward; "
                         "exposed_wait = time the optimiser-step stream sat waiting for it in BucketReducer.finish()")
         red.measure = False
     ms_step = dt / a.steps * 1e3

@@ -85,7 +85,7 @@ typedef struct {
                         * bf16 kernel loads its weight operand straight into registers (1 KB contiguous per wave-instruction)
                         * instead of staging it through LDS; results are bit-identical either way */
   const struct simt_fbn_desc* fbn;   /* optional (may be NULL): the train-mode BatchNorm behind this conv fused into the launch, below */
-  int32_t cu_budget;   /* ABI 2.  Compute units this launch may plan for; 0 = all of the device (256).  Data-parallel plans pass 256 minus the
+  int32_t cu_budget;   /* ABI 2.  Compute units this launch may plan for; 0 = all of the device (256); -1: A/B only, rounds 1-5 tile choice.  Data-parallel plans pass 256 minus the
                         * CUs the collective's persistent kernels hold (NCCL_MAX_NCHANNELS): the one-workgroup-per-CU tile lists of the wide convs
                         * are planned for that many CUs (M = 37 636: 236 tiles of 160 rows for any budget >= 236 -- the default plan already leaves
                         * 20 CUs free; a smaller budget re-plans).  Changes only the pixel rows per tile: every output element is bit-identical across budgets; the per-tile
@@ -270,6 +270,28 @@ int simt_bn_bwd_nblk(long M, int C);
 int simt_bn_bwd(const simt_bn_bwd_desc* d, simt_stream_t stream);
 
 /* ---- stem: 7x7/s2 conv via im2col, BN+ReLU+MaxPool(3,2,1,ceil) (model/deeplab_multi.py:127-133,172-176) --- */
+/* ---- direct 7x7 stride-2 pad-3 stem convolution (round 6; model/deeplab_multi.py:127,172-173: conv1 of the ResNets) ----
+ * Replaces simt_im2col_stem + simt_conv_fprop on the im2col matrix for the bf16 throughput mode: the image patch of an 8 x 32 output tile is
+ * staged in LDS as [row][col][channel], a filter ROW (7 taps x 3 channels = 21 contiguous values) is one 32-deep MFMA k-step.  Up to TWO weight
+ * sets in one launch (the trainable and the frozen network convolve the same image, tools/trainV2_simt.py:351-353,370): per set
+ *   y[s][m][0..63] = act( sum_{r,s,c} x[b][c][2 oy - 3 + r][2 ox - 3 + s] * w[s][o][r][s*3 + c] + bias[s][o] ),  bf16 NHWC,
+ * stats[s] (optional): [simt_stem7_tiles][2][64] per-tile sum / sum of squares of the STORED values (BatchNorm batch statistics; hand
+ * simt_stem7_tiles(...) as the slot count to simt_bn_finalize).  w[s]: simt_stem7_pack(conv1.weight [64][3][7][7] fp32, per-channel scale
+ * or NULL) -> bf16 [64][7][32].  The weight gradient of the stem still runs on the im2col matrix (built in the backward). */
+typedef struct {
+  const float* x;          /* [B][3][H][W] fp32 (the reference's NCHW input tensor) */
+  int32_t B, H, W, Ho, Wo;
+  int32_t nsets;           /* 1 | 2 */
+  const void* w[2];
+  void* y[2];              /* [B*Ho*Wo][64] bf16 */
+  const float* bias[2];    /* [64] or NULL */
+  int32_t relu[2];
+  float* stats[2];         /* or NULL */
+} simt_stem_desc;
+int simt_stem7_tiles(int B, int Ho, int Wo);
+int simt_stem7_pack(const float* w_oihw, const float* cscale, void* dst, simt_stream_t stream);
+int simt_stem7_fwd(const simt_stem_desc* d, simt_stream_t stream);
+
 int simt_im2col_stem(const float* x_nchw, void* A, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW,
                      int stride, int pad, int ldk, int dtype, simt_stream_t stream);
 int simt_bn_relu_maxpool(const void* y, const float* scale, const float* shift, void* p, unsigned char* idx, int B,

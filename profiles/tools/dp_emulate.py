@@ -64,7 +64,7 @@ def main():
     hp = Hyper(open_classes=K, lr=6e-4, lr_T=6e-3)
     cfg = {"n": 0, "rate": 300.0, "lds": 0}
     if a.plan == "first":
-        os.environ["SIMT_PICK_ROWS_FIRST"] = "1"                # read once per process by the library
+        os.environ["SIMT_PICK_ROWS_FIRST"] = "1"                # read by engine.TrunkPlan at construction (cu_budget = -1)
     if a.bn_grid is not None:
         os.environ["SIMT_BN_GRID"] = a.bn_grid
     tr = SimTTrainer(ms.reference_init(ms.state_shapes(19, K, True), seed=1234), ms.reference_init(ms.state_shapes(19, 0, False), seed=1234),

@@ -72,6 +72,12 @@ class HeadDesc(C.Structure):
                 ("single", i32), ("up_half_pixel", i32), ("fix_logits", i32), ("conf_out", c_p), ("label_ws", c_p)]
 
 
+class StemDesc(C.Structure):
+    """simt_stem_desc: the direct 7x7 stem convolution for up to two weight sets."""
+    _fields_ = [("x", c_p), ("B", i32), ("H", i32), ("W", i32), ("Ho", i32), ("Wo", i32), ("nsets", i32),
+                ("w", c_p * 2), ("y", c_p * 2), ("bias", c_p * 2), ("relu", i32 * 2), ("stats", c_p * 2)]
+
+
 class NtmInnerDesc(C.Structure):
     _fields_ = [("ntm", c_p * 2), ("w", c_p * 2), ("ntm_grad", c_p * 2), ("w_m", c_p * 2), ("w_v", c_p * 2),
                 ("T_out", c_p * 2), ("class_dist", c_p),
@@ -104,6 +110,9 @@ SIGNATURES = {
     "simt_last_error": (C.c_char_p, []),
     "simt_abi_version": (_I, []),
     "simt_conv_fprop": (_I, [C.POINTER(ConvDesc), c_p]),
+    "simt_stem7_tiles": (_I, [_I, _I, _I]),
+    "simt_stem7_pack": (_I, [c_p, c_p, c_p, c_p]),
+    "simt_stem7_fwd": (_I, [C.POINTER(StemDesc), c_p]),
     "simt_conv_mtiles": (_I, [C.POINTER(ConvDesc)]),
     "simt_conv_inbn_ok": (_I, [C.POINTER(ConvDesc)]),
     "simt_conv_fprop_pair": (_I, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), c_p]),

@@ -328,10 +328,10 @@ static int launch_conv2(const Conv2KArgs& k, hipStream_t st) {
 // whatever it is given: at M = 37 636 rounds 1-5 took the first one-round size, 148 rows -> 255 tiles, i.e. 7.5 % of the matrix work of every
 // wide conv spent on rows that do not exist -- on a chip whose clock is set by the energy of exactly those launches (profiles/r05_power_clock.txt)
 // -- and left ONE CU to the other stream.  160 rows -> 236 tiles: no padding work, 20 CUs for the weight gradients / the frozen net beside it:
-// the step 24.13 -> 23.68 ms (same box, alternating; profiles/r06_tile_rows.txt).  SIMT_PICK_ROWS_FIRST=1 restores the old choice (A/B).
+// the step 24.13 -> 23.68 ms (same box, alternating; profiles/r06_tile_rows.txt).  cu_budget = -1 restores the old choice (A/B).
 static void pick_rows(int M, int ntn, bool allow160, int* rows, int* tm, int cu_budget) {
   const int CUS = (cu_budget > 0 && cu_budget < 256) ? cu_budget : 256;      // simt_conv_desc.cu_budget: CUs left beside a collective's kernels
-  static const int first = getenv("SIMT_PICK_ROWS_FIRST") ? atoi(getenv("SIMT_PICK_ROWS_FIRST")) : 0;
+  const bool first = cu_budget == -1;        // A/B only (engine: SIMT_PICK_ROWS_FIRST=1 at plan construction): rounds 1-5's first-minimum choice
   long best = -1;
   *rows = 128; *tm = 4;
   for (int r = 128; r <= (allow160 ? 160 : 128); r += 4) {

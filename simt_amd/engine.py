@@ -374,7 +374,9 @@ class TrunkPlan:
         # process group exists; at most 20 are given up): any budget >= 236 leaves the plan as it is, so the budget costs nothing; a smaller one
         # re-plans the tile lists (profiles/r06_dp_emulation.txt).  SIMT_CU_BUDGET=n sets it explicitly (0: the whole device).
         cb = os.environ.get("SIMT_CU_BUDGET")
-        if cb is not None:
+        if os.environ.get("SIMT_PICK_ROWS_FIRST") == "1":
+            self.cu_budget = -1                        # A/B only: rounds 1-5's tile plan (255 tiles of 148 rows at M = 37 636)
+        elif cb is not None:
             self.cu_budget = int(cb)
         elif data_parallel:
             self.cu_budget = 256 - max(0, min(20, int(os.environ.get("NCCL_MAX_NCHANNELS", "16"))))
@@ -600,21 +602,76 @@ class TrunkPlan:
         self.saved = {}
         # ---- stem (model/deeplab_multi.py:127-133,172-176)
         KS = 192
-        if self.stem_from is not None:
+        # Round 6 (VERDICT r5 #1c), OPT-IN with SIMT_DIRECT_STEM=1: the bf16 plans convolve the image DIRECTLY (csrc/stem7.hip: the patch of an
+        # 8 x 32 output tile in LDS, one filter row per MFMA k-step) instead of writing a 226-MB im2col matrix and running a 64-column GEMM over it
+        # per network; a frozen plan built with stem_from=<trainable plan> joins that plan's launch as its second weight set (both networks see the
+        # same image).  Built, parity-green at the storage-format bar, and MEASURED NOT FASTER in the step: the direct launch takes 111 us for both
+        # networks (LDS-read bound: a B fragment feeds only two MFMAs) where im2col + two GEMMs take 134 + 62 + 60 us of which the frozen GEMM
+        # already overlaps; and the stem's weight gradient -- which still multiplies the im2col matrix -- then has to build that matrix in the
+        # backward (side stream, at its start).  24.149 ms against 24.057 ms for the default (same box, six alternating rounds,
+        # profiles/r06_direct_stem.txt).  What would make it pay is a direct weight-gradient kernel (no im2col matrix at all: DESIGN.md section 9).
+        self.direct_stem = dt == torch.bfloat16 and os.environ.get("SIMT_DIRECT_STEM", "0") == "1"
+        y0 = self.new(M0, 64)
+        pool = self.new(Mp, 64)
+        pidx = self.new(Mp, 64, dtype=torch.uint8)
+        self.saved["stem.y"], self.saved["stem.pool"], self.saved["stem.idx"] = y0, pool, pidx
+        if self.direct_stem:
+            w7 = self.new(64 * 7 * 32)
+            tiles = L.load().simt_stem7_tiles(B, H0, W0)
+            if self.train:
+                s = self._new_bn("bn1", M0, 64)
+                assert tiles <= s["nblk"]
+                s["nblk"] = tiles                      # one statistics slot per 8 x 32 tile
+                self.pack_list.add("simt_stem7_pack", self.p["conv1.weight"].data_ptr(), None, w7.data_ptr())
+                mine = dict(w=w7, y=y0, bias=None, relu=0, stats=s["part"])
+            else:
+                sc, sh = self._plan_fold("bn1", 64)
+                self.pack_list.add("simt_stem7_pack", self.p["conv1.weight"].data_ptr(), sc.data_ptr(), w7.data_ptr())
+                mine = dict(w=w7, y=y0, bias=sh, relu=1, stats=None)
+
+            def put(d, i, m):
+                d.w[i], d.y[i], d.relu[i] = m["w"].data_ptr(), m["y"].data_ptr(), m["relu"]
+                d.bias[i] = m["bias"].data_ptr() if m["bias"] is not None else None
+                d.stats[i] = m["stats"].data_ptr() if m["stats"] is not None else None
+            if self.stem_from is not None:
+                o = self.stem_from
+                assert (o.B, o.H, o.W, o.dtype) == (B, self.H, self.W, dt) and o.direct_stem and o.stem_desc.nsets == 1
+                self.x_in = o.x_in
+                put(o.stem_desc, 1, mine)              # second weight set of the partner's launch (its fwd_list item 0)
+                o.stem_desc.nsets = 2
+                o.fwd_list.items[0].flops *= 2.0
+                o._stem_partner_keep = mine
+            else:
+                self.x_in = self.new(B, 3, self.H, self.W, dtype=torch.float32)
+                d = L.StemDesc()
+                d.x, d.B, d.H, d.W, d.Ho, d.Wo, d.nsets = self.x_in.data_ptr(), B, self.H, self.W, H0, W0, 1
+                put(d, 0, mine)
+                self.stem_desc = d
+                f.add_desc("simt_stem7_fwd", d, tag="simt_stem7_fwd", flops=2.0 * M0 * 64 * 147,
+                           nbytes=float(B * 3 * self.H * self.W * 4 + M0 * 64 * 2), shape=f"M{M0} N64 K147 direct 7x7 s2 (one launch for the networks that share the image)")
+            if self.train:
+                self._bn_train(f, "bn1", y0, M0, 64)
+                f.add("simt_bn_relu_maxpool", y0.data_ptr(), s["scale"].data_ptr(), s["shift"].data_ptr(), pool.data_ptr(),
+                      pidx.data_ptr(), B, H0, W0, 64, Hp, Wp, ops.dt_code(dt))
+            else:
+                one, zero = self.new(64, dtype=torch.float32), self.new(64, dtype=torch.float32, zero=True)
+                one.fill_(1.0)
+                f.add("simt_bn_relu_maxpool", y0.data_ptr(), one.data_ptr(), zero.data_ptr(), pool.data_ptr(),
+                      pidx.data_ptr(), B, H0, W0, 64, Hp, Wp, ops.dt_code(dt))
+        elif self.stem_from is not None:
             o = self.stem_from
-            assert (o.B, o.H, o.W, o.dtype) == (B, self.H, self.W, dt)
+            assert (o.B, o.H, o.W, o.dtype) == (B, self.H, self.W, dt) and not o.direct_stem
             self.x_in, A = o.x_in, o.saved["stem.A"]
+            self.saved["stem.A"] = A
         else:
             self.x_in = self.new(B, 3, self.H, self.W, dtype=torch.float32)
             A = self.new(M0, KS)
             f.add("simt_im2col_stem", self.x_in.data_ptr(), A.data_ptr(), B, 3, self.H, self.W, H0, W0, 7, 7, 2, 3, KS,
                   ops.dt_code(dt))
-        self.saved["stem.A"] = A
-        y0 = self.new(M0, 64)
-        pool = self.new(Mp, 64)
-        pidx = self.new(Mp, 64, dtype=torch.uint8)
-        self.saved["stem.y"], self.saved["stem.pool"], self.saved["stem.idx"] = y0, pool, pidx
-        if self.train:
+            self.saved["stem.A"] = A
+        if self.direct_stem:
+            pass
+        elif self.train:
             wi = self._plan_pack("conv1", 64, 3, 7, K_cin=KS)
             s = self._new_bn("bn1", M0, 64)
             self._conv(f, A, wi, y0, Bn=1, Hi=1, Wi=M0, Cin=KS, Ho=1, Wo=M0, Cout=64, taps=[(0, 0)], stats=s["part"],
@@ -991,6 +1048,14 @@ class TrunkPlan:
         for hd in self.heads:
             heads_by_layer.setdefault(hd.feat_layer, []).append(hd)
 
+        if self.direct_stem and self.grads_from_layer == 0:
+            # the forward convolved the image directly: the im2col matrix exists only for the stem's weight gradient at the very end of this
+            # list.  Built FIRST, on the side stream (idle between the frozen forward and the first weight gradients): an HBM-bound 134-us pass
+            # beside the heads' MFMA-bound gradient GEMMs instead of on the tail of the backward
+            A = self.buf("g.stemA", B * self.H0 * self.W0, 192)
+            self.saved["stem.A"] = A
+            b.add("simt_im2col_stem", self.x_in.data_ptr(), A.data_ptr(), B, 3, self.H, self.W, self.H0, self.W0, 7, 7, 2, 3, 192,
+                  ops.dt_code(dt), stream=1)
         n_blocks = len(self.block_io)
         self.grad_ready = {}  # param name -> number of backward launches after which its gradient is final
         self.bwd_marks = {}   # block name -> (first launch, end launch, dz buffer, dx buffer): debugging / DP buckets

@@ -81,7 +81,9 @@ class SimTTrainer:
         # the frozen model sees the same image: it reuses the trainable plan's stem im2col matrix (one im2col per micro-batch)
         self.fixed = TrunkPlan(self.fixed_params, B, H, W, multi_heads(Cn, 0, False), dtype=dtype, train=False,
                                stem_from=self.plan, data_parallel=process_group is not None, **kw)      # (same CU budget = same tile lists as the trainable plan)
-        assert self.plan.fwd_list.items[0].tag == "simt_im2col_stem"
+        # item 0 of the trainable forward feeds BOTH nets: the direct stem launch with the frozen net as its second weight set (bf16), or the im2col
+        assert self.plan.fwd_list.items[0].tag in ("simt_stem7_fwd", "simt_im2col_stem")
+        assert self.plan.fwd_list.items[0].tag == "simt_im2col_stem" or self.plan.stem_desc.nsets == 2
         import os
         # hipGraphs of the three launch lists (frozen forward, trainable forward, backward with its two streams): the host spends
         # ~18 us per eager launch (ctypes + Python), ~1 000 launches per step -- most of a 28 ms step, and the ORDER in which the two
@@ -255,7 +257,7 @@ class SimTTrainer:
         """Steps 2-5 of the iteration for one micro-batch: both forwards, fused head, NTM terms, backward."""
         self.plan.x_in.copy_(image, non_blocking=True)
         self.label.copy_(label, non_blocking=True)
-        # the stem im2col (first launch of the trainable forward) feeds BOTH nets: run it before forking
+        # the stem launch (first launch of the trainable forward: direct conv of both nets, or the im2col they share) feeds BOTH nets: run it before forking
         head = self.plan.fwd_list.items[0]
         rc = head.fn(*head.args, st)
         if rc != 0:

@@ -42,7 +42,7 @@ def test_ctypes_struct_sizes_match_header():
     structs = {"simt_conv_desc": _lib.ConvDesc, "simt_wgrad_desc": _lib.WgradDesc, "simt_bn_bwd_desc": _lib.BnBwdDesc,
                "simt_head_desc": _lib.HeadDesc, "simt_ntm_inner_desc": _lib.NtmInnerDesc,
                "simt_ntm_post_desc": _lib.NtmPostDesc, "simt_sgd_desc": _lib.SgdDesc, "simt_tap_desc": _lib.TapDesc,
-               "simt_wgrad_reduce_job": _lib.WgradReduceJob, "simt_fbn_desc": _lib.FbnDesc}
+               "simt_wgrad_reduce_job": _lib.WgradReduceJob, "simt_fbn_desc": _lib.FbnDesc, "simt_stem_desc": _lib.StemDesc}
     prog = '#include <stdio.h>\n#include "simt_hip.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in structs) + "return 0;}"
     with tempfile.TemporaryDirectory() as td:
