@@ -127,6 +127,30 @@ def conv_wgrad_desc(d):
     L.call("simt_conv_wgrad", C.byref(d), stream_ptr())
 
 
+def _wgrad_cus():
+    """CUs the weight-gradient launches plan their rounds for (SIMT_WGRAD_CUS at plan construction).  Round 6: 128, not the 256 the device has --
+    the weight gradients run on the side stream BESIDE the dgrad / BatchNorm chain, which is the critical path of the backward (13.5 ms of chain
+    against ~4 ms of weight-gradient work): split counts planned for half the chip give the minor launches (layer 4's group, layer3.0's, the
+    heads', layer 1-2's, the stem's) about half the workgroups and half the fp32 slab traffic; they take longer alone (layer3.0's group 178 ->
+    329 us) and the step is 0.25-0.3 ms SHORTER (profiles/r06_wgrad_split.txt: same-box A/B on three boxes).  The seven 255-workgroup launches
+    of layer 3 keep their plan (5 splits of 51 tiles) under either setting; forcing THEM small costs +1.2 ms."""
+    import os
+    return int(os.environ.get("SIMT_WGRAD_CUS", "128"))
+
+
+def _wgrad_epi():
+    """Per-workgroup fixed cost of a weight-gradient launch in 64-pixel stages (prologue + the fp32 tile written to its slab + its share of the
+    reduce pass): the constant of the split-count cost model (SIMT_WGRAD_EPI_STAGES at plan construction)."""
+    import os
+    return int(os.environ.get("SIMT_WGRAD_EPI_STAGES", "10"))
+
+
+def _wgrad_max_wg():
+    """Upper bound on the workgroups of ONE weight-gradient launch (SIMT_WGRAD_MAX_WG at plan construction; 0 = none)."""
+    import os
+    return int(os.environ.get("SIMT_WGRAD_MAX_WG", "0"))
+
+
 def wgrad_nsplit(M, Cd, Ktot, dtype, target_wg=768):
     """Split factor over the pixel dimension.  bf16 / Cd >= 64 / Ktot >= 64 runs the 128x256-tile kernel with one
     workgroup per CU: aim at a whole number of 256-CU rounds; otherwise the 128x128 kernel at ~3 workgroups per CU."""
@@ -135,9 +159,11 @@ def wgrad_nsplit(M, Cd, Ktot, dtype, target_wg=768):
         max_split = max(1, M // (64 * 8))
         best, best_cost = 1, None
         for ns in range(1, min(max_split, 256) + 1):     # one-tile problems (layer1, stem) need up to 256 splits to fill the chip
-            rounds = -(-tiles * ns // 256)
+            if _wgrad_max_wg() and ns > 1 and tiles * ns > _wgrad_max_wg():
+                break
+            rounds = -(-tiles * ns // _wgrad_cus())
             stages = -(-M // (ns * 64))
-            cost = rounds * (stages + 6)            # + epilogue/prologue per workgroup
+            cost = rounds * (stages + _wgrad_epi())            # + epilogue/prologue per workgroup
             if best_cost is None or cost < best_cost:
                 best, best_cost = ns, cost
         return best
@@ -153,9 +179,11 @@ def wgrad_group_nsplit(M, tiles, max_cap=256):
     max_split = max(1, M // (64 * 8))
     best, best_cost = 1, None
     for ns in range(1, min(max_split, max_cap) + 1):
-        rounds = -(-tiles * ns // 256)
+        if _wgrad_max_wg() and ns > 1 and tiles * ns > _wgrad_max_wg():
+            break
+        rounds = -(-tiles * ns // _wgrad_cus())
         stages = -(-M // (ns * 64))
-        cost = rounds * (stages + 6)
+        cost = rounds * (stages + _wgrad_epi())
         if best_cost is None or cost < best_cost:
             best, best_cost = ns, cost
     return best
