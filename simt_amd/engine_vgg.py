@@ -40,8 +40,10 @@ def vgg_head(num_classes, cin=1024):
 class VggPlan(TrunkPlan):
     def __init__(self, params, B, H, W, num_classes, *, dtype=torch.bfloat16, train=True, device=None, vgg_layers=VGG_LAYERS, data_parallel=False):
         self.vgg_layers = list(vgg_layers)
-        super().__init__(params, B, H, W, vgg_head(num_classes, self.vgg_layers[-1][2]), dtype=dtype, train=train, layers=(0, 0, 0, 0),
-                         device=device, data_parallel=data_parallel)
+        # (weight-gradient split counts planned for the whole chip: no BatchNorm / dgrad chain here for them to hide behind -- ops.wgrad_plan)
+        with ops.wgrad_plan(256, 6):
+            super().__init__(params, B, H, W, vgg_head(num_classes, self.vgg_layers[-1][2]), dtype=dtype, train=train, layers=(0, 0, 0, 0),
+                             device=device, data_parallel=data_parallel)
 
     # ------------------------------------------------------------------ forward
     def _build_forward(self):

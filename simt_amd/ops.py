@@ -127,6 +127,25 @@ def conv_wgrad_desc(d):
     L.call("simt_conv_wgrad", C.byref(d), stream_ptr())
 
 
+_WGRAD_PLAN = {"cus": 128, "epi": 10}      # split-count cost model of the weight-gradient launches; plans may override (wgrad_plan)
+
+
+class wgrad_plan:
+    """with ops.wgrad_plan(cus, epi): ... -- the cost-model constants for the plans built inside (engine_vgg: the BatchNorm-free VGG trunk has no
+    long dgrad / BatchNorm chain for the weight gradients to hide behind; its step is 6 % FASTER with the whole-chip plan (256, 6): 661 vs 620
+    images/s, profiles/r06_wgrad_split.txt).  SIMT_WGRAD_CUS / SIMT_WGRAD_EPI_STAGES override everything."""
+
+    def __init__(self, cus, epi):
+        self.new = {"cus": cus, "epi": epi}
+
+    def __enter__(self):
+        self.old = dict(_WGRAD_PLAN)
+        _WGRAD_PLAN.update(self.new)
+
+    def __exit__(self, *exc):
+        _WGRAD_PLAN.update(self.old)
+
+
 def _wgrad_cus():
     """CUs the weight-gradient launches plan their rounds for (SIMT_WGRAD_CUS at plan construction).  Round 6: 128, not the 256 the device has --
     the weight gradients run on the side stream BESIDE the dgrad / BatchNorm chain, which is the critical path of the backward (13.5 ms of chain
@@ -135,14 +154,14 @@ def _wgrad_cus():
     329 us) and the step is 0.25-0.3 ms SHORTER (profiles/r06_wgrad_split.txt: same-box A/B on three boxes).  The seven 255-workgroup launches
     of layer 3 keep their plan (5 splits of 51 tiles) under either setting; forcing THEM small costs +1.2 ms."""
     import os
-    return int(os.environ.get("SIMT_WGRAD_CUS", "128"))
+    return int(os.environ.get("SIMT_WGRAD_CUS", _WGRAD_PLAN["cus"]))
 
 
 def _wgrad_epi():
     """Per-workgroup fixed cost of a weight-gradient launch in 64-pixel stages (prologue + the fp32 tile written to its slab + its share of the
     reduce pass): the constant of the split-count cost model (SIMT_WGRAD_EPI_STAGES at plan construction)."""
     import os
-    return int(os.environ.get("SIMT_WGRAD_EPI_STAGES", "10"))
+    return int(os.environ.get("SIMT_WGRAD_EPI_STAGES", _WGRAD_PLAN["epi"]))
 
 
 def _wgrad_max_wg():
