@@ -102,7 +102,7 @@ def reserve_streams(device=None):
     found the plan's side stream (weight gradients, frozen forward) on the MAIN stream's queue: 26.18 ms per step instead of 24.06, the whole
     two-stream overlap gone.  Call this before torch.distributed.init_process_group / before creating other streams (bench.py and the tools do);
     TrunkPlan calls it too, which is early enough in a single-GPU process.  Idempotent."""
-    if not torch.cuda.is_available():
+    if not torch.cuda.is_available() or os.environ.get("SIMT_NO_RESERVE_STREAMS") == "1":      # (the switch: A/B only)
         return
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     if dev in _RESERVED:
