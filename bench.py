@@ -35,8 +35,8 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense, /opt/skills/guides/MI355X_MICROARCH.md
 FLOP_PER_IMAGE_768 = 3.33e12                            # conv MACs x2, fixed fwd + fwd + bwd
-PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json")          # rocprofv3 PMC summaries (profiles/collect.sh), stamped with the sha256 of the library they
-PMC_MFMA_FILES = ("r05_pmc_mfma.json", "r04_pmc_mfma.json")        # were collected on: used only when that is the library this run has loaded
+PMC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json")          # rocprofv3 PMC summaries (profiles/collect.sh), stamped with the sha256 of the library they
+PMC_MFMA_FILES = ("r06_pmc_mfma.json", "r05_pmc_mfma.json", "r04_pmc_mfma.json")        # were collected on: used only when that is the library this run has loaded
 
 
 def pmc_lookup(files, kernel, key):
