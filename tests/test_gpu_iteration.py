@@ -359,3 +359,43 @@ def test_out_of_range_label_is_reported(dev):
     tr2.step([img.to(dev), img.to(dev)], [lab.to(dev), lab_ok.to(dev)], 0)      # bad labels in the FIRST micro-batch only
     with pytest.raises(ValueError, match="2 label value"):
         tr2.losses()
+
+
+@pytest.mark.parametrize("scope", [0, 2, 1])
+def test_device_scope_events_order_two_streams_under_load(dev, scope):
+    """the launch lists order their two HIP streams with the library's events (simt_event_create): scope 0 = hipEventReleaseToDevice
+    (the documented device-scope release, default since round 6), 2 = hipEventDisableSystemFence (round 5's form), 1 = system scope.  A
+    producer / consumer stress with LARGE buffers (64 MB: far beyond the L2, so stale lines would show) and many iterations: stream A writes a new
+    pattern, records; stream B waits, copies it out and checksums; B records, A waits before it overwrites (write-after-read).  Every iteration's
+    checksum must be exactly that iteration's pattern."""
+    import ctypes as C
+    from simt_amd import _lib as L
+    n = 16 << 20                                   # 16 M fp32 = 64 MB
+    a, b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    buf = torch.zeros(n, device=dev)
+    out = torch.zeros(n, device=dev)
+    sums = torch.zeros(200, device=dev, dtype=torch.float64)
+    ev_w, ev_r = C.c_void_p(), C.c_void_p()
+    L.call("simt_event_create", C.byref(ev_w), scope)
+    L.call("simt_event_create", C.byref(ev_r), scope)
+    torch.cuda.synchronize()
+    try:
+        for it in range(200):
+            with torch.cuda.stream(a):
+                if it:
+                    L.call("simt_stream_wait_event", a.cuda_stream, ev_r)      # B has read the previous pattern
+                buf.fill_(float(it + 1))
+                buf[::4097] += 0.5                                                 # (a second kernel on the same buffer)
+                L.call("simt_event_record", ev_w, a.cuda_stream)
+            with torch.cuda.stream(b):
+                L.call("simt_stream_wait_event", b.cuda_stream, ev_w)
+                out.copy_(buf)
+                sums[it] = out.sum(dtype=torch.float64)
+                L.call("simt_event_record", ev_r, b.cuda_stream)
+        torch.cuda.synchronize()
+        k = len(range(0, n, 4097))
+        want = torch.tensor([(it + 1.0) * n + 0.5 * k for it in range(200)], dtype=torch.float64)
+        assert torch.equal(sums.cpu(), want), f"scope {scope}: first bad iteration {int((sums.cpu() != want).nonzero()[0])}"
+    finally:
+        L.call("simt_event_destroy", ev_w)
+        L.call("simt_event_destroy", ev_r)
