@@ -1035,6 +1035,8 @@ class TrunkPlan:
             kt = len(hd.taps) * hd.cin
             self._slab_cap = max(self._slab_cap, ops.wgrad_nsplit(Mh, cd, kt, dt) * cd * kt)
             if getattr(hd, "expanded", False):
+                with ops.wgrad_plan(256, 6):       # (the plan _build_head_bwd uses for the tap-expanded heads' weight gradients)
+                    self._slab_cap = max(self._slab_cap, ops.wgrad_nsplit(Mh, hd.nexp, hd.cin, dt) * hd.nexp * hd.cin)
                 self._slab_cap = max(self._slab_cap, ops.wgrad_nsplit(Mh, hd.nexp, hd.cin, dt) * hd.nexp * hd.cin)
 
         # upstream gradients of the head logits, in the conv dtype, K-padded for the dgrad GEMM
@@ -1312,7 +1314,13 @@ class TrunkPlan:
         ops._fill_taps(td.dy, td.dx, hd.taps)
         b.add_desc("simt_tap_scatter", td)
         b.wait(b.record(0), 1)
-        nsplit = ops.wgrad_nsplit(Mh, nexp, hd.cin, self.dtype)
+        # (the heads' weight gradients are the FIRST ones of the backward: nothing of the dgrad / BatchNorm chain runs beside them yet, so they
+        # keep the whole-chip split plan; SIMT_HEAD_WGRAD_HALF=1: planned like the trunk's, for half the chip -- A/B)
+        if os.environ.get("SIMT_HEAD_WGRAD_HALF") == "1":
+            nsplit = ops.wgrad_nsplit(Mh, nexp, hd.cin, self.dtype)
+        else:
+            with ops.wgrad_plan(256, 6):
+                nsplit = ops.wgrad_nsplit(Mh, nexp, hd.cin, self.dtype)
         assert nsplit * nexp * hd.cin <= self._slab_cap
         slab = self.buf("wgrad.slab", self._slab_cap, dtype=torch.float32)
         wd = ops.make_wgrad_desc(G, hd.feat, slab, B=B, H=hd.h, W=hd.w, Cin=hd.cin, Ho=hd.h, Wo=hd.w, Cd=nexp, taps=[(0, 0)],
