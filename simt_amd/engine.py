@@ -659,9 +659,11 @@ class TrunkPlan:
                 f.add("simt_bn_relu_maxpool", y0.data_ptr(), one.data_ptr(), zero.data_ptr(), pool.data_ptr(),
                       pidx.data_ptr(), B, H0, W0, 64, Hp, Wp, ops.dt_code(dt))
         elif self.stem_from is not None:
-            o = self.stem_from
-            assert (o.B, o.H, o.W, o.dtype) == (B, self.H, self.W, dt) and not o.direct_stem
-            self.x_in, A = o.x_in, o.saved["stem.A"]
+            # stem_from = plan, or (plan, i, n): this plan convolves images [i * B, (i + 1) * B) of the partner's n * B (the frozen forward split
+            # into n half-batch chains, step.py SIMT_FROZEN_SPLIT): its rows of the partner's im2col matrix
+            o, part, nparts = self.stem_from if isinstance(self.stem_from, tuple) else (self.stem_from, 0, 1)
+            assert (o.B, o.H, o.W, o.dtype) == (B * nparts, self.H, self.W, dt) and not o.direct_stem
+            self.x_in, A = o.x_in, o.saved["stem.A"][part * M0:(part + 1) * M0]
             self.saved["stem.A"] = A
         else:
             self.x_in = self.new(B, 3, self.H, self.W, dtype=torch.float32)

@@ -81,6 +81,17 @@ class SimTTrainer:
         # the frozen model sees the same image: it reuses the trainable plan's stem im2col matrix (one im2col per micro-batch)
         self.fixed = TrunkPlan(self.fixed_params, B, H, W, multi_heads(Cn, 0, False), dtype=dtype, train=False,
                                stem_from=self.plan, data_parallel=process_group is not None, **kw)      # (same CU budget = same tile lists as the trainable plan)
+        # SIMT_FROZEN_SPLIT=n (round 6 experiment): the frozen forward as n chains of B / n images each on n side streams.  The frozen net runs in
+        # eval mode with folded BatchNorm: every image is independent, so the split changes nothing but the launch geometry -- B / n images are
+        # 236 / n one-per-CU workgroups per wide conv, and n such launches FIT the chip side by side (two full-batch launches do not: 2 x 236 > 256),
+        # so one chain's prologue / epilogue can overlap the other's K loop
+        self._fixed_parts, self._side2 = None, []
+        import os
+        nsp = int(os.environ.get("SIMT_FROZEN_SPLIT", "1"))
+        if nsp > 1 and B % nsp == 0 and dtype == torch.bfloat16 and not self.plan.direct_stem:
+            self._fixed_parts = [TrunkPlan(self.fixed_params, B // nsp, H, W, multi_heads(Cn, 0, False), dtype=dtype, train=False,
+                                           stem_from=(self.plan, i, nsp), data_parallel=process_group is not None, **kw) for i in range(nsp)]
+            self._side2 = [torch.cuda.Stream(device=dev) for _ in range(nsp - 1)]
         # item 0 of the trainable forward feeds BOTH nets: the direct stem launch with the frozen net as its second weight set (bf16), or the im2col
         assert self.plan.fwd_list.items[0].tag in ("simt_stem7_fwd", "simt_im2col_stem")
         assert self.plan.fwd_list.items[0].tag == "simt_im2col_stem" or self.plan.stem_desc.nsets == 2
@@ -285,6 +296,25 @@ class SimTTrainer:
             ev_in.record(main)
 
             def frozen():
+                if self._fixed_parts is not None:
+                    Mp = (self.B // len(self._fixed_parts)) * self.h * self.w
+                    evs = []
+                    for i, part in enumerate(self._fixed_parts):
+                        stq = side if i == 0 else self._side2[i - 1]
+                        with torch.cuda.stream(stq), trace.range("frozen-forward part"):
+                            stq.wait_event(ev_in)
+                            part.forward()
+                            ops.softmax_rows(part.out["x2"], self.ldf, self.fixp[i * Mp:(i + 1) * Mp], self.ldf, Mp, self.C)
+                            if i:
+                                e = torch.cuda.Event()
+                                e.record(stq)
+                                evs.append(e)
+                    with torch.cuda.stream(side):
+                        for e in evs:
+                            side.wait_event(e)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                    return ev
                 with torch.cuda.stream(side), trace.range("frozen-forward"):
                     side.wait_event(ev_in)
                     self.fixed.forward()
