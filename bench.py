@@ -339,6 +339,9 @@ def main():
         red.measure = True
     with PowerWatch(local) as pw:
         dt, med = timed(tr, resident(1234 + rank), a.steps, a.warmup)
+    # a fused BatchNorm launch that gave up polling leaves the sticky error word set and every optimiser launch skipped: never report such a run
+    if getattr(tr, "plan", None) is not None and tr.plan.fbn_error():
+        raise SystemExit("bench.py: a fused BatchNorm launch timed out (TrunkPlan.fbn_error): the timed steps did not train; rerun with SIMT_BN_GRID=0")
     comm = None
     if red is not None:
         comm = red.report()              # the exchange of the timed steps (plus warm-up): bytes, buckets, exposed wait
