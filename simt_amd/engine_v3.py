@@ -16,10 +16,14 @@ gamma and beta).  The five branch activations are stored as five planes [5][M][2
 (B*h rows) each; its weight gradient is the matching 5-tap wgrad and its input gradient five 1x1 GEMMs on row blocks of the
 transposed operand.
 """
+import ctypes as C
+import os
+
 import torch
 
+from . import _lib as L
 from . import ops
-from .engine import TrunkPlan, layout_flat_grads
+from .engine import LaunchList, TrunkPlan, layout_flat_grads
 
 R50 = "resnet.resnet_50."
 
@@ -91,8 +95,9 @@ class V3Plan(TrunkPlan):
 
     # ------------------------------------------------------------------ helpers
     def _bn_conv_relu(self, f, x, cname, bname, y, a, *, M, cin, cout, Hi, Wi, Ho, Wo, k, dil=1, stride=1, Bn=None, taps=None,
-                      wi=None):
-        """train: y = conv(x) (+ stats) ; a = relu(bn(y)).  eval: a = relu(conv(x) * scale + shift) in one launch."""
+                      wi=None, defer_apply=False):
+        """train: y = conv(x) (+ stats) ; a = relu(bn(y)).  eval: a = relu(conv(x) * scale + shift) in one launch.
+        defer_apply (train): leave the normalise + ReLU to the caller (the consuming conv may apply it in its operand path: TrunkPlan._conv inbn)."""
         Bn = Bn or self.B
         taps = taps or (ops.conv_taps(3, 3, dil, dil) if k == 3 else [(0, 0)])
         if self.train:
@@ -101,7 +106,7 @@ class V3Plan(TrunkPlan):
             self._conv(f, x, wi, y, Bn=Bn, Hi=Hi, Wi=Wi, Cin=cin, Ho=Ho, Wo=Wo, Cout=cout, taps=taps, stride=stride,
                        stats=s["part"])
             self._bn_train(f, bname, y, M, cout)
-            if a is not None:
+            if a is not None and not defer_apply:
                 f.add("simt_bn_apply", y.data_ptr(), s["scale"].data_ptr(), s["shift"].data_ptr(), None, None, None, None,
                       a.data_ptr(), M, cout, 1, ops.dt_code(self.dtype))
         else:
@@ -159,12 +164,24 @@ class V3Plan(TrunkPlan):
             z = self.new(Mo, c4)
             self._bn_conv_relu(f, x, name + ".conv1", name + ".bn1", y1, a1, M=Mi, cin=inpl, cout=planes, Hi=Hc, Wi=Wc, Ho=Hc, Wo=Wc, k=1)
             self._bn_conv_relu(f, a1, name + ".conv2", name + ".bn2", y2, a2, M=Mo, cin=planes, cout=planes, Hi=Hc, Wi=Wc, Ho=Ho,
-                               Wo=Wo, k=3, stride=stride)
+                               Wo=Wo, k=3, stride=stride, defer_apply=tr)
             if tr:
                 y3 = self.new(Mo, c4)
                 s3 = self._new_bn(name + ".bn3", Mo, c4)
                 w3 = self._plan_pack(name + ".conv3", c4, planes, 1)
-                self._conv(f, a2, w3, y3, Bn=B, Hi=Ho, Wi=Wo, Cin=planes, Ho=Ho, Wo=Wo, Cout=c4, taps=[(0, 0)], stats=s3["part"])
+                # bn2's normalise + ReLU in conv3's operand path where the row-streaming kernel takes conv3 (round 6; engine.TrunkPlan), else the
+                # separate apply launch
+                kw3 = dict(Bn=B, Hi=Ho, Wi=Wo, Cin=planes, Ho=Ho, Wo=Wo, Cout=c4, taps=[(0, 0)], stats=s3["part"])
+                s2 = self.bn[name + ".bn2"]
+                inbn = (os.environ.get("SIMT_NO_INBN", "0") == "0"
+                        and L.load().simt_conv_inbn_ok(C.byref(self._conv(LaunchList(), y2, w3, y3, **kw3))) != 0)
+                if inbn:
+                    self._conv(f, y2, w3, y3, inbn=(s2["scale"], s2["shift"], a2), **kw3)
+                else:
+                    f.add("simt_bn_apply", y2.data_ptr(), s2["scale"].data_ptr(), s2["shift"].data_ptr(), None, None, None, None,
+                          a2.data_ptr(), Mo, planes, 1, ops.dt_code(dt))
+                    self._conv(f, a2, w3, y3, **kw3)
+                rec["inbn"] = bool(inbn)
                 self._bn_train(f, name + ".bn3", y3, Mo, c4)
                 zbits = self.new(Mo, c4 // 8, dtype=torch.uint8)      # ReLU mask of the block output, one bit per element
                 rec.update(y1=y1, a1=a1, y2=y2, a2=a2, y3=y3, zbits=zbits)

@@ -462,3 +462,32 @@ def test_operand_path_batchnorm_plan_bitwise_b4_768(dev, monkeypatch):
     assert torch.isfinite(a["flat"]).all() and a["flat"].abs().max().item() > 0
     assert torch.equal(a["a2"], b["a2"]) and torch.equal(a["x1"], b["x1"]) and torch.equal(a["x2"], b["x2"]) and torch.equal(a["rm"], b["rm"])
     assert torch.equal(a["flat"], b["flat"]), "gradients differ between the operand-path BatchNorm plan and the two-pass plan"
+
+
+def test_operand_path_batchnorm_v3_plan_bitwise_b4_512x1024(dev, monkeypatch):
+    """BASELINE configs[3] (model/deeplabv3.py, B = 4, 512 x 1024; trainable BatchNorm affine): bn2 in conv3's operand path where the
+    row-streaming kernel takes conv3, against the plan with the separate simt_bn_apply launches (SIMT_NO_INBN=1): same logits, same flat
+    gradient (conv weights, BatchNorm weights and biases), bit for bit."""
+    from simt_amd.engine_v3 import V3Plan, v3_state_shapes
+    from test_gpu_v3 import make_state
+    st = make_state(v3_state_shapes(19, 6, True), 11)
+    g = torch.Generator().manual_seed(12)
+    img = torch.randn(B4, 3, 512, 1024, generator=g)
+    res = []
+    for off in ("0", "1"):
+        monkeypatch.setenv("SIMT_NO_INBN", off)
+        plan = V3Plan({k: v.clone().to(dev) for k, v in st.items()}, B4, 512, 1024, 19, 6, True, dtype=BF, train=True)
+        n_in = sum(1 for r in plan.block_io if r.get("inbn"))
+        out = plan.forward(img.to(dev))
+        up = (torch.randn(B4, 25, 32, 64, generator=torch.Generator().manual_seed(13)) * 1e-3).to(dev)
+        plan.backward(torch.nn.functional.interpolate(up, size=(512, 1024), mode="bilinear"))
+        torch.cuda.synchronize()
+        res.append(dict(out=out.clone(), flat=plan.flat_grad.clone(), n_in=n_in))
+        del plan
+        torch.cuda.empty_cache()
+    a, b = res
+    print(f"DeepLabv3 plan: {a['n_in']} of 13 Bottlenecks apply bn2 in conv3's operand path")
+    assert a["n_in"] >= 3 and b["n_in"] == 0
+    assert torch.isfinite(a["flat"]).all() and a["flat"].abs().max().item() > 0
+    assert torch.equal(a["out"], b["out"])
+    assert torch.equal(a["flat"], b["flat"]), "v3 plan with bn2 in conv3's operand path differs from the plan without"
