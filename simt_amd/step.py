@@ -215,7 +215,9 @@ class SimTTrainer:
         if self.pg is not None:
             from .dp import BucketReducer, make_buckets
             order, sizes, end = self.exchange_table()
-            buckets = make_buckets(order, sizes, self.plan.grad_ready, bucket_elems=self.BUCKET_ELEMS)
+            import os as _os
+            be = int(float(_os.environ.get("SIMT_DP_BUCKET_MB", "0")) * (1 << 18)) or self.BUCKET_ELEMS      # (MB of fp32 per all-reduce; default 32)
+            buckets = make_buckets(order, sizes, self.plan.grad_ready, bucket_elems=be)
             # the bad-label count (lout[12], accumulated by simt_ntm_post) rides in the same exchange: after the mean every rank holds
             # total / world, so losses() needs no collective of its own and every rank raises in the same call
             self.reducer = BucketReducer(self.plan.flat_grad[:end], buckets, group=self.pg, extra=[self._xchg[12:]])
