@@ -40,8 +40,13 @@ def _worker(rank, world, port, q):
         red = BucketReducer(flat, make_buckets(order, sizes, ready, bucket_elems=2000), group=dist.group.WORLD, extra=[extra])
         red.measure = True                             # bench.py's "comm" object comes from this report
         red.start()
+        made = []
         for launches in (5, 10, 30, 35, 70):          # the backward replay reports progress at its cut points
-            red.ready_upto(launches)
+            before = red.next
+            # (round 6) the producer event comes as a FACTORY: it is called only at the cut points where a bucket really leaves
+            red.ready_upto(launches, lambda: made.append(launches))
+            assert (made[-1:] == [launches]) == (red.next > before), (launches, made, before, red.next)
+        assert 1 <= len(made) <= 5
         red.finish()
         rep = red.report()
         assert rep["bytes_per_step"] == (total + extra.numel()) * 4 and rep["buckets"] == len(red.buckets) and rep["world"] == world
