@@ -33,6 +33,9 @@ M = B * H * W
 NSET = 6
 
 
+CLOCKS = {}          # candidate name of the last timeit() -> (socket W, shader MHz) while it ran back to back for ~0.3 s (sysfs, bench.PowerWatch)
+
+
 def timeit(fns, rounds=8, reps=5):
     """fns: {name: [callable per operand set]} -> {name: median us per launch}; the candidates' measurements alternate."""
     for f in fns.values():
@@ -51,7 +54,29 @@ def timeit(fns, rounds=8, reps=5):
             e1.record()
             torch.cuda.synchronize()
             out[k].append(e0.elapsed_time(e1) * 1e3 / (rounds * len(f)))
-    return {k: float(np.median(v)) for k, v in out.items()}
+    med = {k: float(np.median(v)) for k, v in out.items()}
+    # power / shader clock under each candidate alone: enough launches for ~0.35 s so that the 0.1-s sysfs sampler sees the steady state
+    CLOCKS.clear()
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+        from bench import PowerWatch
+        for k, f in fns.items():
+            n = max(1, int(0.35e6 / (med[k] * len(f))))
+            with PowerWatch(0) as pw:
+                for _ in range(n):
+                    for g in f:
+                        g()
+                torch.cuda.synchronize()
+            r = pw.report() or {}
+            CLOCKS[k] = (r.get("avg_w"), r.get("sclk_mhz_avg"))
+    except Exception:
+        pass
+    return med
+
+
+def _clk(k):
+    w, m = CLOCKS.get(k, (None, None))
+    return f"{w:.0f} W {m:.0f} MHz" if w and m else "-"
 
 
 def own_conv(lib, st, Cin, Cout, k, dil, relu=True, stats=False):
@@ -218,7 +243,7 @@ def main():
                 what = {"matmul": "torch.matmul [M,K]x[K,N] (dense operand" + (", NOT a conv: the GEMM alone)" if k == 3 else ")"),
                         "addmm+relu": "torch.addmm + relu_ (bias / ReLU as the frozen net's epilogue; 2 launches)",
                         "conv2d": "F.conv2d channels_last (MIOpen)"}[vk]
-                print(f"  {name:34s} {r['own']:8.1f} {fl / r['own'] / 1e6:9.0f} {r[vk]:10.1f} {fl / r[vk] / 1e6:12.0f} {r['own'] / r[vk]:16.2f}   {what}", flush=True)
+                print(f"  {name:34s} {r['own']:8.1f} {fl / r['own'] / 1e6:9.0f} {r[vk]:10.1f} {fl / r[vk] / 1e6:12.0f} {r['own'] / r[vk]:16.2f}   {what}   [own {_clk('own')} | vendor {_clk(vk)}]", flush=True)
             del own, keep1, mm, keep2, mme, keep4, cands
             torch.cuda.empty_cache()
         # the tap-expanded classifier GEMM (2048 -> 432, fp32 result in the product; the vendor leg writes bf16: less output traffic)
