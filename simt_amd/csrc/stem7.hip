@@ -10,9 +10,9 @@
 // its own epilogue (BatchNorm batch statistics | folded bias + ReLU) and output buffer.
 //
 // Workgroup: 8 waves on an 8 x 32 tile of output pixels (patch 21 x 69 pixels x 3 channels bf16, 448-byte row pitch, pad columns zero: the
-// lanes of the last k-group read past the 21 real values -- finite data times zero weights).  Wave w: 32 output channels (w & 3: two 16-row
-// weight blocks of one set, 14 A fragments = 56 VGPRs resident) x 128 pixels (w >> 2: four tile rows, 8 pixel blocks).  Per tile and wave
-// 112 MFMAs, 224 ds_read_b32.  HBM: the image once (fp32 NCHW, halo re-read 1.3x) + the outputs: ~30-40 us for both networks at 4 x 768 x 768.
+// lanes of the last k-group read past the 21 real values -- finite data times zero weights).  Wave w: tile row w (two pixel blocks) x all 128
+// output channels, weights from LDS in fragment order; per tile and wave 112 MFMAs, 56 ds_read_b128 + 56 ds_read_b32; the outputs leave through an
+// LDS tile as full 128-byte pixel rows.  HBM: the image once (fp32 NCHW, halo re-read 1.3x) + the outputs.
 #include "common.h"
 
 namespace {
@@ -31,159 +31,165 @@ struct StemArgs {
   float* stats[2];         // [tiles][2][64]
 };
 
-__global__ __launch_bounds__(512, 2) void stem7_kernel(StemArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t patch[PR * PITCH];
-  __shared__ float sred[2][2][2][64];          // [set][pixel half][sum | sum of squares][channel]
-  // output rows of one pass, both sets: [set][4 tile rows x 32 pixels][64 channels] bf16 at a 144-byte pitch -- the accumulator layout (4 channels
-  // of 16 pixels per lane group) written straight to HBM is 32-byte pieces of 16 different lines per store instruction (the first version: 135 us
-  // for 150 MB); through LDS every store is 16 bytes of a full 128-byte pixel row
-  constexpr int OP = 144;
-  __shared__ __attribute__((aligned(16))) char otile[2 * 128 * OP];
+// v5 (round 6, late): the weights of BOTH sets live in LDS in A-fragment order (56 KB: one conflict-free ds_read_b128 per fragment) and a wave owns
+// two pixel blocks (one tile row) for all 128 output channels -- a B fragment now feeds 16 MFMAs and an A fragment 2, where v4's B fragment fed 2
+// (each wave held its 32 channels' weights in registers and four waves re-read every pixel fragment): 224 ds_read_b32 per wave and tile -> 56 b32 + 56 b128.
+constexpr int OP = 144;                        // output-tile row pitch in bytes (64 channels bf16 + pad): conflict-free 8-byte accumulator writes
+constexpr int W_LDS = 2 * 4 * 7 * 1024, P_LDS = ((PR * PITCH * 2 + 15) / 16) * 16, O_LDS = 2 * TH * TW * OP;
+constexpr int STEM_LDS = W_LDS + 2 * P_LDS + O_LDS;
+constexpr int NIT_P = (PR * 3 * PC + 511) / 512;   // patch elements per thread
+
+// v6: PERSISTENT workgroups (one per CU: 149 KB of LDS), weights staged once per workgroup, the next tile's patch requested from HBM before this
+// tile's MFMAs and parked in registers until the tile is done (double-buffered patch in LDS).  v4 / v5 (one tile per workgroup, 2 304 workgroups in nine
+// rounds) took 111-118 us whatever the LDS read pattern: every tile paid its own weight staging and HBM round trips with nothing to overlap them.
+__device__ __forceinline__ void stem_patch_load(const StemArgs& a, int t, int tid, float (&v)[NIT_P]) {
+  const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, b = t / (a.tiles_x * a.tiles_y);
+  const int iy0 = 2 * ty * TH - 3, ix0 = 2 * tx * TW - 3;
+  const float* xb = a.x + (size_t)b * 3 * a.H * a.W;
+  // UNCONDITIONAL loads from clamped coordinates, zeroed by a select: a load under `if` is its own basic block with its own s_waitcnt vmcnt(0)
+#pragma unroll
+  for (int it = 0; it < NIT_P; ++it) {
+    const int i = tid + it * 512;
+    const int col = i % PC, jc = i / PC, c = jc % 3, row = jc / 3;
+    const int iy = iy0 + row, ix = ix0 + col;
+    const bool inb = i < PR * 3 * PC && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1), cc = min(c, 2);
+    const float tv = xb[((size_t)cc * a.H + cy) * a.W + cx];
+    v[it] = inb ? tv : 0.f;
+  }
+}
+__device__ __forceinline__ void stem_patch_store(bf16_t* patch, int tid, const float (&v)[NIT_P]) {
+#pragma unroll
+  for (int it = 0; it < NIT_P; ++it) {
+    const int i = tid + it * 512;
+    const int col = i % PC, jc = i / PC, c = jc % 3, row = jc / 3;
+    if (i < PR * 3 * PC) patch[row * PITCH + col * 3 + c] = f2bf(v[it]);
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void stem7_kernel(StemArgs a, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wlds = smem;                           // [set * 4 + channel block][7 filter rows][64 lanes][16 B]
+  bf16_t* const patch0 = (bf16_t*)(smem + W_LDS);
+  bf16_t* const patch1 = (bf16_t*)(smem + W_LDS + P_LDS);
+  char* otile = smem + W_LDS + 2 * P_LDS;      // [set][256 pixels][OP]; after the copy-out: the statistics partials [512][16] floats
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cb = wave & 3, ph = wave >> 2;     // channel quarter of the 128 (2 sets x 64), pixel half of the tile
-  const int set = cb >> 1;
-  const bool active = set < a.nsets;
-  int t = blockIdx.x;
-  const int tx = t % a.tiles_x; t /= a.tiles_x;
-  const int ty = t % a.tiles_y;
-  const int b = t / a.tiles_y;
-  const int oy0 = ty * TH, ox0 = tx * TW;
-  // ---- weights of this wave: 2 blocks of 16 output channels x 7 filter rows, A fragments (row = channel lane & 15, k' = (lane >> 4) * 8 ...)
-  bf16x8 wf[2][7];
-  if (active) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 7; ++r)
-        wf[j][r] = *(const bf16x8*)(a.w[set] + ((size_t)((cb & 1) * 32 + j * 16 + (lane & 15)) * 7 + r) * 32 + (lane >> 4) * 8);
+  const int ncb = 4 * a.nsets;
+  // ---- weights -> LDS once, fragment-linear: fragment (cbg, r), lane L = 16 bytes of channel (cbg & 3) * 16 + (L & 15), filter row r, k' = (L >> 4) * 8 ...
+  for (int i = tid; i < ncb * 7 * 64; i += 512) {
+    const int L = i & 63, fr = i >> 6, r = fr % 7, cbg = fr / 7;
+    const bf16_t* src = a.w[cbg >> 2] + ((size_t)((cbg & 3) * 16 + (L & 15)) * 7 + r) * 32 + (L >> 4) * 8;
+    *(uint4*)(wlds + (size_t)i * 16) = *(const uint4*)src;
   }
-  // ---- patch: fp32 NCHW -> bf16 [row][col][c] in LDS (coalesced along the image row; out-of-image pixels and the pad columns are zeros)
-  const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
-  const float* xb = a.x + (size_t)b * 3 * a.H * a.W;
-  {
-    // all loads of a thread are requested before the first is used (constant trip count, fully unrolled: the staging is 9 dependent-free
-    // round trips otherwise -- the first version of this kernel spent ~2/3 of its time here)
-    constexpr int NIT = (PR * 3 * PC + 511) / 512;
-    float v[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int i = tid + it * 512;
-      const int col = i % PC, jc = i / PC, c = jc % 3, row = jc / 3;
-      const int iy = iy0 + row, ix = ix0 + col;
-      // UNCONDITIONAL loads from clamped coordinates, zeroed by a select afterwards: a load under `if` is its own basic block with its own
-      // s_waitcnt vmcnt(0) -- nine serialised HBM round trips per tile (disassembly of the first version: 11 of its 16 us per tile)
-      const bool inb = i < PR * 3 * PC && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1), cc = min(c, 2);
-      const float t = xb[((size_t)cc * a.H + cy) * a.W + cx];
-      v[it] = inb ? t : 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int i = tid + it * 512;
-      const int col = i % PC, jc = i / PC, c = jc % 3, row = jc / 3;
-      if (i < PR * 3 * PC) patch[row * PITCH + col * 3 + c] = f2bf(v[it]);
-    }
+  // pad columns of both patch buffers: zeros, once
+  for (int i = tid; i < 2 * PR * (PITCH - PC * 3); i += 512) {
+    const int bsel = i / (PR * (PITCH - PC * 3)), k = i % (PR * (PITCH - PC * 3));
+    (bsel ? patch1 : patch0)[(k / (PITCH - PC * 3)) * PITCH + PC * 3 + k % (PITCH - PC * 3)] = (bf16_t)0;
   }
-  for (int i = tid; i < PR * (PITCH - PC * 3); i += 512) patch[(i / (PITCH - PC * 3)) * PITCH + PC * 3 + i % (PITCH - PC * 3)] = (bf16_t)0;
+  float pv[NIT_P];
+  int t = blockIdx.x, cur = 0;
+  if (t < ntiles) { stem_patch_load(a, t, tid, pv); stem_patch_store(patch0, tid, pv); }
   __syncthreads();
-  // ---- two passes of 4 pixel blocks each (64 accumulator registers would cost the second workgroup per CU): MFMA, then the epilogue:
-  // lane holds channels (cb & 1) * 32 + j * 16 + (lane >> 4) * 4 + e of pixel (lane & 15) of each block
-  float s1[2][4], s2[2][4];
+  for (; t < ntiles; t += gridDim.x, cur ^= 1) {
+    const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, b = t / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const bool more = t + (int)gridDim.x < ntiles;
+    if (more) stem_patch_load(a, t + gridDim.x, tid, pv);          // in flight during this tile's MFMAs
+    const bf16_t* patch = cur ? patch1 : patch0;
+    // ---- MFMA: wave = tile row `wave`, pixel blocks pb = 0, 1 (columns pb * 16 + (lane & 15)); D: channel (lane >> 4) * 4 + e of block cbg, pixel lane & 15
+    f32x4 acc[8][2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+    for (int c = 0; c < 8; ++c)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { s1[j][e] = 0.f; s2[j][e] = 0.f; }
-  const bool want_stats = active && a.stats[set] != nullptr;
-  const bool relu = active && a.relu[set] != 0;
-  float bv[2][4];
+      for (int pb = 0; pb < 2; ++pb) acc[c][pb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      const int kq = lane >> 4, pxl = lane & 15;
+      const bf16_t* src0 = patch + (2 * wave) * PITCH + (2 * pxl) * 3 + kq * 8;               // 4-byte aligned: (6 px + 8 kq) elements
+      const bf16_t* src1 = src0 + 2 * 16 * 3;
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+      for (int r = 0; r < 7; ++r) {
+        union { unsigned u[4]; bf16x8 v; } f0, f1;
+        const unsigned* s0 = (const unsigned*)(src0 + r * PITCH);
+        const unsigned* s1 = (const unsigned*)(src1 + r * PITCH);
+        f0.u[0] = s0[0]; f0.u[1] = s0[1]; f0.u[2] = s0[2]; f0.u[3] = s0[3];
+        f1.u[0] = s1[0]; f1.u[1] = s1[1]; f1.u[2] = s1[2]; f1.u[3] = s1[3];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bv[j][e] = (active && a.bias[set]) ? a.bias[set][(cb & 1) * 32 + j * 16 + (lane >> 4) * 4 + e] : 0.f;
-  const int kq = lane >> 4, pxl = lane & 15;
-#pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    if (active) {
-      f32x4 acc[2][4];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      // pixel block p = half * 4 + q of this wave: tile row ph * 4 + p / 2, columns (p & 1) * 16 + (lane & 15)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int p = half * 4 + q;
-        const int py = ph * 4 + (p >> 1), px = (p & 1) * 16 + pxl;
-        const bf16_t* src = patch + (2 * py) * PITCH + (2 * px) * 3 + kq * 8;          // 4-byte aligned: (6 px + 8 kq) elements
-#pragma unroll
-        for (int r = 0; r < 7; ++r) {
-          const unsigned* s4 = (const unsigned*)(src + r * PITCH);
-          union { unsigned u[4]; bf16x8 v; } f;
-          f.u[0] = s4[0]; f.u[1] = s4[1]; f.u[2] = s4[2]; f.u[3] = s4[3];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][r], f.v, acc[j][q], 0, 0, 0);
+        for (int c = 0; c < 8; ++c) {
+          if (c < ncb) {
+            const bf16x8 wf = *(const bf16x8*)(wlds + ((c * 7 + r) * 64 + lane) * 16);
+            acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, f0.v, acc[c][0], 0, 0, 0);
+            acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, f1.v, acc[c][1], 0, 0, 0);
+          }
         }
       }
+    }
+    // ---- accumulators (+ bias, ReLU) -> bf16 output tile in LDS
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int c0 = (cb & 1) * 32 + j * 16 + (lane >> 4) * 4;
+    for (int c = 0; c < 8; ++c) {
+      if (c < ncb) {
+        const int set = c >> 2, c0 = (c & 3) * 16 + (lane >> 4) * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias[set]) { bv[0] = a.bias[set][c0]; bv[1] = a.bias[set][c0 + 1]; bv[2] = a.bias[set][c0 + 2]; bv[3] = a.bias[set][c0 + 3]; }
+        const bool relu = a.relu[set] != 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int p = half * 4 + q;
-          const int oy = oy0 + ph * 4 + (p >> 1), ox = ox0 + (p & 1) * 16 + (lane & 15);
-          if (oy >= a.Ho || ox >= a.Wo) continue;
+        for (int pb = 0; pb < 2; ++pb) {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[e] = acc[j][q][e] + bv[j][e];
+            v[e] = acc[c][pb][e] + bv[e];
             if (relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
           }
           uint2 o;
           o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-          *(uint2*)(otile + (set * 128 + (ph * 2 + (q >> 1)) * 32 + (p & 1) * 16 + (lane & 15)) * OP + c0 * 2) = o;
-          if (want_stats) {                      // statistics of the values AS STORED (bf16), like every conv epilogue of this library
-            const float q0 = __uint_as_float(o.x << 16), q1 = __uint_as_float(o.x & 0xffff0000u);
-            const float q2 = __uint_as_float(o.y << 16), q3 = __uint_as_float(o.y & 0xffff0000u);
-            s1[j][0] += q0; s1[j][1] += q1; s1[j][2] += q2; s1[j][3] += q3;
-            s2[j][0] = fmaf(q0, q0, s2[j][0]); s2[j][1] = fmaf(q1, q1, s2[j][1]); s2[j][2] = fmaf(q2, q2, s2[j][2]); s2[j][3] = fmaf(q3, q3, s2[j][3]);
+          *(uint2*)(otile + (set * 256 + wave * 32 + pb * 16 + (lane & 15)) * OP + c0 * 2) = o;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- copy-out: full 128-byte pixel rows in 16-byte pieces; thread = (pixel, 8-channel piece tid & 7) -- and, for a set with statistics, the
+    // sums of the values AS STORED over this thread's pixels (fixed order), combined through LDS below
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    int sset = -1;
+    for (int st_ = 0; st_ < a.nsets; ++st_) {
+      const bool want = a.stats[st_] != nullptr && sset < 0;     // (statistics for ONE set per launch: the trainable one)
+      if (want) sset = st_;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = tid + it * 512, lp = idx >> 3, ch = idx & 7;
+        const int oy = oy0 + (lp >> 5), ox = ox0 + (lp & 31);
+        if (oy < a.Ho && ox < a.Wo) {
+          const uint4 o = *(const uint4*)(otile + (st_ * 256 + lp) * OP + ch * 16);
+          st_out16(a.y[st_] + ((size_t)(b * a.Ho + oy) * a.Wo + ox) * 64 + ch * 8, o);
+          if (want) {
+            const unsigned w4[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float q0 = __uint_as_float(w4[e] << 16), q1 = __uint_as_float(w4[e] & 0xffff0000u);
+              s1[2 * e] += q0; s1[2 * e + 1] += q1;
+              s2[2 * e] = fmaf(q0, q0, s2[2 * e]); s2[2 * e + 1] = fmaf(q1, q1, s2[2 * e + 1]);
+            }
           }
         }
       }
     }
-    __syncthreads();
-    // copy-out of this pass: 2 sets x 128 pixels x 8 pieces of 16 bytes; row slot rs of the pass = tile row (rs >> 1) * 4 + 2 * half + (rs & 1)
+    if (more) stem_patch_store(cur ? patch0 : patch1, tid, pv);        // the other buffer: nobody reads it in this iteration
+    if (sset >= 0) {                           // (uniform)
+      __syncthreads();                         // every piece of the output tile has been read: its LDS becomes the partials
+      float* spart = (float*)otile;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = tid + it * 512;
-      const int st_ = idx >> 10, rem = idx & 1023, lp = rem >> 3, ch = rem & 7;
-      const int rs = lp >> 5, oy = oy0 + (rs >> 1) * 4 + 2 * half + (rs & 1), ox = ox0 + (lp & 31);
-      if (st_ < a.nsets && oy < a.Ho && ox < a.Wo)
-        st_out16(a.y[st_] + ((size_t)(b * a.Ho + oy) * a.Wo + ox) * 64 + ch * 8, *(const uint4*)(otile + (st_ * 128 + lp) * OP + ch * 16));
+      for (int e = 0; e < 8; ++e) { spart[tid * 16 + e] = s1[e]; spart[tid * 16 + 8 + e] = s2[e]; }
+      __syncthreads();
+      if (tid < 128) {                         // channel c = tid & 63, q = tid >> 6: the 64 threads with tid' & 7 == c >> 3, in order
+        const int c = tid & 63, q = tid >> 6;
+        float tsum = 0.f;
+        for (int j2 = 0; j2 < 64; ++j2) tsum += spart[((c >> 3) + 8 * j2) * 16 + q * 8 + (c & 7)];
+        a.stats[sset][((size_t)t * 2 + q) * 64 + c] = tsum;
+      }
     }
     __syncthreads();
-  }
-  // ---- per-tile BatchNorm partial sums: 16 pixel lanes (DPP row, fixed order) -> LDS -> the two pixel halves in order -> [tile][2][64]
-  if (active && a.stats[set]) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t1 = s1[j][e], t2 = s2[j][e];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
-        if ((lane & 15) == 0) {
-          const int c = (cb & 1) * 32 + j * 16 + (lane >> 4) * 4 + e;
-          sred[set][ph][0][c] = t1;
-          sred[set][ph][1][c] = t2;
-        }
-      }
-  }
-  __syncthreads();
-  if (tid < 256) {
-    const int st_ = tid >> 7, q = (tid >> 6) & 1, c = tid & 63;
-    if (st_ < a.nsets && a.stats[st_])
-      a.stats[st_][((size_t)blockIdx.x * 2 + q) * 64 + c] = sred[st_][0][q][c] + sred[st_][1][q][c];
   }
 }
 
@@ -224,7 +230,11 @@ extern "C" int simt_stem7_fwd(const simt_stem_desc* d, simt_stream_t stream) {
     SIMT_CHECK(d->w[s] && d->y[s]);
     a.w[s] = (const bf16_t*)d->w[s]; a.y[s] = (bf16_t*)d->y[s]; a.bias[s] = d->bias[s]; a.relu[s] = d->relu[s]; a.stats[s] = d->stats[s];
   }
-  hipLaunchKernelGGL(stem7_kernel, dim3(a.B * a.tiles_y * a.tiles_x), dim3(512), 0, (hipStream_t)stream, a);
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)stem7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS); attr_done = true; }
+  const int ntiles = a.B * a.tiles_y * a.tiles_x;
+  SIMT_CHECK(!(d->nsets == 2 && d->stats[0] && d->stats[1]));      // statistics for one set per launch
+  hipLaunchKernelGGL(stem7_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(512), STEM_LDS, (hipStream_t)stream, a, ntiles);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }

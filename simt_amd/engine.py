@@ -605,10 +605,10 @@ class TrunkPlan:
         # Round 6 (VERDICT r5 #1c), OPT-IN with SIMT_DIRECT_STEM=1: the bf16 plans convolve the image DIRECTLY (csrc/stem7.hip: the patch of an
         # 8 x 32 output tile in LDS, one filter row per MFMA k-step) instead of writing a 226-MB im2col matrix and running a 64-column GEMM over it
         # per network; a frozen plan built with stem_from=<trainable plan> joins that plan's launch as its second weight set (both networks see the
-        # same image).  Built, parity-green at the storage-format bar, and MEASURED NOT FASTER in the step: the direct launch takes 111 us for both
-        # networks (LDS-read bound: a B fragment feeds only two MFMAs) where im2col + two GEMMs take 134 + 62 + 60 us of which the frozen GEMM
+        # same image).  Built, parity-green at the storage-format bar, and MEASURED NOT FASTER in the step: the direct launch takes 87 us for both
+        # networks (persistent workgroups, six versions from 140 us) where im2col + two GEMMs take 134 + 62 + 60 us of which the frozen GEMM
         # already overlaps; and the stem's weight gradient -- which still multiplies the im2col matrix -- then has to build that matrix in the
-        # backward (side stream, at its start).  24.149 ms against 24.057 ms for the default (same box, six alternating rounds,
+        # backward (side stream, at its start).  23.452 ms against 23.451 ms for the default (same box, six alternating rounds,
         # profiles/r06_direct_stem.txt).  What would make it pay is a direct weight-gradient kernel (no im2col matrix at all: DESIGN.md section 9).
         self.direct_stem = dt == torch.bfloat16 and os.environ.get("SIMT_DIRECT_STEM", "0") == "1"
         y0 = self.new(M0, 64)
