@@ -291,6 +291,11 @@ typedef struct {
 int simt_stem7_tiles(int B, int Ho, int Wo);
 int simt_stem7_pack(const float* w_oihw, const float* cscale, void* dst, simt_stream_t stream);
 int simt_stem7_fwd(const simt_stem_desc* d, simt_stream_t stream);
+/* Weight gradient of the stem convolution straight from the image (replaces simt_im2col_stem + simt_conv_wgrad + simt_wgrad_reduce for conv1,
+ * tools/trainV2_simt.py:428): dw[o][c][r][s] = sum_pixels dy[p][o] * x[b][c][2 oy - 3 + r][2 ox - 3 + s], fp32 accumulation, the per-workgroup partials
+ * added in fixed order (bitwise reproducible).  part: [simt_stem7_wgrad_workgroups(B, Ho, Wo)][64 * 7 * 32] fp32 workspace; dw is overwritten. */
+int simt_stem7_wgrad_workgroups(int B, int Ho, int Wo);
+int simt_stem7_wgrad(const float* x_nchw, const void* dy, float* part, float* dw, int B, int H, int W, int Ho, int Wo, simt_stream_t stream);
 
 int simt_im2col_stem(const float* x_nchw, void* A, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW,
                      int stride, int pad, int ldk, int dtype, simt_stream_t stream);

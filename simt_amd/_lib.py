@@ -113,6 +113,8 @@ SIGNATURES = {
     "simt_stem7_tiles": (_I, [_I, _I, _I]),
     "simt_stem7_pack": (_I, [c_p, c_p, c_p, c_p]),
     "simt_stem7_fwd": (_I, [C.POINTER(StemDesc), c_p]),
+    "simt_stem7_wgrad_workgroups": (_I, [_I, _I, _I]),
+    "simt_stem7_wgrad": (_I, [c_p, c_p, c_p, c_p, _I, _I, _I, _I, _I, c_p]),
     "simt_conv_mtiles": (_I, [C.POINTER(ConvDesc)]),
     "simt_conv_inbn_ok": (_I, [C.POINTER(ConvDesc)]),
     "simt_conv_fprop_pair": (_I, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), c_p]),

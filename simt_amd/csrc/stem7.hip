@@ -193,6 +193,127 @@ __global__ __launch_bounds__(512, 2) void stem7_kernel(StemArgs a, int ntiles) {
   }
 }
 
+// ---- weight gradient of the stem, directly from the image (no im2col matrix): dW[o][c][r][s] = sum_pixels dy[p][o] * x[c][2 oy - 3 + r][2 ox - 3 + s]
+// (loss.backward() through conv1, tools/trainV2_simt.py:428; computed like the reference computes it although the SimT stage never applies it).
+// Same tiles and patch as the forward.  The reduction runs over PIXELS: one MFMA k-step = one tile row of 32 pixels, A = dy^T (the tile's gradient
+// rows staged TRANSPOSED in LDS: [channel][pixel], so a fragment is 16 contiguous bytes), B = the patch read at a 6-element pixel stride (8 x
+// ds_read_u16 per fragment).  Wave r (0..6) owns filter row r: 4 channel blocks x 2 k'-blocks of accumulators, kept in registers over all the tiles
+// of a persistent workgroup; every workgroup then writes its [64][7][32] fp32 partial, and stem7_wgrad_reduce_kernel adds the partials in fixed
+// order into the OIHW gradient (bitwise reproducible).
+constexpr int DYT_PITCH = 256 + 8;             // elements per channel row of the transposed gradient tile (pad: conflict-free b128 reads)
+constexpr int WG_LDS = 2 * P_LDS + 64 * DYT_PITCH * 2;
+
+struct StemWgradArgs {
+  const float* x;
+  const bf16_t* dy;        // [B*Ho*Wo][64]
+  float* part;             // [workgroups][64][7][32]
+  int B, H, W, Ho, Wo, tiles_y, tiles_x;
+};
+
+__global__ __launch_bounds__(512, 2) void stem7_wgrad_kernel(StemWgradArgs w, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* const patch0 = (bf16_t*)smem;
+  bf16_t* const patch1 = (bf16_t*)(smem + P_LDS);
+  bf16_t* const dyT = (bf16_t*)(smem + 2 * P_LDS);      // [64 channels][DYT_PITCH]: pixel = tile row * 32 + column
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  StemArgs a;                                            // (the patch helpers take the forward's argument struct)
+  a.x = w.x; a.B = w.B; a.H = w.H; a.W = w.W; a.Ho = w.Ho; a.Wo = w.Wo; a.tiles_y = w.tiles_y; a.tiles_x = w.tiles_x; a.nsets = 0;
+  for (int i = tid; i < 2 * PR * (PITCH - PC * 3); i += 512) {
+    const int bsel = i / (PR * (PITCH - PC * 3)), k = i % (PR * (PITCH - PC * 3));
+    (bsel ? patch1 : patch0)[(k / (PITCH - PC * 3)) * PITCH + PC * 3 + k % (PITCH - PC * 3)] = (bf16_t)0;
+  }
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) acc[ob][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float pv[NIT_P];
+  uint4 g[4];
+  // a tile's gradient rows (pixels outside the image: zeros, so their patch values do not count); clamped unconditional loads + select
+  auto dy_load = [&](int tt) {
+    const int tx = tt % w.tiles_x, ty = (tt / w.tiles_x) % w.tiles_y, b = tt / (w.tiles_x * w.tiles_y);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 512, lp = idx >> 3, ch = idx & 7;
+      const int oy = ty * TH + (lp >> 5), ox = tx * TW + (lp & 31);
+      const bool inb = oy < w.Ho && ox < w.Wo;
+      const int cy = min(oy, w.Ho - 1), cx = min(ox, w.Wo - 1);
+      const uint4 v = *(const uint4*)(w.dy + ((size_t)(b * w.Ho + cy) * w.Wo + cx) * 64 + ch * 8);
+      g[it] = inb ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  int t = blockIdx.x, cur = 0;
+  if (t < ntiles) { stem_patch_load(a, t, tid, pv); dy_load(t); stem_patch_store(patch0, tid, pv); }
+  for (; t < ntiles; t += gridDim.x, cur ^= 1) {
+    const bool more = t + (int)gridDim.x < ntiles;
+    // ---- gradient rows -> LDS, transposed; then the NEXT tile's loads are in flight under this tile's MFMAs
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 512, lp = idx >> 3, ch = idx & 7;
+      const unsigned w4[4] = {g[it].x, g[it].y, g[it].z, g[it].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dyT[(ch * 8 + 2 * e) * DYT_PITCH + lp] = (bf16_t)(w4[e] & 0xffffu);
+        dyT[(ch * 8 + 2 * e + 1) * DYT_PITCH + lp] = (bf16_t)(w4[e] >> 16);
+      }
+    }
+    if (more) { stem_patch_load(a, t + gridDim.x, tid, pv); dy_load(t + gridDim.x); }
+    __syncthreads();
+    if (wave < 7) {
+      const bf16_t* patch = cur ? patch1 : patch0;
+      const int r = wave, kq = lane >> 4, kp = lane & 15;
+#pragma unroll
+      for (int py = 0; py < TH; ++py) {                  // k-step: tile row py, pixels kq * 8 + e
+        bf16x8 bf[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const bf16_t* src = patch + (2 * py + r) * PITCH + (2 * (kq * 8)) * 3 + kb * 16 + kp;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bf[kb][e] = (short)src[e * 6];
+        }
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+          const bf16x8 af = *(const bf16x8*)(dyT + (ob * 16 + kp) * DYT_PITCH + py * 32 + kq * 8);
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) acc[ob][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[kb], acc[ob][kb], 0, 0, 0);
+        }
+      }
+    }
+    if (more) stem_patch_store(cur ? patch0 : patch1, tid, pv);
+    __syncthreads();
+  }
+  // ---- this workgroup's partial: D row = channel ob * 16 + (lane >> 4) * 4 + e, column = k' = kb * 16 + (lane & 15)
+  if (wave < 7) {
+    float* dst = w.part + (size_t)blockIdx.x * (64 * 7 * 32);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          dst[((ob * 16 + (lane >> 4) * 4 + e) * 7 + wave) * 32 + kb * 16 + (lane & 15)] = acc[ob][kb][e];
+  }
+}
+
+// dW[o][c][r][s] = sum over the workgroups' partials [g][o][r][s * 3 + c], in fixed order: a workgroup takes 64 consecutive partial elements, its 16
+// thread rows add the partials g = ty, ty + 16, ... in order, then thread row 0 adds the 16 row sums in order
+__global__ __launch_bounds__(1024) void stem7_wgrad_reduce_kernel(const float* part, int nwg, float* dw) {
+  __shared__ float sm[16][64];
+  const int tx = threadIdx.x, ty = threadIdx.y, e = blockIdx.x * 64 + tx;     // e = (o * 7 + r) * 32 + k'
+  float t = 0.f;
+  for (int g = ty; g < nwg; g += 16) t += part[(size_t)g * (64 * 7 * 32) + e];
+  sm[ty][tx] = t;
+  __syncthreads();
+  if (ty == 0) {
+    float v = sm[0][tx];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v += sm[q][tx];
+    const int kk = e & 31, r = (e >> 5) % 7, o = e / 224;
+    if (kk < 21) dw[((o * 3 + kk % 3) * 7 + r) * 7 + kk / 3] = v;
+  }
+}
+
 // conv1.weight fp32 OIHW [64][3][7][7] (optionally scaled per output channel: the frozen net's folded BatchNorm) -> bf16 [64][7][32], k' = s*3 + c
 __global__ void stem7_pack_kernel(const float* w, const float* cscale, bf16_t* dst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -235,6 +356,26 @@ extern "C" int simt_stem7_fwd(const simt_stem_desc* d, simt_stream_t stream) {
   const int ntiles = a.B * a.tiles_y * a.tiles_x;
   SIMT_CHECK(!(d->nsets == 2 && d->stats[0] && d->stats[1]));      // statistics for one set per launch
   hipLaunchKernelGGL(stem7_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(512), STEM_LDS, (hipStream_t)stream, a, ntiles);
+  SIMT_LAUNCH_CHECK();
+  return SIMT_OK;
+}
+
+extern "C" int simt_stem7_wgrad_workgroups(int B, int Ho, int Wo) {
+  const int n = simt_stem7_tiles(B, Ho, Wo);
+  return n < 256 ? n : 256;
+}
+
+// part: [simt_stem7_wgrad_workgroups(B, Ho, Wo)][64 * 7 * 32] fp32 workspace; dw: [64][3][7][7] fp32 (overwritten)
+extern "C" int simt_stem7_wgrad(const float* x, const void* dy, float* part, float* dw, int B, int H, int W, int Ho, int Wo, simt_stream_t stream) {
+  SIMT_CHECK(x && dy && part && dw && B > 0 && Ho == (H + 6 - 7) / 2 + 1 && Wo == (W + 6 - 7) / 2 + 1);
+  StemWgradArgs w;
+  w.x = x; w.dy = (const bf16_t*)dy; w.part = part; w.B = B; w.H = H; w.W = W; w.Ho = Ho; w.Wo = Wo;
+  w.tiles_y = (Ho + TH - 1) / TH; w.tiles_x = (Wo + TW - 1) / TW;
+  const int ntiles = B * w.tiles_y * w.tiles_x, nwg = ntiles < 256 ? ntiles : 256;
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)stem7_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS); attr_done = true; }
+  hipLaunchKernelGGL(stem7_wgrad_kernel, dim3(nwg), dim3(512), WG_LDS, (hipStream_t)stream, w, ntiles);
+  hipLaunchKernelGGL(stem7_wgrad_reduce_kernel, dim3(64 * 7 * 32 / 64), dim3(64, 16), 0, (hipStream_t)stream, (const float*)part, nwg, dw);
   SIMT_LAUNCH_CHECK();
   return SIMT_OK;
 }

@@ -602,15 +602,15 @@ class TrunkPlan:
         self.saved = {}
         # ---- stem (model/deeplab_multi.py:127-133,172-176)
         KS = 192
-        # Round 6 (VERDICT r5 #1c), OPT-IN with SIMT_DIRECT_STEM=1: the bf16 plans convolve the image DIRECTLY (csrc/stem7.hip: the patch of an
-        # 8 x 32 output tile in LDS, one filter row per MFMA k-step) instead of writing a 226-MB im2col matrix and running a 64-column GEMM over it
-        # per network; a frozen plan built with stem_from=<trainable plan> joins that plan's launch as its second weight set (both networks see the
-        # same image).  Built, parity-green at the storage-format bar, and MEASURED NOT FASTER in the step: the direct launch takes 87 us for both
-        # networks (persistent workgroups, six versions from 140 us) where im2col + two GEMMs take 134 + 62 + 60 us of which the frozen GEMM
-        # already overlaps; and the stem's weight gradient -- which still multiplies the im2col matrix -- then has to build that matrix in the
-        # backward (side stream, at its start).  23.452 ms against 23.451 ms for the default (same box, six alternating rounds,
-        # profiles/r06_direct_stem.txt).  What would make it pay is a direct weight-gradient kernel (no im2col matrix at all: DESIGN.md section 9).
-        self.direct_stem = dt == torch.bfloat16 and os.environ.get("SIMT_DIRECT_STEM", "0") == "1"
+        # Round 6 (VERDICT r5 #1c): the bf16 plans convolve the image DIRECTLY (csrc/stem7.hip: the patch of an 8 x 32 output tile in LDS, one
+        # filter row per MFMA k-step) instead of writing a 226-MB im2col matrix and running a 64-column GEMM over it per network; a frozen plan
+        # built with stem_from=<trainable plan> joins that plan's launch as its second weight set (both networks see the same image); conv1's
+        # weight gradient comes straight from the image too (simt_stem7_wgrad, pixels as the MFMA reduction dimension), so no im2col matrix
+        # exists anywhere in the step.  87 us forward (both networks) + 57 + 7 us weight gradient against 134 (im2col) + 62 + 60 (two GEMMs)
+        # + ~75 us (gradient GEMM + reduce); the step: -0.06 / -0.12 ms on two boxes, six alternating rounds each, every round below
+        # (profiles/r06_direct_stem.txt).  The forward alone (weight gradient still through an im2col matrix built in the backward) was
+        # neutral.  SIMT_DIRECT_STEM=0: rounds 1-5's im2col + GEMM stem; fp32 plans always use it.
+        self.direct_stem = dt == torch.bfloat16 and os.environ.get("SIMT_DIRECT_STEM", "1") != "0"
         y0 = self.new(M0, 64)
         pool = self.new(Mp, 64)
         pidx = self.new(Mp, 64, dtype=torch.uint8)
@@ -620,7 +620,8 @@ class TrunkPlan:
             tiles = L.load().simt_stem7_tiles(B, H0, W0)
             if self.train:
                 s = self._new_bn("bn1", M0, 64)
-                assert tiles <= s["nblk"]
+                if tiles > s["nblk"]:                  # (small ragged images: partial 8 x 32 tiles outnumber the 128-row blocks)
+                    s["part"] = self.new(tiles, 2, 64, dtype=torch.float32)
                 s["nblk"] = tiles                      # one statistics slot per 8 x 32 tile
                 self.pack_list.add("simt_stem7_pack", self.p["conv1.weight"].data_ptr(), None, w7.data_ptr())
                 mine = dict(w=w7, y=y0, bias=None, relu=0, stats=s["part"])
@@ -1029,7 +1030,7 @@ class TrunkPlan:
                 ns = ops.wgrad_group_nsplit(Mo, sum(ops.wgrad_tiles(Mo, cd, kt, tco) for cd, kt in shp))
                 self._slab_cap = max(self._slab_cap, ns * sum(cd * kt for cd, kt in shp))
         M0 = B * self.H0 * self.W0
-        self._slab_cap = max(self._slab_cap, ops.wgrad_nsplit(M0, 64, 192, dt) * 64 * 192)
+        self._slab_cap = max(self._slab_cap, ops.wgrad_nsplit(M0, 64, 192, dt) * 64 * 192, 256 * 64 * 7 * 32)     # (256 x ...: simt_stem7_wgrad's partials)
         self._bnb_cap = max(self._bnb_cap, ops.bn_bwd_nblk(M0, 64) * 3 * 64)
         for hd in self.heads:
             Mh = B * hd.h * hd.w
@@ -1052,7 +1053,9 @@ class TrunkPlan:
         for hd in self.heads:
             heads_by_layer.setdefault(hd.feat_layer, []).append(hd)
 
-        if self.direct_stem and self.grads_from_layer == 0:
+        # conv1's weight gradient straight from the image too (simt_stem7_wgrad): then no im2col matrix exists anywhere in the step
+        self.direct_stem_wgrad = self.direct_stem and os.environ.get("SIMT_DIRECT_STEM_WGRAD", "1") != "0"
+        if self.direct_stem and self.grads_from_layer == 0 and not self.direct_stem_wgrad:
             # the forward convolved the image directly: the im2col matrix exists only for the stem's weight gradient at the very end of this
             # list.  Built FIRST, on the side stream (idle between the frozen forward and the first weight gradients): an HBM-bound 134-us pass
             # beside the heads' MFMA-bound gradient GEMMs instead of on the tail of the backward
@@ -1253,8 +1256,17 @@ class TrunkPlan:
         stem_stream = 0 if os.environ.get("SIMT_STEM_WGRAD_MAIN", "1") != "0" else 1
         if stem_stream == 1:
             b.wait(b.record(0), 1)
-        self._wgrad(b, dy0, self.saved["stem.A"], None, Bn=1, Hi=1, Wi=M0, Cin=192, Ho=1, Wo=M0, Cd=64, ldd=64,
-                    taps=[(0, 0)], stride=1, parts=[("conv1.weight", 0, 0, 64, 1, 147)], stream=stem_stream)
+        if self.direct_stem_wgrad:
+            nwg = L.load().simt_stem7_wgrad_workgroups(B, H0, W0)
+            part = self.buf("wgrad.slab" if stem_stream == 1 else "wgrad.slab.main", self._slab_cap, dtype=torch.float32)
+            assert nwg * 64 * 7 * 32 <= self._slab_cap
+            b.add("simt_stem7_wgrad", self.x_in.data_ptr(), dy0.data_ptr(), part.data_ptr(), self.grads["conv1.weight"].data_ptr(), B, self.H,
+                  self.W, H0, W0, stream=stem_stream, flops=2.0 * M0 * 64 * 147,
+                  nbytes=float(M0 * 64 * self.esz + B * 3 * self.H * self.W * 4 + 2 * nwg * 64 * 7 * 32 * 4), shape=f"M{M0} direct")
+            self.grad_ready["conv1.weight"] = len(b)
+        else:
+            self._wgrad(b, dy0, self.saved["stem.A"], None, Bn=1, Hi=1, Wi=M0, Cin=192, Ho=1, Wo=M0, Cd=64, ldd=64,
+                        taps=[(0, 0)], stride=1, parts=[("conv1.weight", 0, 0, 64, 1, 147)], stream=stem_stream)
         b.wait(b.record(1), 0)        # join: the optimiser (stream 0) sees every gradient
 
     def _build_head_bwd(self, hd, dz_prev, Mo, c4, bi, bnr=None):

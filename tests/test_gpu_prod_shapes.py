@@ -523,6 +523,39 @@ def test_direct_stem_both_networks_one_launch_bf16(dev, geom):
     assert torch.equal(y1, y[1])
 
 
+@pytest.mark.parametrize("geom", [(B4, 768, 768), (2, 65, 97), (1, 512, 1024), (1, 33, 41)], ids=["b4_768", "ragged_65x97", "b1_512x1024", "one_tile_row"])
+def test_direct_stem_weight_gradient_vs_float64(dev, geom):
+    """simt_stem7_wgrad: conv1's weight gradient straight from the fp32 NCHW image (loss.backward() through model/deeplab_multi.py:172,
+    tools/trainV2_simt.py:428) against torch's float64 conv2d_weight of the same bf16-rounded image and bf16 gradient rows: fp32 accumulation
+    (products of two bf16 values are exact in fp32), so the bar is fp32 summation error over B * Ho * Wo terms, not bf16; two calls agree bit
+    for bit (fixed-order reduction of the workgroups' partials); ragged sizes exercise the zero rows of partial tiles."""
+    B, H, W = geom
+    H0, W0 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    M0 = B * H0 * W0
+    g = torch.Generator().manual_seed(H * 3 + W)
+    img = (torch.rand(B, 3, H, W, generator=g) * 255.0 - 115.0).to(dev)
+    dy = (torch.randn(M0, 64, generator=g) * 1e-3).to(dev, BF)
+    lib = L.load()
+    nwg = lib.simt_stem7_wgrad_workgroups(B, H0, W0)
+    assert nwg == min(256, lib.simt_stem7_tiles(B, H0, W0))
+    part = torch.full((nwg, 64 * 7 * 32), float("nan"), device=dev)
+    out = []
+    for _ in range(2):
+        dw = torch.full((64, 3, 7, 7), float("nan"), device=dev)
+        L.call("simt_stem7_wgrad", img.data_ptr(), dy.data_ptr(), part.data_ptr(), dw.data_ptr(), B, H, W, H0, W0, ops.stream_ptr())
+        torch.cuda.synchronize()
+        out.append(dw)
+    assert torch.equal(out[0], out[1])
+    xr = img.to(BF).double().cpu()
+    dyr = dy.double().cpu().view(B, H0, W0, 64).permute(0, 3, 1, 2).contiguous()
+    ref = torch.nn.grad.conv2d_weight(xr, (64, 3, 7, 7), dyr, stride=2, padding=3)
+    # scale of one output: sqrt(M0) * |x| * |dy|; fp32 accumulation in tiles of 256 pixels then <= 256 partials
+    scale = (xr.pow(2).mean().sqrt() * dyr.pow(2).mean().sqrt()).item() * M0 ** 0.5
+    err = (out[0].double().cpu() - ref).abs().max().item()
+    print(f"direct stem wgrad {geom}: {nwg} workgroups, max err {err:.3e} (scale {scale:.3e})")
+    assert err < 2e-5 * scale
+
+
 def test_direct_stem_plan_matches_the_im2col_plan(dev, monkeypatch):
     """The production plans with the direct stem (default) against SIMT_DIRECT_STEM=0 (im2col + GEMM): a different summation order in the stem
     (filter rows of 21 + 11 zero columns vs the OIHW flattening), so the comparison is at the storage format: the stem outputs within 1 bf16 ulp,
@@ -536,8 +569,9 @@ def test_direct_stem_plan_matches_the_im2col_plan(dev, monkeypatch):
     cd = ms.load_class_dist("bapa")
     img, lab = ms.synthetic_batch(2, 129, 193, cd, seed=4, device=dev)
     res = []
-    for direct in ("1", "0"):
+    for direct, dwg in (("1", "1"), ("0", "1"), ("1", "0")):
         monkeypatch.setenv("SIMT_DIRECT_STEM", direct)
+        monkeypatch.setenv("SIMT_DIRECT_STEM_WGRAD", dwg)
         tr = SimTTrainer(st, fst, ms.ntm_init(19, 3, 1), ms.ntm_init(19, 3, 2), Hyper(open_classes=3), cd, 2, 129, 193, dtype=BF, device=dev, layers=lay)
         assert tr.plan.direct_stem == (direct == "1") and tr.fixed.direct_stem == (direct == "1")
         tag0 = tr.plan.fwd_list.items[0].tag
@@ -545,13 +579,19 @@ def test_direct_stem_plan_matches_the_im2col_plan(dev, monkeypatch):
         assert not any(it.tag in ("simt_stem7_fwd", "simt_im2col_stem") for it in tr.fixed.fwd_list.items)
         if direct == "1":
             assert tr.plan.stem_desc.nsets == 2
+            # no im2col matrix anywhere in the step when the weight gradient is direct too
+            tags = [it.tag for it in tr.plan.bwd_list.items]
+            assert ("simt_stem7_wgrad" in tags) == (dwg == "1") and ("simt_im2col_stem" in tags) == (dwg == "0")
         tr.step(img, lab, 0)
         torch.cuda.synchronize()
         res.append(dict(y=tr.plan.saved["stem.y"].clone(), fy=tr.fixed.saved["stem.y"].clone(), fx2=tr.fixed.out["x2"].clone(),
                         gw=tr.plan.grads["conv1.weight"].clone(), l=tr.lout[:9].clone()))
         del tr
         torch.cuda.empty_cache()
-    a, b = res
+    a, b, c = res
+    # same forward, same dy0 (bitwise): the direct weight gradient against the im2col + GEMM one differs by fp32 summation order only
+    assert torch.equal(a["y"], c["y"]) and torch.equal(a["l"], c["l"])
+    assert _rel(a["gw"], c["gw"]) < 1e-5
     for k in ("y", "fy"):
         da, db = a[k].double(), b[k].double()
         ulp = _ulp_bf16(db, db.pow(2).mean().sqrt().item() * 2.0 ** -6)
