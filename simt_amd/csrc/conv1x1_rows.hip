@@ -20,7 +20,8 @@
 #include <type_traits>
 
 // Compile-time timing ablations (scratch builds only; outputs meaningless): 1 = no fragment reads / MFMA, 2 = no global stores,
-// 4 = no LDS-DMA loads, 8 = store waves idle (barriers only), 64 = no epilogue in the compute waves, 128 = no fragment reads, 256 = no statistics
+// 4 = no LDS-DMA loads, 8 = store waves idle (barriers only), 64 = no epilogue in the compute waves, 128 = no fragment reads, 256 = no statistics,
+// 512 = the store waves' global operands (residual, BatchNorm-backward y) from an L2-resident window
 #ifndef SIMT_ROWS_ABL
 #define SIMT_ROWS_ABL 0
 #endif
@@ -51,7 +52,7 @@ template <int KS, int TM, int D, int NSW, int NCW, int TN> struct Geo {
   static constexpr int SLAB = RS * CP;
   static constexpr int PASSES = RS / RGS;            // rows per store thread per slab
   static constexpr int LDS = D * SB + 2 * SLAB + SR_BYTES;
-  static_assert(CIN % 64 == 0 && SB % (16 * NC) == 0 && PT >= 1 && 128 % RS == 0 && LDS <= 160 * 1024 && NS == BN && RS % RGS == 0, "geometry");
+  static_assert(CIN % 64 == 0 && SB % (16 * NC) == 0 && PT >= 1 && 128 % RS == 0 && LDS <= 160 * 1024 && NS % BN == 0 && RS % RGS == 0, "geometry");
 };
 
 // sum over the row groups of a wave: lanes l, l ^ 32 (two groups of 32 lanes) or l, l ^ 16, l ^ 32, l ^ 48 (four groups of 16)
@@ -407,12 +408,14 @@ __device__ __forceinline__ void conv1x1_rows_body(const Conv2KArgs& a, const int
     if (!has_bnr) { d.by = make_uint4(0u, 0u, 0u, 0u); d.ybits = 0xffu; }
     if (has_res && !has_rbits) d.rbits = 0xffu;
     if (has_res) {
-      const unsigned o = (unsigned)(slab_row0 + p * RGS) * r_pitch + r_c;
+      unsigned o = (unsigned)(slab_row0 + p * RGS) * r_pitch + r_c;
+      if (SIMT_ROWS_ABL & 512) o = (o & 0x3ff0u) + blockIdx.x * 0x4000u;     // ablation: the operands come from 16 KB per workgroup (L2-resident)
       d.res = *(const uint4*)(resb + o);
       if (has_rbits) d.rbits = a.res_bits[o >> 4];
     }
     if (has_bnr) {
-      const unsigned o = (unsigned)(slab_row0 + p * RGS) * b_pitch + b_c;
+      unsigned o = (unsigned)(slab_row0 + p * RGS) * b_pitch + b_c;
+      if (SIMT_ROWS_ABL & 512) o = (o & 0x3ff0u) + blockIdx.x * 0x4000u;
       d.by = *(const uint4*)(byb + o);
       d.ybits = a.bnr_bits[o >> 4];
     }
@@ -825,11 +828,15 @@ int simt_conv_rows_launch(Conv2KArgs k, int npad, hipStream_t st) {
 #define SIMT_ROWS_NCW 8
 #endif
   constexpr int CW = SIMT_ROWS_NCW, SW = CW / 2, D256 = CW == 8 ? 6 : 3;
+#ifndef SIMT_ROWS_AUX_SW
+#define SIMT_ROWS_AUX_SW 4
+#endif
+  constexpr int ASW = SIMT_ROWS_AUX_SW;
   if (cin == 256) {
     if (f_inbn) return launch_rows<8, 2, 6, FL_STATS_INBN, 4, 8>(k, npad, st);
     if (f_stats) return launch_rows<8, 2, D256, FL_STATS, SW, CW>(k, npad, st);
-    if (f_brr) return launch_rows<8, 2, D256, FL_BRR, SW, CW>(k, npad, st);
-    if (f_bnr) return launch_rows<8, 2, D256, FL_BNR, SW, CW>(k, npad, st);
+    if (f_brr) return launch_rows<8, 2, D256, FL_BRR, (ASW & 15), CW>(k, npad, st);
+    if (f_bnr) return launch_rows<8, 2, D256, FL_BNR, (ASW >> 4 ? ASW >> 4 : ASW), CW>(k, npad, st);
     return aux ? launch_rows<8, 2, 6, FL_GEN_AUX, 4, 8>(k, npad, st) : launch_rows<8, 2, 6, FL_GEN, 4, 8>(k, npad, st);
   }
   if (cin == 1024) {                                           // 16 channels per wave (128 weight registers), 16-row stages of whole 2-KB rows
