@@ -270,7 +270,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dz, const T
 
 // dgamma / dbeta (trainable affine, e.g. torchvision's BatchNorm in model/deeplabv3.py): dbeta = sum g, dgamma = sum g*xhat
 // are exactly the two sums of the backward; written when the pointers are given (dgamma2: the second BN sharing g).
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, long count, float* coef,
+// (launch bounds: 8 waves per SIMD = at most 64 VGPRs.  The weight-gradient launches on the other stream hold 448 of a SIMD's 512 VGPRs on 255 CUs; at
+// 73 VGPRs this kernel's workgroups fitted on the one free CU only: 212 us instead of 7 beside conv_wgrad3_multi_kernel, 12 times per step --
+// profiles/tools/small_kernel_contention.py.  At 64 it takes 10 us there; the step gains little, the wait moves to the next kernel that cannot share a CU.)
+__global__ __launch_bounds__(256, 8) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, long count, float* coef,
                                                              float* dgamma, float* dbeta, float* dgamma2, float* dbeta2) {
   __shared__ double red[32][8][3];
   double s[3];
@@ -334,6 +337,85 @@ __global__ void bn_bwd_apply_kernel(const T* dz, const T* z, const T* y, const f
   }
 }
 
+// The same pass with FOUR channels per thread (bf16, one BatchNorm: every Bottleneck launch of the step), built for at most 64 VGPRs.  Why: the
+// weight-gradient launches on the other stream hold 448 of a SIMD's 512 VGPRs on 255 CUs for ~400 us at a time; the 8-channel kernel above (114
+// VGPRs: five constants x 8 channels) cannot share a CU with them and ran on whatever CUs they left -- 164 us instead of 38 beside
+// conv_wgrad3_multi_kernel, 14 launches per step (profiles/tools/small_kernel_contention.py) -- although one is bound by the matrix pipe and LDS
+// and the other by HBM.  Half the constants and half the data per thread fit beside them.  Same expression per element: bitwise the 8-channel
+// kernel's output (tests/test_gpu_bn_pool.py).  SIMT_BNB_APPLY4=0 (compile time) keeps the 8-channel form.
+#ifndef SIMT_BNB_APPLY4
+#define SIMT_BNB_APPLY4 1
+#endif
+__device__ __forceinline__ void load4(const float* p, float* v) { const float4 a = *(const float4*)p; v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+__device__ __forceinline__ void unpack4(const uint2& r, float* v) {
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+// UN elements of the grid-stride loop per thread are requested before the first is used (beside the weight gradients this kernel gets ONE wave per
+// SIMD: 64 of 512 VGPRs are left).  Measured, same box, four alternating rounds: UN = 1 / 2 / 4 -> 23.42 / 23.45 / 23.62 ms per step against 23.76 for
+// the 8-channel kernel: the 4 096-workgroup grid leaves a thread ~9 elements, so deeper batches only lengthen the ragged last round.  MM: the mask
+// mode, compile time (registers).
+#ifndef SIMT_BNB_APPLY4_UN
+#define SIMT_BNB_APPLY4_UN 1
+#endif
+template <int MM>
+__global__ __launch_bounds__(256, 8) void bn_bwd_apply4_kernel(const bf16_t* dz, const bf16_t* z, const bf16_t* y, const float* mean, const float* rstd,
+                                                               const float* scale, const float* shift, const float* coef, bf16_t* dy, bf16_t* gout,
+                                                               long nvec4, int C) {
+  constexpr int UN = SIMT_BNB_APPLY4_UN;
+  const int vpr = C >> 2;
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;     // (the grid stride is a multiple of vpr: host)
+  const int c = (int)(i0 % vpr) << 2;
+  float mu[4], rs[4], sc[4], c1[4], c2[4], sh[4];
+  load4(mean + c, mu);
+  load4(rstd + c, rs);
+  load4(scale + c, sc);
+  load4(coef + c, c1);
+  load4(coef + C + c, c2);
+  if (MM == 2) load4(shift + c, sh);
+  // 32-bit byte offsets from uniform bases (host: the tensor is < 2 GB): one address register per element in flight
+  const unsigned nb = (unsigned)nvec4 * 8u, Sb = gridDim.x * blockDim.x * 8u;
+  const char* dzb = (const char*)dz; const char* yb = (const char*)y; const char* zb = (const char*)z;
+  char* dyb = (char*)dy; char* gb = (char*)gout;
+  for (unsigned o0 = (unsigned)i0 * 8u; o0 < nb; o0 += Sb * UN) {
+    uint2 gr[UN], yr[UN], zr[UN];
+    unsigned bb[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {                                 // (past the end: the first element again -- loaded, never stored)
+      const unsigned ou = o0 + u * Sb < nb ? o0 + u * Sb : o0;
+      gr[u] = *(const uint2*)(dzb + ou);
+      yr[u] = *(const uint2*)(yb + ou);
+      if (MM == 1) zr[u] = *(const uint2*)(zb + ou);
+      if (MM == 3) bb[u] = (unsigned)((const unsigned char*)zb)[ou >> 4] >> ((ou >> 1) & 4u);      // element ou / 8: byte (ou / 8) / 2, nibble (ou / 8) & 1
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const unsigned ou = o0 + u * Sb;
+      if (ou >= nb) break;
+      float g[4], yv[4];
+      unpack4(gr[u], g);
+      unpack4(yr[u], yv);
+      if (MM == 1) {
+        float zv[4];
+        unpack4(zr[u], zv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = zv[e] > 0.f ? g[e] : 0.f;
+      } else if (MM == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = (yv[e] * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
+      } else if (MM == 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = ((bb[u] >> e) & 1u) ? g[e] : 0.f;
+      }
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = sc[e] * (g[e] - c1[e] - ((yv[e] - mu[e]) * rs[e]) * c2[e]);
+      *(uint2*)(dyb + ou) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+      if (gout) *(uint2*)(gb + ou) = make_uint2(pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]));
+    }
+  }
+}
+
 static inline int bn_bwd_rows_per_block(long M, int C) {
   int rpar = 256 / (C / 8);
   long target_blocks = 512;   // partials are [nblk][3][C] floats re-read by the finalize pass: keep them small
@@ -373,7 +455,18 @@ extern "C" int simt_bn_bwd(const simt_bn_bwd_desc* d, simt_stream_t stream) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 7) / 8), dim3(256), 0, st, d->part, nblk, d->C, d->M, d->coef,
                      d->dgamma, d->dbeta, d->dgamma2, d->dbeta2);
   SIMT_LAUNCH_CHECK();
-  if (d->dtype == SIMT_BF16) {
+  if (SIMT_BNB_APPLY4 && d->dtype == SIMT_BF16 && !d->y2 && nvec * 16 < (1l << 31)) {
+#ifndef SIMT_BNB_APPLY4_CAP
+#define SIMT_BNB_APPLY4_CAP 4096
+#endif
+    long gl = (nvec * 2 + 256l * SIMT_BNB_APPLY4_UN - 1) / (256l * SIMT_BNB_APPLY4_UN);
+    int g4 = (int)(gl > SIMT_BNB_APPLY4_CAP ? SIMT_BNB_APPLY4_CAP : gl < 1 ? 1 : gl);
+    if (d->C / 4 > 256) g4 = (g4 + 1) & ~1;                    // the grid stride (g4 * 256 threads) stays a multiple of C / 4 <= 512
+#define SIMT_BNB4(MM) hipLaunchKernelGGL(bn_bwd_apply4_kernel<MM>, dim3(g4), dim3(256), 0, st, (const bf16_t*)d->dz, (const bf16_t*)d->z, (const bf16_t*)d->y, \
+                                         d->mean, d->rstd, d->scale, d->shift, d->coef, (bf16_t*)d->dy, (bf16_t*)d->gout, nvec * 2, d->C)
+    if (d->mask_mode == 3) SIMT_BNB4(3); else if (d->mask_mode == 2) SIMT_BNB4(2); else if (d->mask_mode == 1) SIMT_BNB4(1); else SIMT_BNB4(0);
+#undef SIMT_BNB4
+  } else if (d->dtype == SIMT_BF16) {
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)d->dz,
                        (const bf16_t*)d->z, (const bf16_t*)d->y, d->mean, d->rstd, d->scale, d->shift, d->coef,
                        (const bf16_t*)d->y2, d->mean2, d->rstd2, d->scale2, (bf16_t*)d->dy, (bf16_t*)d->dy2,

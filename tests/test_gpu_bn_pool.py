@@ -214,3 +214,45 @@ def test_sgd_multi_duplicate_listing_semantics(dev):
         torch.cuda.synchronize()
         for r, p in zip(ref, dp):
             assert rel(p.cpu(), r.detach()) < 2e-6, f"step {step}"
+
+
+@pytest.mark.parametrize("Cn,M", [(64, 5000), (256, 37636), (1024, 1001), (2048, 777), (512, 4 * 97 * 97 + 3)])
+@pytest.mark.parametrize("mask_mode", [0, 1, 2, 3])
+def test_bn_bwd_apply_four_channel_kernel_is_bitwise_the_eight_channel_one(dev, Cn, M, mask_mode):
+    """Round 6: simt_bn_bwd's apply pass for ONE BatchNorm in bf16 runs bn_bwd_apply4_kernel (four channels per thread, <= 64 VGPRs: it shares
+    a CU with the weight-gradient launches of the other stream); with a second BatchNorm (y2: the downsample partner) the call keeps the
+    eight-channel kernel, which writes the FIRST BatchNorm's dy from the same expression.  Same inputs through both: dy, the masked gradient
+    (gout) bit for bit, for every mask mode, ragged row counts and the widest channel count (torch.nn.BatchNorm2d backward,
+    model/deeplab_multi.py:64-76 train mode)."""
+    g = torch.Generator().manual_seed(Cn + M + mask_mode)
+    BF = torch.bfloat16
+    dz = torch.randn(M, Cn, generator=g).to(dev, BF)
+    y = (torch.randn(M, Cn, generator=g) * 2 + 0.3).to(dev, BF)
+    mean = torch.randn(Cn, generator=g).mul(0.2).to(dev)
+    rstd = (torch.rand(Cn, generator=g) + 0.5).to(dev)
+    gamma = (torch.rand(Cn, generator=g) + 0.5).to(dev)
+    scale = gamma * rstd
+    shift = torch.randn(Cn, generator=g).mul(0.3).to(dev) - mean * scale
+    z = None
+    if mask_mode == 1:
+        z = torch.randn(M, Cn, generator=g).to(dev, BF)
+    elif mask_mode == 3:
+        z = torch.randint(0, 256, (M * Cn // 8,), generator=g, dtype=torch.int32).to(torch.uint8).to(dev)
+    nblk = ops.bn_bwd_nblk(M, Cn)
+    out = []
+    for two in (False, True):
+        part = torch.zeros(nblk, 3, Cn, device=dev)
+        coef = torch.zeros(3, Cn, device=dev)
+        dy = torch.full((M, Cn), float("nan"), device=dev, dtype=BF)
+        dy2 = torch.full((M, Cn), float("nan"), device=dev, dtype=BF)
+        gout = torch.full((M, Cn), float("nan"), device=dev, dtype=BF)
+        kw = dict(y2=y, mean2=mean, rstd2=rstd, scale2=scale, dy2=dy2) if two else {}
+        d = ops.make_bn_bwd_desc(dz=dz, y=y, mean=mean, rstd=rstd, scale=scale, shift=shift, part=part, coef=coef, dy=dy, M=M, Cn=Cn,
+                                 mask_mode=mask_mode, z=z, gout=gout, **kw)
+        ops.bn_bwd_desc(d)
+        torch.cuda.synchronize()
+        out.append((dy, gout, coef[:2].clone(), dy2))
+    (dy4, g4, c4, _), (dy8, g8, c8, dy8b) = out
+    assert torch.equal(c4, c8)                                   # the reduce pass is the same kernel either way
+    assert torch.isfinite(dy4.float()).all() and torch.equal(dy4, dy8) and torch.equal(g4, g8)
+    assert torch.equal(dy8b, dy8)                                # (the partner was given the same operands)
