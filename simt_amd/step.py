@@ -84,7 +84,8 @@ class SimTTrainer:
         # SIMT_FROZEN_SPLIT=n (round 6 experiment): the frozen forward as n chains of B / n images each on n side streams.  The frozen net runs in
         # eval mode with folded BatchNorm: every image is independent, so the split changes nothing but the launch geometry -- B / n images are
         # 236 / n one-per-CU workgroups per wide conv, and n such launches FIT the chip side by side (two full-batch launches do not: 2 x 236 > 256),
-        # so one chain's prologue / epilogue can overlap the other's K loop
+        # so one chain's prologue / epilogue can overlap the other's K loop.  Measured +0.65 / +1.65 ms; needs SIMT_DIRECT_STEM=0 (the parts take their
+        # rows of the trainable plan's im2col matrix), ignored otherwise
         self._fixed_parts, self._side2 = None, []
         import os
         nsp = int(os.environ.get("SIMT_FROZEN_SPLIT", "1"))
