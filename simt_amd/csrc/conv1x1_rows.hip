@@ -828,6 +828,9 @@ int simt_conv_rows_launch(Conv2KArgs k, int npad, hipStream_t st) {
 #define SIMT_ROWS_NCW 8
 #endif
   constexpr int CW = SIMT_ROWS_NCW, SW = CW / 2, D256 = CW == 8 ? 6 : 3;
+  // SIMT_ROWS_AUX_SW (compile-time A/B): store waves of the residual flavours at Cin = 256 -- low nibble: bias + residual + ReLU, high nibble (or the
+  // same value): bit-masked residual + BatchNorm-backward reduce.  8 = the 1 024-thread form (two rows per store thread and slab, 124 / 128 VGPRs):
+  // parity green, measured no change (61.7 / 42.5 us: profiles/r06_rows_aux.txt -- the store path's vector work does not hide under the MFMAs whoever issues it)
 #ifndef SIMT_ROWS_AUX_SW
 #define SIMT_ROWS_AUX_SW 4
 #endif

@@ -351,8 +351,8 @@ extern "C" int simt_stem7_fwd(const simt_stem_desc* d, simt_stream_t stream) {
     SIMT_CHECK(d->w[s] && d->y[s]);
     a.w[s] = (const bf16_t*)d->w[s]; a.y[s] = (bf16_t*)d->y[s]; a.bias[s] = d->bias[s]; a.relu[s] = d->relu[s]; a.stats[s] = d->stats[s];
   }
-  static bool attr_done = false;
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)stem7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS); attr_done = true; }
+  static SimtLdsAttrCache attr_cache;                       // (per device: the attribute is the device's, a process may drive several)
+  if (simt_lds_attr_needed(&attr_cache, STEM_LDS)) (void)hipFuncSetAttribute((const void*)stem7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS);
   const int ntiles = a.B * a.tiles_y * a.tiles_x;
   SIMT_CHECK(!(d->nsets == 2 && d->stats[0] && d->stats[1]));      // statistics for one set per launch
   hipLaunchKernelGGL(stem7_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(512), STEM_LDS, (hipStream_t)stream, a, ntiles);
@@ -372,8 +372,8 @@ extern "C" int simt_stem7_wgrad(const float* x, const void* dy, float* part, flo
   w.x = x; w.dy = (const bf16_t*)dy; w.part = part; w.B = B; w.H = H; w.W = W; w.Ho = Ho; w.Wo = Wo;
   w.tiles_y = (Ho + TH - 1) / TH; w.tiles_x = (Wo + TW - 1) / TW;
   const int ntiles = B * w.tiles_y * w.tiles_x, nwg = ntiles < 256 ? ntiles : 256;
-  static bool attr_done = false;
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)stem7_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS); attr_done = true; }
+  static SimtLdsAttrCache attr_cache;
+  if (simt_lds_attr_needed(&attr_cache, WG_LDS)) (void)hipFuncSetAttribute((const void*)stem7_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS);
   hipLaunchKernelGGL(stem7_wgrad_kernel, dim3(nwg), dim3(512), WG_LDS, (hipStream_t)stream, w, ntiles);
   hipLaunchKernelGGL(stem7_wgrad_reduce_kernel, dim3(64 * 7 * 32 / 64), dim3(64, 16), 0, (hipStream_t)stream, (const float*)part, nwg, dw);
   SIMT_LAUNCH_CHECK();
