@@ -287,6 +287,11 @@ class SimTTrainer:
                 self._fwd_both = self._paired_forwards()
             with trace.range("forward + frozen-forward (one launch per layer for both networks)"):
                 self._fwd_both.run()
+        elif order == "paced" and not self._fixed_graph:
+            if self._fwd_both is None:
+                self._fwd_both = self._paced_forwards()
+            with trace.range("forward + frozen-forward (frozen 3x3 convs paced behind the trainable conv3s)"):
+                self._fwd_both.run()
         elif order in ("bnside", "bnside2") and not self._fixed_graph:
             if self._fwd_both is None:
                 self._fwd_both = self._bn_side_forwards()
@@ -544,6 +549,68 @@ class SimTTrainer:
             frozen_upto_next_conv()
         if ev_bn is not None:
             both.wait(ev_bn, 0)
+        return both
+
+    def _paced_forwards(self):
+        """Both forwards as ONE launch list on the two streams (round 6, SIMT_FWD_ORDER=paced): the trainable net on the main stream exactly as in
+        the default order, the frozen net on the side stream -- but its k-th 3x3 conv waits for an event recorded behind the trainable net's k-th
+        conv3.  What follows that conv3 on the main stream is the finalize and the wide bn3 + residual + ReLU pass (231 MB, HBM-bound, no LDS, 53
+        VGPRs: it shares a CU with a conv workgroup), and a BatchNorm pass hides half of itself under a 3x3 conv and nothing under the K = 1024
+        1x1 conv (profiles/r06_corun.txt).  In the default order the host enqueues the frozen forward behind the trainable one and it runs after
+        it, alone (profiles/tools/queue_gaps.py: 4.1 ms), so that pairing never happens.  ONE cross-queue edge per Bottleneck, on the queue that
+        has the slack (the frozen chain is ~100 us per Bottleneck against ~170 us): the main stream never waits for the side stream before the end
+        of the forward (model/deeplab_multi.py:81-101; tools/trainV2_simt.py:351-353,370)."""
+        import re
+        from .engine import _Launch
+        lib = L.load()
+        both = LaunchList()
+        conv = lib.simt_conv_fprop
+        t_items = list(self._fwd_rest.items)
+        f_items = [_Launch(g.fn, g.args, g.keep, g.tag, g.flops, g.bytes, g.shape, stream=1) for g in self.fixed.fwd_list.items]
+        f_items.append(_Launch(lib.simt_softmax_rows, (ops._p(self.fixed.out["x2"]), self.ldf, ops._p(self.fixp), self.ldf, self.B * self.h * self.w,
+                                                       self.C), (self.fixed.out["x2"], self.fixp), "simt_softmax_rows", stream=1))
+        assert all(it.fn is not None and it.stream == 0 for it in t_items)
+
+        def is_conv2(it):
+            return it.fn is conv and " taps9 " in f" {it.shape or ''} " and "tap-expanded" not in (it.shape or "")
+
+        def is_conv3(it):
+            m = re.search(r"N(\d+) K(\d+) taps1 ", f"{it.shape or ''} ") if it.fn is conv else None
+            return bool(m) and int(m.group(1)) == 4 * int(m.group(2))
+        # (layer1.0's downsample conv has conv3's shape: a Bottleneck's conv3 is the first such conv BEHIND its 3x3 conv)
+        marks, armed = set(), False
+        for i, it in enumerate(t_items):
+            if is_conv2(it):
+                armed = True
+            elif armed and is_conv3(it):
+                marks.add(i)
+                armed = False
+        n2 = sum(1 for it in f_items if is_conv2(it))
+        assert n2 == len(marks) and n2 > 0, (n2, len(marks))
+        fi = 0
+
+        def frozen_until_next_conv2(ev):
+            """the frozen net's launches up to (not including) its next 3x3 conv; the first of them -- a 3x3 conv -- behind `ev`"""
+            nonlocal fi
+            if fi < len(f_items) and ev is not None:
+                both.wait(ev, 1)
+            first = True
+            while fi < len(f_items) and (first or not is_conv2(f_items[fi])):
+                both.items.append(f_items[fi])
+                fi += 1
+                first = False
+        # the frozen net's head of list (stem pool, conv1 of the first Bottleneck): free-running beside the trainable stem
+        while fi < len(f_items) and not is_conv2(f_items[fi]):
+            both.items.append(f_items[fi])
+            fi += 1
+        for i, it in enumerate(t_items):
+            both.items.append(it)
+            if i in marks:
+                frozen_until_next_conv2(both.record(0))
+        while fi < len(f_items):
+            both.items.append(f_items[fi])
+            fi += 1
+        both.wait(both.record(1), 0)                 # the head needs the frozen posterior
         return both
 
     def _capture_graphs(self):

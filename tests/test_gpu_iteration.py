@@ -301,6 +301,7 @@ def test_early_sgd_and_schedule_switches_same_trajectory(dev, monkeypatch):
                 {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "1", "SIMT_FWD_ORDER": "main"}, {"SIMT_EARLY_SGD": "0", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "interleave"},
                 {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "pair"},       # round 5, opt-in (the default order stays "main"): one launch per layer for both networks
                 {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "bnside2"},
+                {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "paced"},       # round 6: the frozen 3x3 convs released behind the trainable conv3s
                 {"SIMT_EARLY_SGD": "1", "SIMT_GRAPHS": "-1", "SIMT_FWD_ORDER": "main", "SIMT_LIGHT_EVENTS": "0"}):      # torch.cuda.Event instead of the device-scope events
         monkeypatch.delenv("SIMT_LIGHT_EVENTS", raising=False)
         for k, v in env.items():
